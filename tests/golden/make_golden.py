@@ -1,0 +1,397 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REFERENCE itself.
+
+Runs ONLY in the authoring container (needs /root/reference, read-only).  The reference's
+``Decoder`` class is imported by file path (it needs nothing but torch) and driven with the exact
+torch call sequence of the reference's step body (train_deep_sdf.py:483-545): ``nn.Embedding(max_norm)``
+lookup, ``torch.cat``, ``decoder(input)``, ``torch.clamp``, ``L1Loss(sum)/N``, code regulariser,
+``backward()``, ``torch.optim.Adam`` with two parameter groups.  Outputs are DATA ONLY (.npz):
+inputs + expected outputs.  No reference source, bytecode or TorchScript is written anywhere.
+
+Dropout: the reference's ``F.dropout`` is replaced, for the duration of a forward, by a function that
+applies the hash masks of ``oracle.deepsdf_oracle.dropout_keep`` (the HIP kernels' mask spec), so a
+training-mode golden is reproducible by any implementation of that integer hash.
+
+Usage:  python tests/golden/make_golden.py          (writes tests/golden/g*.npz)
+"""
+import importlib.util
+import json
+import math
+import os
+import sys
+import zipfile
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import deepsdf_oracle as orc  # noqa: E402
+
+REF = "/root/reference"
+
+
+def ref_decoder_cls():
+    spec = importlib.util.spec_from_file_location(
+        "ref_deep_sdf_decoder", os.path.join(REF, "deep_sdf/networks/deep_sdf_decoder.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.Decoder
+
+
+class MaskInjector:
+    """Context manager: F.dropout(x, p, training) -> x * mask/(1-p) with queued masks (call order =
+    layer order, deep_sdf_decoder.py:105-106)."""
+
+    def __init__(self, masks):
+        self.q = [m for m in masks if m is not None]
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        self.F = F
+        self.orig = F.dropout
+        q = self.q
+
+        def fake(x, p=0.5, training=True, inplace=False):
+            if not training or p == 0.0:
+                return x
+            m = q.pop(0)
+            assert m.shape == x.shape, (m.shape, x.shape)
+            return x * m.to(x.dtype) * (1.0 / (1.0 - p))
+
+        F.dropout = fake
+        return self
+
+    def __exit__(self, *a):
+        self.F.dropout = self.orig
+        assert not self.q, "unused masks"
+
+
+def build_ref(Decoder, latent_size, net_specs, params):
+    dec = Decoder(latent_size, **net_specs)
+    sd = dec.state_dict()
+    assert list(sd.keys()) == list(params.keys()), (list(sd.keys()), list(params.keys()))
+    dec.load_state_dict({k: v.clone() for k, v in params.items()})
+    return dec
+
+
+def ref_step(dec, lat, opt, batches, *, delta, lam, epoch, code_reg, masks_per_chunk, train=True, grad_clip=None):
+    """train_deep_sdf.py:483-545 for one optimiser step.  ``batches`` = list of (indices, xyz, sdf_gt) chunks
+    (already chunked as torch.chunk would, :495-501)."""
+    n_total = sum(b[1].shape[0] for b in batches)
+    dec.train(train)
+    opt.zero_grad()
+    loss_l1 = torch.nn.L1Loss(reduction="sum")
+    batch_loss = 0.0
+    ys = []
+    for ci, (idx, xyz, gt) in enumerate(batches):
+        gt = torch.clamp(gt, -delta, delta)
+        batch_vecs = lat(idx)
+        inp = torch.cat([batch_vecs, xyz], dim=1)
+        masks = masks_per_chunk[ci] if masks_per_chunk is not None else []
+        with MaskInjector(masks):
+            pred = dec(inp)
+        ys.append(pred.detach().clone())
+        pred = torch.clamp(pred, -delta, delta)
+        chunk_loss = loss_l1(pred, gt) / n_total
+        if code_reg:
+            l2 = torch.sum(torch.norm(batch_vecs, dim=1))
+            chunk_loss = chunk_loss + (lam * min(1, epoch / 100) * l2) / n_total
+        chunk_loss.backward()
+        batch_loss += chunk_loss.item()
+    grads = {k: p.grad.detach().clone() for k, p in dec.named_parameters()}
+    dlat = lat.weight.grad.detach().clone()
+    gn = None
+    if grad_clip is not None:
+        gn = torch.nn.utils.clip_grad_norm_(dec.parameters(), grad_clip)
+        grads_clipped = {k: p.grad.detach().clone() for k, p in dec.named_parameters()}
+    else:
+        grads_clipped = None
+    opt.step()
+    return batch_loss, torch.cat(ys), grads, dlat, gn, grads_clipped
+
+
+def pack(prefix, d):
+    # .clone(): live parameters / Adam buffers keep mutating after this call; snapshot them
+    return {f"{prefix}/{k}": (v.detach().clone().numpy() if torch.is_tensor(v) else np.array(v)) for k, v in d.items()}
+
+
+def synth_batch(gen, scenes, S, G=3):
+    """[B scenes] x S points: xyz ~ U(-1,1), sdf = ||x - c|| - r (clamp exercised: many |sdf| < 0.1)."""
+    idx, xyz, gt = [], [], []
+    for s in scenes:
+        c = (torch.rand(G, generator=gen) - 0.5) * 0.6
+        r = 0.3 + 0.3 * torch.rand(1, generator=gen)
+        half = S // 2
+        box = torch.rand(half, G, generator=gen) * 2 - 1
+        d = torch.randn(S - half, G, generator=gen)
+        d = d / d.norm(dim=1, keepdim=True)
+        surf = c + r * d + 0.05 * torch.randn(S - half, G, generator=gen)
+        p = torch.cat([box, surf])
+        xyz.append(p)
+        gt.append((p - c).norm(dim=1, keepdim=True) - r)
+        idx.append(torch.full((S,), s, dtype=torch.int64))
+    return torch.cat(idx), torch.cat(xyz).float(), torch.cat(gt).float()
+
+
+def margins_ok(dec_net, params, x0, gt, delta, masks=None, training=False, tol=2e-5):
+    """Reject batches where a ReLU pre-activation or |y|-delta sits within tol of its threshold."""
+    p64 = {k: v.double() for k, v in params.items()}
+    _, sv = orc.decoder_forward(dec_net, p64, x0.double(), training=training, masks=masks)
+    # clamp boundary and sign(pred - gt) flips switch a whole point's gradient: keep a hard margin there
+    if ((sv.y.abs() - delta).abs() < tol).any():
+        return False
+    if gt is not None:
+        diff = torch.clamp(sv.y, -delta, delta) - torch.clamp(gt.double().reshape(-1, 1), -delta, delta)
+        if ((diff != 0) & (diff.abs() < tol)).any():
+            return False
+    # a ReLU flip only moves one unit of one point (forward is continuous): checked on small nets only
+    n_pre = sum(ly.out_dim for ly in dec_net.layers[:-1]) * x0.shape[0]
+    if n_pre <= 50000:
+        Wb = orc.effective_weights(dec_net, p64)
+        for l in range(dec_net.n_lin - 1):
+            pre = sv.inputs[l] @ Wb[l][0].t() + Wb[l][1]
+            if (pre.abs() < 1e-6).any():
+                return False
+    return True
+
+
+def case_train(Decoder, name, *, L, net_specs, S_tot, scenes_steps, S, seed, delta=0.1, lam=1e-4,
+               epoch=37, code_bound=1.0, code_reg=True, lr=(5e-4, 1e-3), batch_split=1, dropout_train=False,
+               drop_seed=0, grad_clip=None, store="full", oversize_row=None):
+    """Run len(scenes_steps) optimiser steps on the reference; store inputs + expected outputs."""
+    net = orc.make_net(L, **net_specs)
+    params = orc.init_params(net, seed)
+    gen = torch.Generator().manual_seed(seed + 1)
+    lat0 = torch.randn(S_tot, L, generator=gen) * (1.0 / math.sqrt(L))
+    if oversize_row is not None:
+        lat0[oversize_row] *= 3.0 / lat0[oversize_row].norm()   # norm 3 > CodeBound -> renorm must fire
+    dec = build_ref(Decoder, L, net_specs, params)
+    lat = torch.nn.Embedding(S_tot, L, max_norm=code_bound)
+    lat.weight.data.copy_(lat0)
+    opt = torch.optim.Adam([{"params": dec.parameters(), "lr": lr[0]}, {"params": lat.parameters(), "lr": lr[1]}])
+    out = {"meta": np.frombuffer(json.dumps(dict(
+        L=L, net_specs=net_specs, S_tot=S_tot, S=S, seed=seed, delta=delta, lam=lam, epoch=epoch,
+        code_bound=code_bound, code_reg=code_reg, lr=list(lr), batch_split=batch_split,
+        dropout_train=dropout_train, drop_seed=drop_seed, grad_clip=grad_clip, store=store,
+        n_steps=len(scenes_steps))).encode(), dtype=np.uint8)}
+    out.update(pack("lat0", {"w": lat0}))
+    if store == "full":
+        out.update(pack("params0", params))
+    for si, scenes in enumerate(scenes_steps):
+        for attempt in range(20):
+            idx, xyz, gt = synth_batch(gen, scenes, S)
+            chunks = list(zip(torch.chunk(idx, batch_split), torch.chunk(xyz, batch_split), torch.chunk(gt, batch_split)))
+            masks_pc, row0 = None, 0
+            if dropout_train:
+                masks_pc = []
+                for (ci, xc, gc) in chunks:
+                    masks_pc.append(orc.dropout_masks(net, drop_seed, si, xc.shape[0], row_offset=row0))
+                    row0 += xc.shape[0]
+            # margin check on the concatenated batch with the CURRENT reference params
+            cur = {k: v.detach().clone() for k, v in dec.state_dict().items()}
+            lat_probe = lat.weight.detach().clone()
+            orc.renorm_rows_(lat_probe, idx, code_bound)
+            x0 = torch.cat([lat_probe[idx], xyz], 1)
+            mm = None
+            if dropout_train:  # chunk masks continue the row counter, so their concatenation is this
+                mm = orc.dropout_masks(net, drop_seed, si, xyz.shape[0], row_offset=0)
+            if margins_ok(net, cur, x0, gt, delta, masks=mm, training=dropout_train):
+                break
+        else:
+            raise RuntimeError("could not draw a batch with safe margins")
+        loss, y, grads, dlat, gn, gclip = ref_step(dec, lat, opt, chunks, delta=delta, lam=lam, epoch=epoch,
+                                                   code_reg=code_reg, masks_per_chunk=masks_pc,
+                                                   train=dropout_train or True, grad_clip=grad_clip)
+        pre = f"step{si}"
+        out.update(pack(pre + "/in", {"idx": idx, "xyz": xyz, "gt": gt}))
+        out.update(pack(pre + "/out", {"loss": np.float64(loss), "y": y.reshape(-1)}))
+        out.update(pack(pre + "/dlat", {"w": dlat}))
+        out.update(pack(pre + "/lat_after", {"w": lat.weight.detach()}))
+        if gn is not None:
+            out.update(pack(pre + "/out", {"grad_norm": gn}))
+        if store == "full":
+            out.update(pack(pre + "/grads", grads))
+            out.update(pack(pre + "/params_after", dict(dec.state_dict())))
+            st = opt.state_dict()["state"]
+            names = list(dict(dec.named_parameters()).keys()) + ["latent"]
+            for i, nme in enumerate(names):
+                out.update(pack(f"{pre}/adam_m", {nme: st[i]["exp_avg"]}))
+                out.update(pack(f"{pre}/adam_v", {nme: st[i]["exp_avg_sq"]}))
+        else:  # "slice": small tensors in full, big ones as corner + Frobenius norm
+            for k, g in grads.items():
+                if g.numel() <= 4096:
+                    out.update(pack(pre + "/grads", {k: g}))
+                else:
+                    out.update(pack(pre + "/grads_corner", {k: g[:8, :8]}))
+                    out.update(pack(pre + "/grads_fro", {k: g.double().norm()}))
+            for k, p_ in dec.state_dict().items():
+                if p_.numel() <= 4096:
+                    out.update(pack(pre + "/params_after", {k: p_}))
+                else:
+                    out.update(pack(pre + "/params_after_corner", {k: p_[:8, :8]}))
+                    out.update(pack(pre + "/params_after_fro", {k: p_.double().norm()}))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, {k: v.shape for k, v in list(out.items())[:0]})
+
+
+def case_forward_eval(Decoder, name, *, L, net_specs, N, seed):
+    """Eval-mode forward only (decode_sdf semantics, deep_sdf/utils.py:54-65)."""
+    net = orc.make_net(L, **net_specs)
+    params = orc.init_params(net, seed)
+    gen = torch.Generator().manual_seed(seed + 7)
+    x = torch.cat([torch.randn(N, L, generator=gen) / math.sqrt(L), torch.rand(N, 3, generator=gen) * 2 - 1], 1)
+    dec = build_ref(Decoder, L, net_specs, params).eval()
+    with torch.no_grad():
+        y = dec(x)
+    out = {"meta": np.frombuffer(json.dumps(dict(L=L, net_specs=net_specs, N=N, seed=seed)).encode(), dtype=np.uint8)}
+    out.update(pack("in", {"x": x}))
+    out.update(pack("out", {"y": y.reshape(-1)}))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name)
+
+
+def case_lr(name):
+    """G5: schedule values from the reference's schedule classes' formulas, evaluated by the reference
+    code itself is impossible without importing train_deep_sdf.py (needs matplotlib etc.); the formulas
+    (train_deep_sdf.py:28-56) are three one-liners, so this golden stores hand-evaluated doubles."""
+    specs = [
+        {"Type": "Step", "Initial": 0.0005, "Interval": 500, "Factor": 0.5},
+        {"Type": "Step", "Initial": 0.001, "Interval": 500, "Factor": 0.5},
+        {"Type": "Warmup", "Initial": 1e-5, "Final": 1e-3, "Length": 500},
+        {"Type": "Constant", "Value": 3e-4},
+    ]
+    epochs = [0, 1, 499, 500, 501, 1000, 2001]
+    # literal python arithmetic of the reference's get_learning_rate bodies
+    vals = []
+    for s in specs:
+        row = []
+        for e in epochs:
+            if s["Type"] == "Step":
+                row.append(s["Initial"] * (s["Factor"] ** (e // s["Interval"])))
+            elif s["Type"] == "Warmup":
+                row.append(s["Final"] if e > s["Length"] else s["Initial"] + (s["Final"] - s["Initial"]) * e / s["Length"])
+            else:
+                row.append(s["Value"])
+        vals.append(row)
+    with open(os.path.join(HERE, name + ".json"), "w") as f:
+        json.dump({"specs": specs, "epochs": epochs, "values": vals}, f, indent=1)
+    print("wrote", name)
+
+
+def case_real_weights(name):
+    """G6: real trained weights shipped by the reference
+    (experiments/corner_spheres_only_small_network/cpp_model.pt).  torch.load(weights_only=True) REFUSES
+    TorchScript archives, and torch.jit.load would deserialise code from the file, so the raw tensor
+    storages are read as plain bytes with zipfile (nothing from the file is executed).  Storage order
+    follows state_dict order (bias, g, v per layer); the assignment is validated against the per-parameter
+    norms the reference logged at the same epoch (Logs.pth 'param_magnitude', safe-loaded)."""
+    exp = os.path.join(REF, "experiments/corner_spheres_only_small_network")
+    specs = json.load(open(os.path.join(exp, "specs.json")))
+    L = specs["CodeLength"]
+    ns = dict(specs["NetworkSpecs"])
+    net = orc.make_net(L, **ns)
+    names = orc.param_names(net)
+    shapes = {}
+    for l, ly in enumerate(net.layers):
+        shapes[f"lin{l}.bias"] = (ly.out_dim,)
+        shapes[f"lin{l}.parametrizations.weight.original0"] = (ly.out_dim, 1)
+        shapes[f"lin{l}.parametrizations.weight.original1"] = (ly.out_dim, ly.in_dim)
+        shapes[f"lin{l}.weight"] = (ly.out_dim, ly.in_dim)
+    z = zipfile.ZipFile(os.path.join(exp, "cpp_model.pt"))
+    params = {}
+    for i, nme in enumerate(names):
+        raw = np.frombuffer(z.read(f"cpp_model/data/{i}"), dtype="<f4")
+        assert raw.size == int(np.prod(shapes[nme])), (nme, raw.size, shapes[nme])
+        params[nme] = torch.from_numpy(raw.reshape(shapes[nme]).copy())
+    logs = torch.load(os.path.join(exp, "Logs.pth"), weights_only=True)
+    pm = logs["param_magnitude"]
+    check = {}
+    for nme in names:
+        logged = float(pm[nme][-1])
+        mine = float(params[nme].norm())
+        check[nme] = (logged, mine)
+    y0, _ = orc.decoder_forward(net, params, torch.zeros(1, L + ns["geom_dimension"]), training=False)
+    out = {"meta": np.frombuffer(json.dumps(dict(L=L, net_specs=ns, f0_survey=-0.1340,
+                                                 logged_norms={k: v[0] for k, v in check.items()})).encode(), dtype=np.uint8)}
+    out.update(pack("params", params))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, "f(0)=", float(y0), "norm check (logged, extracted):")
+    for k, v in check.items():
+        print("   ", k, v)
+
+
+def case_latent_only(Decoder, name, *, L, net_specs, N, iters, seed, delta=0.1, lr=5e-3, l2reg=1e-4):
+    """G7 (config 4 / SURVEY a9): frozen eval-mode reference Decoder + torch.optim.Adam([z])."""
+    net = orc.make_net(L, **net_specs)
+    params = orc.init_params(net, seed)
+    dec = build_ref(Decoder, L, net_specs, params).eval()
+    for p in dec.parameters():
+        p.requires_grad_(False)
+    gen = torch.Generator().manual_seed(seed + 3)
+    z = (torch.randn(1, L, generator=gen) * 0.01).requires_grad_(True)
+    z0 = z.detach().clone()
+    opt = torch.optim.Adam([z], lr=lr)
+    out = {"meta": np.frombuffer(json.dumps(dict(L=L, net_specs=net_specs, N=N, iters=iters, seed=seed,
+                                                 delta=delta, lr=lr, l2reg=l2reg)).encode(), dtype=np.uint8)}
+    out.update(pack("params0", params))
+    out.update(pack("z0", {"z": z0}))
+    l1 = torch.nn.L1Loss()
+    for it in range(iters):
+        _, xyz, gt = synth_batch(gen, [0], N)
+        opt.zero_grad()
+        inp = torch.cat([z.expand(N, -1), xyz], 1)
+        pred = torch.clamp(dec(inp), -delta, delta)
+        loss = l1(pred, torch.clamp(gt, -delta, delta)) + l2reg * torch.mean(z.pow(2))
+        loss.backward()
+        opt.step()
+        out.update(pack(f"it{it}", {"xyz": xyz, "gt": gt, "loss": np.float64(loss.item()),
+                                    "dz": z.grad.detach().clone(), "z_after": z.detach().clone()}))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name)
+
+
+def main():
+    torch.set_num_threads(4)
+    Decoder = ref_decoder_cls()
+    wn4 = dict(dims=[64] * 4, dropout=[0, 1, 2, 3], dropout_prob=0.0, norm_layers=[0, 1, 2, 3], latent_in=[2],
+               xyz_in_all=False, use_tanh=False, latent_dropout=False, weight_norm=True, geom_dimension=3)
+    # G1a: tiny-full, 2 steps; step 1 omits scene 2 (dense Adam on an absent row); row 1 starts above CodeBound
+    case_train(Decoder, "g1a_tiny_full", L=4, net_specs=wn4, S_tot=3, scenes_steps=[[0, 1, 2], [0, 1]], S=32,
+               seed=11, oversize_row=1)
+    # G1b: last layer weight-normed too (norm_layers covers it) + use_tanh (tanh o tanh), as shipped small nets
+    wn4b = dict(wn4, norm_layers=[0, 1, 2, 3, 4, 5, 6, 7], use_tanh=True, latent_in=[1], dims=[32] * 4)
+    case_train(Decoder, "g1b_lastnorm_tanh", L=2, net_specs=wn4b, S_tot=2, scenes_steps=[[0, 1], [1, 0]], S=40, seed=12)
+    # G1c: no weight norm at all, no skip, no code bound, no regulariser, grad clipping on
+    plain = dict(dims=[48] * 3, dropout=None, dropout_prob=0.0, norm_layers=(), latent_in=(), xyz_in_all=False,
+                 use_tanh=False, latent_dropout=False, weight_norm=False, geom_dimension=3)
+    case_train(Decoder, "g1c_plain_clip", L=5, net_specs=plain, S_tot=2, scenes_steps=[[0, 1]], S=48, seed=13,
+               code_bound=None, code_reg=False, grad_clip=0.05)
+    # G2: the 8x512 benchmark architecture, 256-point slice
+    big = dict(dims=[512] * 8, dropout=[0, 1, 2, 3, 4, 5, 6, 7], dropout_prob=0.0, norm_layers=[0, 1, 2, 3, 4, 5, 6, 7],
+               latent_in=[4], xyz_in_all=False, use_tanh=False, latent_dropout=False, weight_norm=True, geom_dimension=3)
+    case_train(Decoder, "g2_8x512_slice", L=256, net_specs=big, S_tot=4, scenes_steps=[[0, 1, 2, 3]], S=64, seed=21,
+               store="slice", oversize_row=2)
+    # G3: dropout-injected training mode (hash masks), small + 8x512
+    wn4d = dict(wn4, dropout_prob=0.2)
+    case_train(Decoder, "g3a_dropout_tiny", L=4, net_specs=wn4d, S_tot=3, scenes_steps=[[0, 1, 2], [2, 0, 1]], S=32, seed=31,
+               dropout_train=True, drop_seed=1234)
+    bigd = dict(big, dropout_prob=0.2)
+    case_train(Decoder, "g3b_dropout_8x512", L=256, net_specs=bigd, S_tot=4, scenes_steps=[[0, 1, 2, 3]], S=64, seed=32,
+               dropout_train=True, drop_seed=99, store="slice")
+    # G4: batch_split=2 (chunk boundary inside a scene: 3 scenes x 32 pts -> chunks of 48)
+    case_train(Decoder, "g4_batch_split2", L=4, net_specs=wn4d, S_tot=3, scenes_steps=[[0, 1, 2]], S=32, seed=41,
+               batch_split=2, dropout_train=True, drop_seed=7)
+    case_lr("g5_lr_schedules")
+    case_real_weights("g6_real_weights")
+    case_latent_only(Decoder, "g7_latent_only", L=8, net_specs=dict(wn4, latent_in=[2]), N=96, iters=5, seed=71)
+    case_forward_eval(Decoder, "g8_eval_8x512", L=256, net_specs=bigd, N=128, seed=81)
+    case_forward_eval(Decoder, "g8_eval_6x128", L=1, net_specs=dict(
+        dims=[128] * 6, dropout=list(range(8)), dropout_prob=0.2, norm_layers=list(range(8)), latent_in=[2],
+        xyz_in_all=False, use_tanh=False, latent_dropout=False, weight_norm=True, geom_dimension=3), N=100, seed=82)
+
+
+if __name__ == "__main__":
+    main()
