@@ -1,0 +1,3 @@
+"""deepsdf_amd -- MI355X-native DeepSDF auto-decoder training step (HIP kernels behind a C ABI) with the
+reference's specs.json / experiment-directory host API.  See DESIGN.md."""
+__version__ = "0.1.0"

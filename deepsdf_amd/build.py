@@ -1,0 +1,41 @@
+"""Build libdsdf_hip.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc.  No torch involved."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "dsdf_api.hip")
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("dsdf_api.hip", "gemm.hpp", "kernels.hpp", "common.hpp")] + [
+    os.path.join(os.path.dirname(HERE), "include", "dsdf.h")]
+LIB = os.path.join(HERE, "libdsdf_hip.so")
+
+
+def hipcc_path():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build_library(force=False, verbose=False):
+    """Compile csrc/dsdf_api.hip -> deepsdf_amd/libdsdf_hip.so for gfx950.  Returns the library path."""
+    if not force and not is_stale():
+        return LIB
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

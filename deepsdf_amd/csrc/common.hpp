@@ -1,0 +1,64 @@
+// common.hpp -- shared device helpers for libdsdf_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dsdf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// 32-bit avalanche mix; specification: oracle/deepsdf_oracle.py _lowbias32
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
+}
+
+// dropout keep bit of element (grow, col); ck = lowbias32(col * 0x85EBCA77 + key) is per column.
+// One hash serves rows 2q and 2q+1 (low / high 16 bits).  Spec: oracle dropout_keep.
+__device__ __forceinline__ uint32_t drop_col_key(uint32_t col, uint32_t key) {
+  return lowbias32(col * 0x85EBCA77u + key);
+}
+__device__ __forceinline__ uint32_t drop_pair_hash(uint32_t ck, uint32_t grow) {
+  return lowbias32(ck ^ ((grow >> 1) * 0x9E3779B1u));
+}
+__device__ __forceinline__ bool drop_keep(uint32_t h, uint32_t grow, uint32_t thr16) {
+  const uint32_t bits = (grow & 1u) ? (h >> 16) : (h & 0xFFFFu);
+  return bits >= thr16;
+}
+
+// Blocks b and b+8 share an XCD (round-robin dispatch, observed; speed only).  Give every XCD a
+// contiguous range of logical ids so that neighbouring tiles (which share operand panels) hit one L2.
+// Bijective for any nwg.
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = b & 7, s = b >> 3;
+  const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + s;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// deterministic block-wide sum for 256-thread blocks; result valid in every thread
+__device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 floats of LDS */) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__device__ __forceinline__ void zero_tail4(float4& v, int rem) {  // keep the first `rem` elements
+  if (rem < 4) v.w = 0.f;
+  if (rem < 3) v.z = 0.f;
+  if (rem < 2) v.y = 0.f;
+  if (rem < 1) v.x = 0.f;
+}
+
+}  // namespace dsdf

@@ -1,0 +1,685 @@
+// dsdf_api.hip -- the C ABI of libdsdf_hip.so (include/dsdf.h): workspace planning + launch sequencing.
+// No device allocation, no synchronisation, no global mutable state (thread-local error string only).
+#include "../../include/dsdf.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "gemm.hpp"
+#include "kernels.hpp"
+
+using namespace dsdf;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_OK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) return fail(DSDF_E_LAUNCH, "%s failed: %s", #expr, hipGetErrorString(e_));   \
+  } while (0)
+#define LAUNCH_OK(name)                                                                                \
+  do {                                                                                                 \
+    hipError_t e_ = hipGetLastError();                                                                 \
+    if (e_ != hipSuccess) return fail(DSDF_E_LAUNCH, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
+  } while (0)
+#define TRY(expr)            \
+  do {                       \
+    int rc_ = (expr);        \
+    if (rc_ != 0) return rc_; \
+  } while (0)
+
+inline int64_t rup(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+constexpr int NSPLIT_MAX = 32;     // split-K factor of the dW GEMMs
+constexpr int LAST_BLOCKS_MAX = 1024;
+constexpr int LAST_GROUPS = 16;    // second-stage partial groups of the last-layer reduction
+
+int validate(const DsdfNet* n) {
+  if (!n) return fail(DSDF_E_INVALID, "net is NULL");
+  if (n->n_layers < 2 || n->n_layers > DSDF_MAX_LAYERS) return fail(DSDF_E_INVALID, "n_layers %d out of range", n->n_layers);
+  const int W0 = n->latent_size + n->geom_dim;
+  if (n->latent_size < 0 || n->geom_dim < 1) return fail(DSDF_E_INVALID, "bad latent_size/geom_dim");
+  if (n->in_dim[0] != W0) return fail(DSDF_E_INVALID, "in_dim[0] %d != latent_size+geom_dim %d", n->in_dim[0], W0);
+  if (n->out_dim[n->n_layers - 1] != 1) return fail(DSDF_E_INVALID, "last layer must have out_dim 1");
+  if (n->skip_mask & 1u) return fail(DSDF_E_INVALID, "latent_in may not contain layer 0");
+  if (n->skip_mask >> n->n_layers) return fail(DSDF_E_INVALID, "skip_mask names a layer >= n_layers");
+  if (__builtin_popcount(n->skip_mask) > 1) return fail(DSDF_E_INVALID, "at most one latent_in layer is supported");
+  for (int l = 0; l < n->n_layers; ++l) {
+    if (n->in_dim[l] < 1 || n->out_dim[l] < 1 || n->in_dim[l] > 2048 || n->out_dim[l] > 65536)
+      return fail(DSDF_E_INVALID, "layer %d: unsupported size %d -> %d", l, n->in_dim[l], n->out_dim[l]);
+    if (l > 0) {
+      const int expect = n->out_dim[l - 1] + ((n->skip_mask >> l) & 1 ? W0 : 0);
+      if (n->in_dim[l] != expect) return fail(DSDF_E_INVALID, "layer %d: in_dim %d != %d", l, n->in_dim[l], expect);
+    }
+  }
+  if (n->in_dim[n->n_layers - 1] % 4 != 0) return fail(DSDF_E_INVALID, "last hidden width must be a multiple of 4");
+  if (!(n->dropout_p >= 0.f && n->dropout_p < 1.f)) return fail(DSDF_E_INVALID, "dropout_p must be in [0,1)");
+  return 0;
+}
+
+struct Packed {
+  int64_t w_off[DSDF_MAX_LAYERS], wt_off[DSDF_MAX_LAYERS];
+  int ldw[DSDF_MAX_LAYERS], ldwt[DSDF_MAX_LAYERS];
+  int64_t total;
+};
+Packed packed_layout(const DsdfNet* n) {
+  Packed p;
+  int64_t o = 0;
+  for (int l = 0; l < n->n_layers; ++l) {
+    p.ldw[l] = (int)rup(n->in_dim[l], 32);
+    p.ldwt[l] = (int)rup(n->out_dim[l], 32);
+    p.w_off[l] = o;  o += rup((int64_t)n->out_dim[l] * p.ldw[l], 64);
+    p.wt_off[l] = o; o += rup((int64_t)n->in_dim[l] * p.ldwt[l], 64);
+  }
+  p.total = o;
+  return p;
+}
+
+void param_layout(const DsdfNet* n, DsdfParamLayout* L) {
+  int64_t o = 0;
+  for (int l = 0; l < DSDF_MAX_LAYERS; ++l) L->bias_off[l] = L->g_off[l] = L->v_off[l] = -1;
+  for (int l = 0; l < n->n_layers; ++l) {
+    const int64_t out = n->out_dim[l], in = n->in_dim[l];
+    if ((n->weight_norm_mask >> l) & 1) {
+      L->bias_off[l] = o; o += out;
+      L->g_off[l] = o;    o += out;
+      L->v_off[l] = o;    o += out * in;
+    } else {
+      L->v_off[l] = o;    o += out * in;
+      L->bias_off[l] = o; o += out;
+    }
+  }
+  L->total = o;
+}
+
+// ---- workspace plan -----------------------------------------------------------------------------
+struct Plan {
+  int nl, W0, N, R;
+  int ld_in[DSDF_MAX_LAYERS];
+  size_t in_off[DSDF_MAX_LAYERS];
+  int ld_dp, ldz, ldcs, ld_part, last_blocks, nsplit, kchunk, mt;
+  long long slab;
+  size_t u_off, y_off, dp_off[2], dzA_off, dzB_off, slab_off, colsum_off, part_off, part2_off, partdb_off,
+      partloss_off, segpart_off, segnorm_off, regloss_off, gnorm_off, total;
+};
+
+Plan make_plan(const DsdfNet* n, int64_t N, int64_t R, bool inference) {
+  Plan P;
+  memset(&P, 0, sizeof(P));
+  P.nl = n->n_layers; P.W0 = n->latent_size + n->geom_dim; P.N = (int)N; P.R = (int)R;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o += (size_t)rup((int64_t)bytes, 256); return r; };
+  int maxw = 4;
+  for (int l = 0; l < P.nl; ++l) {
+    P.ld_in[l] = (int)rup(n->in_dim[l], 4);
+    if (P.ld_in[l] > maxw) maxw = P.ld_in[l];
+  }
+  if (inference) {
+    size_t pp[2] = {take((size_t)N * maxw * 4), take((size_t)N * maxw * 4)};
+    for (int l = 0; l < P.nl; ++l) {
+      if (l == 0 || ((n->skip_mask >> l) & 1)) P.in_off[l] = take((size_t)N * P.ld_in[l] * 4);
+      else P.in_off[l] = pp[l & 1];
+    }
+    P.total = o;
+    return P;
+  }
+  for (int l = 0; l < P.nl; ++l) P.in_off[l] = take((size_t)N * P.ld_in[l] * 4);
+  P.u_off = take((size_t)N * 4);
+  P.y_off = take((size_t)N * 4);
+  P.ld_dp = maxw;
+  P.dp_off[0] = take((size_t)N * maxw * 4);
+  P.dp_off[1] = take((size_t)N * maxw * 4);
+  P.ldz = (int)rup(P.W0, 4);
+  P.dzA_off = take((size_t)N * P.ldz * 4);
+  P.dzB_off = take((size_t)N * P.ldz * 4);
+  // split-K of the dW GEMMs: chunks of >= 256 points, at most NSPLIT_MAX slabs
+  int ns = (int)((N + 255) / 256);
+  if (ns > NSPLIT_MAX) ns = NSPLIT_MAX;
+  if (ns < 1) ns = 1;
+  P.kchunk = (int)rup((N + ns - 1) / ns, BK);
+  P.nsplit = (int)((N + P.kchunk - 1) / P.kchunk);
+  int64_t maxslab = 0;
+  int maxout = 1;
+  for (int l = 0; l < P.nl - 1; ++l) {
+    const int64_t s = (int64_t)n->out_dim[l] * P.ld_in[l];
+    if (s > maxslab) maxslab = s;
+    if (n->out_dim[l] > maxout) maxout = n->out_dim[l];
+  }
+  P.slab = rup(maxslab, 64);
+  P.slab_off = take((size_t)P.nsplit * P.slab * 4);
+  P.mt = (int)((N + BM - 1) / BM);
+  P.ldcs = (int)rup(maxout, 4);
+  P.colsum_off = take((size_t)P.mt * P.ldcs * 4);
+  P.last_blocks = (int)((N + 15) / 16);
+  if (P.last_blocks > LAST_BLOCKS_MAX) P.last_blocks = LAST_BLOCKS_MAX;
+  if (P.last_blocks < 1) P.last_blocks = 1;
+  P.ld_part = 2 * P.ld_in[P.nl - 1];  // [dW_last | colsum_prev]
+  P.part_off = take((size_t)P.last_blocks * P.ld_part * 4);
+  P.part2_off = take((size_t)LAST_GROUPS * P.ld_part * 4);
+  P.partdb_off = take((size_t)P.last_blocks * 4);
+  P.partloss_off = take((size_t)P.last_blocks * 4);
+  P.segpart_off = take((size_t)(R > 0 ? R : 1) * (n->latent_size > 0 ? n->latent_size : 1) * 4);
+  P.segnorm_off = take((size_t)(R > 0 ? R : 1) * 4);
+  P.regloss_off = take(256);
+  P.gnorm_off = take(1024 * 4);
+  P.total = o;
+  return P;
+}
+
+template <typename T>
+inline T* at(void* ws, size_t off) { return reinterpret_cast<T*>(static_cast<char*>(ws) + off); }
+
+// ---- launch helpers -------------------------------------------------------------------------------
+template <int EPI>
+int launch_nt(const NtArgs& a, hipStream_t st) {
+  if (a.M <= 0 || a.N <= 0) return 0;
+  if (a.K <= 0) return fail(DSDF_E_INVALID, "gemm_nt: K must be positive");
+  if ((a.lda & 3) || (a.ldb & 3) || !aligned16(a.A) || !aligned16(a.B))
+    return fail(DSDF_E_INVALID, "gemm_nt: operands must be 16-byte aligned with ld %% 4 == 0");
+  if (a.lda < rup(a.K, 4) || a.ldb < rup(a.K, 4)) return fail(DSDF_E_INVALID, "gemm_nt: ld smaller than K rounded up to 4");
+  const int grid = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(grid), dim3(256), 0, st, a);
+  LAUNCH_OK("gemm_nt_kernel");
+  return 0;
+}
+
+int launch_tn(const TnArgs& a, int nsplit, hipStream_t st) {
+  if (a.M <= 0 || a.N <= 0 || nsplit <= 0) return 0;
+  if ((a.lda & 3) || (a.ldb & 3) || !aligned16(a.A) || !aligned16(a.B))
+    return fail(DSDF_E_INVALID, "gemm_tn: operands must be 16-byte aligned with ld %% 4 == 0");
+  if (a.lda < rup(a.M, 4) || a.ldb < rup(a.N, 4)) return fail(DSDF_E_INVALID, "gemm_tn: ld smaller than the tile width");
+  if (a.kchunk % BK) return fail(DSDF_E_INVALID, "gemm_tn: kchunk must be a multiple of %d", BK);
+  const int grid = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * nsplit;
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(256), 0, st, a);
+  LAUNCH_OK("gemm_tn_kernel");
+  return 0;
+}
+
+template <int MODE>
+int launch_last(const LastArgs& a, int blocks, hipStream_t st) {
+  if (a.n <= 0) return 0;
+  const int in = a.in;
+  if (in <= 256) hipLaunchKernelGGL((last_layer_kernel<MODE, 1>), dim3(blocks), dim3(256), 0, st, a);
+  else if (in <= 512) hipLaunchKernelGGL((last_layer_kernel<MODE, 2>), dim3(blocks), dim3(256), 0, st, a);
+  else if (in <= 1024) hipLaunchKernelGGL((last_layer_kernel<MODE, 4>), dim3(blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((last_layer_kernel<MODE, 8>), dim3(blocks), dim3(256), 0, st, a);
+  LAUNCH_OK("last_layer_kernel");
+  return 0;
+}
+
+// rows [g*P/G, (g+1)*P/G) of part[P][ld] summed into out[g][ld] (fixed order)
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* part, int P, int ld, int n, float* out, int G) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), ry = threadIdx.x >> 6, g = blockIdx.y;
+  const int beg = (int)((long long)g * P / G), end = (int)((long long)(g + 1) * P / G);
+  float s = 0.f;
+  if (c < n)
+    for (int r = beg + ry; r < end; r += 4) s += part[(size_t)r * ld + c];
+  red[ry][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (ry == 0 && c < n) {
+    const int x = threadIdx.x;
+    out[(size_t)g * ld + c] = (red[0][x] + red[1][x]) + (red[2][x] + red[3][x]);
+  }
+}
+
+int materialize(const DsdfNet* net, const float* params, float* packed, hipStream_t st) {
+  DsdfParamLayout L;
+  param_layout(net, &L);
+  const Packed pk = packed_layout(net);
+  for (int l = 0; l < net->n_layers; ++l) {
+    WnArgs a;
+    a.v = params + L.v_off[l];
+    a.g = L.g_off[l] >= 0 ? params + L.g_off[l] : nullptr;
+    a.W = packed + pk.w_off[l];
+    a.WT = (l == net->n_layers - 1) ? nullptr : packed + pk.wt_off[l];
+    a.out = net->out_dim[l]; a.in = net->in_dim[l]; a.ldw = pk.ldw[l]; a.ldwt = pk.ldwt[l];
+    a.wn = a.g != nullptr;
+    hipLaunchKernelGGL(weight_norm_kernel, dim3((a.out + 31) / 32), dim3(256), 0, st, a);
+    LAUNCH_OK("weight_norm_kernel");
+  }
+  return 0;
+}
+
+// x0 (+ skip copies) from either the latent table + segments or an explicit input
+int run_gather(const DsdfNet* net, const Plan& P, void* ws, const float* table, const DsdfBatch* b, const float* input,
+               int64_t ld_in, int64_t n, hipStream_t st) {
+  GatherArgs g;
+  memset(&g, 0, sizeof(g));
+  g.table = table; g.L = net->latent_size; g.G = net->geom_dim;
+  if (b) { g.xyz = b->xyz; g.seg_scene = b->seg_scene; g.seg_offset = b->seg_offset; g.R = (int)b->n_segments; }
+  g.input = input; g.ld_in = ld_in; g.n = (int)n;
+  g.ndst = 0;
+  g.dst[g.ndst++] = GatherDst{at<float>(ws, P.in_off[0]), P.ld_in[0], 0};
+  for (int l = 1; l < net->n_layers; ++l)
+    if ((net->skip_mask >> l) & 1) g.dst[g.ndst++] = GatherDst{at<float>(ws, P.in_off[l]), P.ld_in[l], net->out_dim[l - 1]};
+  hipLaunchKernelGGL(gather_concat_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, g);
+  LAUNCH_OK("gather_concat_kernel");
+  return 0;
+}
+
+// hidden layers 0..nl-2: in[l+1][:, :out_l] = dropout(relu(in[l] W_l^T + b_l))
+int run_hidden_forward(const DsdfNet* net, const Plan& P, void* ws, const float* packed, const float* params, int64_t n,
+                       int training, const uint32_t* keys, uint32_t row_offset, hipStream_t st) {
+  DsdfParamLayout L;
+  param_layout(net, &L);
+  const Packed pk = packed_layout(net);
+  for (int l = 0; l < net->n_layers - 1; ++l) {
+    NtArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = at<float>(ws, P.in_off[l]); a.lda = P.ld_in[l];
+    a.B = packed + pk.w_off[l]; a.ldb = pk.ldw[l];
+    a.C = at<float>(ws, P.in_off[l + 1]); a.ldc = P.ld_in[l + 1];
+    a.M = (int)n; a.N = net->out_dim[l]; a.K = net->in_dim[l];
+    a.bias = params + L.bias_off[l];
+    a.relu = 1;
+    const bool drop = training && ((net->dropout_mask >> l) & 1) && net->dropout_p > 0.f;
+    if (drop) {
+      long thr = lround((double)net->dropout_p * 65536.0);
+      if (thr > 65535) thr = 65535;
+      a.drop_thr = (uint32_t)thr;
+      a.drop_key = keys[l];
+      a.drop_scale = 1.0f / (1.0f - net->dropout_p);
+      a.row_offset = row_offset;
+    }
+    TRY(launch_nt<EPI_FWD>(a, st));
+  }
+  return 0;
+}
+
+float mask_scale_of(const DsdfNet* net, int layer, int training) {
+  const bool drop = training && ((net->dropout_mask >> layer) & 1) && net->dropout_p > 0.f;
+  return drop ? 1.0f / (1.0f - net->dropout_p) : 1.0f;
+}
+
+// shared backward over hidden layers, given dp of layer nl-2 in dp[0] and the last layer's partials.
+// ncols_dz: how many leading x0 columns of d/dx0 are needed (L for training, W0 for the module path).
+int run_backward(const DsdfNet* net, const Plan& P, void* ws, const float* packed, const float* params, int64_t n,
+                 int training, float* grads, int accumulate, int ncols_dz, bool* used_dzB, hipStream_t st) {
+  DsdfParamLayout L;
+  param_layout(net, &L);
+  const Packed pk = packed_layout(net);
+  const int nl = net->n_layers;
+  const int last = nl - 1;
+  // second stage of the last layer's partials
+  {
+    const int w = P.ld_part;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((w + 63) / 64, LAST_GROUPS), dim3(256), 0, st,
+                       at<float>(ws, P.part_off), P.last_blocks, P.ld_part, w, at<float>(ws, P.part2_off), LAST_GROUPS);
+    LAUNCH_OK("reduce_rows_kernel");
+    FinArgs f;
+    memset(&f, 0, sizeof(f));
+    f.slabs = at<float>(ws, P.part2_off); f.nsplit = LAST_GROUPS; f.slab = P.ld_part; f.ldc = P.ld_part;
+    f.colsum = at<float>(ws, P.partdb_off); f.npart = P.last_blocks; f.ldcs = 1;
+    f.g = L.g_off[last] >= 0 ? params + L.g_off[last] : nullptr;
+    f.v = params + L.v_off[last];
+    f.dg = L.g_off[last] >= 0 ? grads + L.g_off[last] : nullptr;
+    f.dv = grads + L.v_off[last];
+    f.db = grads + L.bias_off[last];
+    f.out = 1; f.in = net->in_dim[last]; f.accumulate = accumulate;
+    hipLaunchKernelGGL(finalize_layer_kernel, dim3(1), dim3(256), 0, st, f);
+    LAUNCH_OK("finalize_layer_kernel(last)");
+  }
+  *used_dzB = false;
+  int cur = 0;
+  for (int l = last - 1; l >= 0; --l) {
+    float* dp = at<float>(ws, P.dp_off[cur]);
+    // dW_l = dp^T in_l  (split-K slabs)
+    TnArgs t;
+    memset(&t, 0, sizeof(t));
+    t.A = dp; t.lda = P.ld_dp; t.B = at<float>(ws, P.in_off[l]); t.ldb = P.ld_in[l];
+    t.C = at<float>(ws, P.slab_off); t.ldc = P.ld_in[l]; t.M = net->out_dim[l]; t.N = net->in_dim[l]; t.K = (int)n;
+    t.kchunk = P.kchunk; t.slab = P.slab;
+    TRY(launch_tn(t, P.nsplit, st));
+    FinArgs f;
+    memset(&f, 0, sizeof(f));
+    f.slabs = t.C; f.nsplit = P.nsplit; f.slab = P.slab; f.ldc = t.ldc;
+    if (l == last - 1) { f.colsum = at<float>(ws, P.part2_off) + P.ld_in[last]; f.npart = LAST_GROUPS; f.ldcs = P.ld_part; }
+    else { f.colsum = at<float>(ws, P.colsum_off); f.npart = P.mt; f.ldcs = P.ldcs; }
+    f.g = L.g_off[l] >= 0 ? params + L.g_off[l] : nullptr;
+    f.v = params + L.v_off[l];
+    f.dg = L.g_off[l] >= 0 ? grads + L.g_off[l] : nullptr;
+    f.dv = grads + L.v_off[l];
+    f.db = grads + L.bias_off[l];
+    f.out = net->out_dim[l]; f.in = net->in_dim[l]; f.accumulate = accumulate;
+    hipLaunchKernelGGL(finalize_layer_kernel, dim3(f.out), dim3(256), 0, st, f);
+    LAUNCH_OK("finalize_layer_kernel");
+    // dX
+    NtArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = dp; a.lda = P.ld_dp; a.B = packed + pk.wt_off[l]; a.ldb = pk.ldwt[l];
+    a.M = (int)n; a.K = net->out_dim[l];
+    if (l > 0) {
+      const bool skip = (net->skip_mask >> l) & 1;
+      a.C = at<float>(ws, P.dp_off[cur ^ 1]); a.ldc = P.ld_dp;
+      a.act = at<float>(ws, P.in_off[l]); a.ldact = P.ld_in[l];
+      a.mask_cols = net->out_dim[l - 1];
+      a.mask_scale = mask_scale_of(net, l - 1, training);
+      a.N = skip ? (ncols_dz > 0 ? a.mask_cols + ncols_dz : a.mask_cols) : net->in_dim[l];
+      if (skip && ncols_dz > 0) { a.C2 = at<float>(ws, P.dzB_off); a.ldc2 = P.ldz; a.c2_cols = ncols_dz; *used_dzB = true; }
+      a.colsum = at<float>(ws, P.colsum_off); a.ldcs = P.ldcs;
+      TRY(launch_nt<EPI_BWD>(a, st));
+      cur ^= 1;
+    } else if (ncols_dz > 0) {
+      a.C = at<float>(ws, P.dzA_off); a.ldc = P.ldz; a.N = ncols_dz;
+      TRY(launch_nt<EPI_PLAIN>(a, st));
+    }
+  }
+  return 0;
+}
+
+int check_common(const DsdfNet* net, const void* packed, const void* params, const void* ws) {
+  TRY(validate(net));
+  if (!packed || !params || !ws) return fail(DSDF_E_INVALID, "NULL packed/params/workspace pointer");
+  if (!aligned16(packed) || !aligned16(params) || (reinterpret_cast<uintptr_t>(ws) & 255))
+    return fail(DSDF_E_INVALID, "packed/params must be 16-byte and workspace 256-byte aligned");
+  return 0;
+}
+
+}  // namespace
+
+// ===================================================================================================
+extern "C" {
+
+int dsdf_abi_version(void) { return DSDF_ABI_VERSION; }
+const char* dsdf_last_error(void) { return g_err; }
+
+int dsdf_param_layout(const DsdfNet* net, DsdfParamLayout* out) {
+  TRY(validate(net));
+  if (!out) return fail(DSDF_E_INVALID, "out is NULL");
+  param_layout(net, out);
+  return 0;
+}
+
+int dsdf_packed_floats(const DsdfNet* net, int64_t* n_floats) {
+  TRY(validate(net));
+  if (!n_floats) return fail(DSDF_E_INVALID, "n_floats is NULL");
+  *n_floats = packed_layout(net).total;
+  return 0;
+}
+
+int dsdf_workspace_bytes(const DsdfNet* net, int64_t n_points, int64_t n_segments, size_t* bytes) {
+  TRY(validate(net));
+  if (!bytes || n_points < 0 || n_segments < 0) return fail(DSDF_E_INVALID, "bad arguments");
+  if (n_points > (1ll << 30)) return fail(DSDF_E_INVALID, "n_points too large");
+  *bytes = make_plan(net, n_points, n_segments, false).total;
+  return 0;
+}
+
+int dsdf_decode_workspace_bytes(const DsdfNet* net, int64_t n_points, size_t* bytes) {
+  TRY(validate(net));
+  if (!bytes || n_points < 0 || n_points > (1ll << 30)) return fail(DSDF_E_INVALID, "bad arguments");
+  *bytes = make_plan(net, n_points, 0, true).total;
+  return 0;
+}
+
+int dsdf_materialize_weights(const DsdfNet* net, const float* params, float* packed, void* stream) {
+  TRY(validate(net));
+  if (!params || !packed) return fail(DSDF_E_INVALID, "NULL pointer");
+  return materialize(net, params, packed, (hipStream_t)stream);
+}
+
+int dsdf_decode(const DsdfNet* net, const float* packed, const float* params, const float* input, int64_t ld_in,
+                int64_t n, float* sdf_out, void* ws, size_t ws_bytes, void* stream) {
+  TRY(check_common(net, packed, params, ws));
+  if (n == 0) return 0;
+  if (!input || !sdf_out || n < 0 || ld_in < net->in_dim[0]) return fail(DSDF_E_INVALID, "bad input/sdf_out/ld_in");
+  const Plan P = make_plan(net, n, 0, true);
+  if (ws_bytes < P.total) return fail(DSDF_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, P.total);
+  hipStream_t st = (hipStream_t)stream;
+  TRY(run_gather(net, P, ws, nullptr, nullptr, input, ld_in, n, st));
+  TRY(run_hidden_forward(net, P, ws, packed, params, n, 0, nullptr, 0, st));
+  DsdfParamLayout L;
+  param_layout(net, &L);
+  const Packed pk = packed_layout(net);
+  const int last = net->n_layers - 1;
+  LastArgs a;
+  memset(&a, 0, sizeof(a));
+  a.a = at<float>(ws, P.in_off[last]); a.lda = P.ld_in[last]; a.in = net->in_dim[last];
+  a.w = packed + pk.w_off[last]; a.b = params + L.bias_off[last]; a.n = (int)n; a.use_tanh = net->use_tanh;
+  a.y_out = sdf_out;
+  int blocks = (int)((n + 15) / 16);
+  if (blocks > 2048) blocks = 2048;
+  return launch_last<LAST_FWD>(a, blocks, st);
+}
+
+int dsdf_module_forward(const DsdfNet* net, const float* packed, const float* params, const float* input,
+                        int64_t ld_in, int64_t n, int32_t training, const uint32_t* dropout_key, float* sdf_out,
+                        void* ws, size_t ws_bytes, void* stream) {
+  TRY(check_common(net, packed, params, ws));
+  if (n == 0) return 0;
+  if (!input || !sdf_out || n < 0 || ld_in < net->in_dim[0]) return fail(DSDF_E_INVALID, "bad input/sdf_out/ld_in");
+  if (training && net->dropout_p > 0.f && net->dropout_mask && !dropout_key) return fail(DSDF_E_INVALID, "dropout_key is NULL");
+  const Plan P = make_plan(net, n, 0, false);
+  if (ws_bytes < P.total) return fail(DSDF_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, P.total);
+  hipStream_t st = (hipStream_t)stream;
+  TRY(run_gather(net, P, ws, nullptr, nullptr, input, ld_in, n, st));
+  TRY(run_hidden_forward(net, P, ws, packed, params, n, training, dropout_key, 0, st));
+  DsdfParamLayout L;
+  param_layout(net, &L);
+  const Packed pk = packed_layout(net);
+  const int last = net->n_layers - 1;
+  LastArgs a;
+  memset(&a, 0, sizeof(a));
+  a.a = at<float>(ws, P.in_off[last]); a.lda = P.ld_in[last]; a.in = net->in_dim[last];
+  a.w = packed + pk.w_off[last]; a.b = params + L.bias_off[last]; a.n = (int)n; a.use_tanh = net->use_tanh;
+  a.y_out = sdf_out; a.u_save = at<float>(ws, P.u_off);
+  return launch_last<LAST_FWD>(a, P.last_blocks, st);
+}
+
+int dsdf_module_backward(const DsdfNet* net, const float* packed, const float* params, const float* d_sdf, int64_t n,
+                         int32_t training, float* grads, int32_t accumulate, float* d_input, int64_t ld_din, void* ws,
+                         size_t ws_bytes, void* stream) {
+  TRY(check_common(net, packed, params, ws));
+  if (n == 0) return 0;
+  if (!d_sdf || !grads || n < 0) return fail(DSDF_E_INVALID, "bad d_sdf/grads");
+  if (d_input && ld_din < net->in_dim[0]) return fail(DSDF_E_INVALID, "ld_din too small");
+  const Plan P = make_plan(net, n, 0, false);
+  if (ws_bytes < P.total) return fail(DSDF_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, P.total);
+  hipStream_t st = (hipStream_t)stream;
+  DsdfParamLayout L;
+  param_layout(net, &L);
+  const Packed pk = packed_layout(net);
+  const int last = net->n_layers - 1;
+  LastArgs a;
+  memset(&a, 0, sizeof(a));
+  a.a = at<float>(ws, P.in_off[last]); a.lda = P.ld_in[last]; a.in = net->in_dim[last];
+  a.w = packed + pk.w_off[last]; a.b = params + L.bias_off[last]; a.n = (int)n; a.use_tanh = net->use_tanh;
+  a.d_sdf = d_sdf; a.u_in = at<float>(ws, P.u_off);
+  a.dp_prev = at<float>(ws, P.dp_off[0]); a.lddp = P.ld_dp; a.mask_scale = mask_scale_of(net, last - 1, training);
+  a.part_dw = at<float>(ws, P.part_off); a.ld_part = P.ld_part;
+  a.part_colsum = at<float>(ws, P.part_off) + P.ld_in[last];
+  a.part_db = at<float>(ws, P.partdb_off); a.part_loss = at<float>(ws, P.partloss_off);
+  TRY(launch_last<LAST_BWD_EXT>(a, P.last_blocks, st));
+  bool used_dzB = false;
+  TRY(run_backward(net, P, ws, packed, params, n, training, grads, accumulate, d_input ? P.W0 : 0, &used_dzB, st));
+  if (d_input) {
+    const long long tot = (long long)n * P.W0;
+    hipLaunchKernelGGL(add2_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, at<float>(ws, P.dzA_off), P.ldz,
+                       used_dzB ? at<float>(ws, P.dzB_off) : nullptr, P.ldz, d_input, (long long)ld_din, (int)n, P.W0);
+    LAUNCH_OK("add2_kernel");
+  }
+  return 0;
+}
+
+int dsdf_train_forward_backward(const DsdfNet* net, const float* packed, const float* params, float* latent_table,
+                                int64_t n_scenes, const DsdfBatch* b, const DsdfLossCfg* cfg, float* grads, float* dlat,
+                                float* loss_out, float* sdf_out, int32_t accumulate, void* ws, size_t ws_bytes,
+                                void* stream) {
+  TRY(check_common(net, packed, params, ws));
+  if (!b || !cfg || !latent_table || !grads || !dlat || !loss_out) return fail(DSDF_E_INVALID, "NULL argument");
+  const int64_t n = b->n_points, R = b->n_segments;
+  if (n <= 0 || R <= 0 || n_scenes <= 0) return fail(DSDF_E_INVALID, "empty batch (n_points %lld, n_segments %lld)", (long long)n, (long long)R);
+  if (!b->seg_scene || !b->seg_offset || !b->xyz || !b->sdf_gt) return fail(DSDF_E_INVALID, "NULL batch pointer");
+  if (b->n_norm <= 0) return fail(DSDF_E_INVALID, "n_norm must be positive");
+  if (net->latent_size <= 0) return fail(DSDF_E_INVALID, "training needs latent_size > 0");
+  const Plan P = make_plan(net, n, R, false);
+  if (ws_bytes < P.total) return fail(DSDF_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, P.total);
+  hipStream_t st = (hipStream_t)stream;
+  const int Lc = net->latent_size;
+
+  if (cfg->code_bound > 0.f) {
+    hipLaunchKernelGGL(latent_renorm_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, latent_table, Lc, b->seg_scene,
+                       (int)R, cfg->code_bound);
+    LAUNCH_OK("latent_renorm_kernel");
+  }
+  TRY(run_gather(net, P, ws, latent_table, b, nullptr, 0, n, st));
+  TRY(run_hidden_forward(net, P, ws, packed, params, n, cfg->training, cfg->dropout_key, (uint32_t)b->row_offset, st));
+
+  DsdfParamLayout L;
+  param_layout(net, &L);
+  const Packed pk = packed_layout(net);
+  const int last = net->n_layers - 1;
+  LastArgs a;
+  memset(&a, 0, sizeof(a));
+  a.a = at<float>(ws, P.in_off[last]); a.lda = P.ld_in[last]; a.in = net->in_dim[last];
+  a.w = packed + pk.w_off[last]; a.b = params + L.bias_off[last]; a.n = (int)n; a.use_tanh = net->use_tanh;
+  a.y_out = sdf_out; a.gt = b->sdf_gt; a.delta = cfg->clamp_dist; a.inv_n = 1.0f / (float)b->n_norm;
+  a.dp_prev = at<float>(ws, P.dp_off[0]); a.lddp = P.ld_dp; a.mask_scale = mask_scale_of(net, last - 1, cfg->training);
+  a.part_dw = at<float>(ws, P.part_off); a.ld_part = P.ld_part;
+  a.part_colsum = at<float>(ws, P.part_off) + P.ld_in[last];
+  a.part_db = at<float>(ws, P.partdb_off); a.part_loss = at<float>(ws, P.partloss_off);
+  TRY(launch_last<LAST_TRAIN>(a, P.last_blocks, st));
+
+  bool used_dzB = false;
+  TRY(run_backward(net, P, ws, packed, params, n, cfg->training, grads, accumulate, Lc, &used_dzB, st));
+
+  SegArgs s;
+  memset(&s, 0, sizeof(s));
+  s.dzA = at<float>(ws, P.dzA_off); s.dzB = used_dzB ? at<float>(ws, P.dzB_off) : nullptr; s.ldz = P.ldz;
+  s.seg_scene = b->seg_scene; s.seg_offset = b->seg_offset; s.R = (int)R; s.L = Lc; s.table = latent_table;
+  s.segpart = at<float>(ws, P.segpart_off); s.segnorm = at<float>(ws, P.segnorm_off);
+  hipLaunchKernelGGL(seg_reduce_kernel, dim3((unsigned)R, (Lc + 63) / 64), dim3(256), 0, st, s);
+  LAUNCH_OK("seg_reduce_kernel");
+  if (!accumulate) HIP_OK(hipMemsetAsync(dlat, 0, (size_t)n_scenes * Lc * sizeof(float), st));
+  ScatterArgs sc;
+  memset(&sc, 0, sizeof(sc));
+  sc.segpart = s.segpart; sc.segnorm = s.segnorm; sc.seg_scene = b->seg_scene; sc.seg_offset = b->seg_offset;
+  sc.R = (int)R; sc.L = Lc; sc.table = latent_table; sc.dlat = dlat;
+  sc.creg = cfg->reg_coef / (float)b->n_norm; sc.reg_loss = at<float>(ws, P.regloss_off);
+  hipLaunchKernelGGL(seg_scatter_kernel, dim3((Lc + 255) / 256), dim3(256), 0, st, sc);
+  LAUNCH_OK("seg_scatter_kernel");
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, at<float>(ws, P.partloss_off), P.last_blocks,
+                     1.0f / (float)b->n_norm, at<float>(ws, P.regloss_off), loss_out, accumulate);
+  LAUNCH_OK("loss_finish_kernel");
+  return 0;
+}
+
+int dsdf_grad_norm(const float* grads, int64_t n, float max_norm, float* norm_out, float* coef_out, void* ws,
+                   size_t ws_bytes, void* stream) {
+  if (!grads || !norm_out || !coef_out || !ws || n <= 0) return fail(DSDF_E_INVALID, "bad arguments");
+  int blocks = (int)((n + 4095) / 4096);
+  if (blocks > 1024) blocks = 1024;
+  if (ws_bytes < (size_t)blocks * 4) return fail(DSDF_E_WORKSPACE, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, st, grads, (long long)n, (float*)ws);
+  LAUNCH_OK("sumsq_partial_kernel");
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, blocks, max_norm, norm_out, coef_out);
+  LAUNCH_OK("clip_coef_kernel");
+  return 0;
+}
+
+static int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, const DsdfAdamCfg* c,
+                       const float* gscale, hipStream_t st) {
+  if (n <= 0) return 0;
+  const double bc1 = 1.0 - pow((double)c->beta1, (double)c->step);
+  const double bc2 = 1.0 - pow((double)c->beta2, (double)c->step);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, (long long)n, 1.0f - c->beta1, c->beta2,
+                     1.0f - c->beta2, step_size, bc2_sqrt, c->eps, gscale);
+  LAUNCH_OK("adam_kernel");
+  return 0;
+}
+
+int dsdf_adam_step(const DsdfNet* net, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                   float* latent_table, const float* dlat, float* lat_exp_avg, float* lat_exp_avg_sq,
+                   int64_t n_latent_floats, const DsdfAdamCfg* cfg, float* packed, void* stream) {
+  TRY(validate(net));
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !cfg || !packed) return fail(DSDF_E_INVALID, "NULL argument");
+  if (cfg->step < 1) return fail(DSDF_E_INVALID, "Adam step must be >= 1");
+  hipStream_t st = (hipStream_t)stream;
+  DsdfParamLayout L;
+  param_layout(net, &L);
+  TRY(adam_launch(params, grads, exp_avg, exp_avg_sq, L.total, cfg->lr_decoder, cfg, cfg->grad_scale, st));
+  if (n_latent_floats > 0) {
+    if (!latent_table || !dlat || !lat_exp_avg || !lat_exp_avg_sq) return fail(DSDF_E_INVALID, "NULL latent argument");
+    TRY(adam_launch(latent_table, dlat, lat_exp_avg, lat_exp_avg_sq, n_latent_floats, cfg->lr_latent, cfg, nullptr, st));
+  }
+  return materialize(net, params, packed, st);
+}
+
+int dsdf_adam_latent_only(float* latent, const float* dlat, float* exp_avg, float* exp_avg_sq, int64_t n,
+                          const DsdfAdamCfg* cfg, void* stream) {
+  if (!latent || !dlat || !exp_avg || !exp_avg_sq || !cfg || n <= 0) return fail(DSDF_E_INVALID, "bad arguments");
+  if (cfg->step < 1) return fail(DSDF_E_INVALID, "Adam step must be >= 1");
+  return adam_launch(latent, dlat, exp_avg, exp_avg_sq, n, cfg->lr_latent, cfg, nullptr, (hipStream_t)stream);
+}
+
+int dsdf_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
+                 int64_t K, const float* bias, void* stream) {
+  if (!A || !B || !C) return fail(DSDF_E_INVALID, "NULL operand");
+  NtArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.B = B; a.C = C; a.lda = (int)lda; a.ldb = (int)ldb; a.ldc = (int)ldc; a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.bias = bias;
+  return launch_nt<EPI_PLAIN>(a, (hipStream_t)stream);
+}
+
+int dsdf_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
+                 int64_t K, void* ws, size_t ws_bytes, void* stream) {
+  if (!A || !B || !C || !ws) return fail(DSDF_E_INVALID, "NULL operand");
+  int ns = (int)((K + 255) / 256);
+  if (ns > NSPLIT_MAX) ns = NSPLIT_MAX;
+  if (ns < 1) ns = 1;
+  const int kchunk = (int)rup((K + ns - 1) / ns, BK);
+  const int nsplit = (int)((K + kchunk - 1) / kchunk);
+  const long long slab = rup(M * ldc, 64);
+  if (ws_bytes < (size_t)nsplit * slab * 4) return fail(DSDF_E_WORKSPACE, "gemm_tn needs %lld bytes of workspace", (long long)nsplit * slab * 4);
+  TnArgs t;
+  memset(&t, 0, sizeof(t));
+  t.A = A; t.B = B; t.C = (float*)ws; t.lda = (int)lda; t.ldb = (int)ldb; t.ldc = (int)ldc; t.M = (int)M; t.N = (int)N;
+  t.K = (int)K; t.kchunk = kchunk; t.slab = slab;
+  hipStream_t st = (hipStream_t)stream;
+  TRY(launch_tn(t, nsplit, st));
+  // plain fixed-order slab sum (no weight norm): reuse the finalize kernel with g == NULL and no bias partials
+  FinArgs f;
+  memset(&f, 0, sizeof(f));
+  if (N > 2048 || ldc != N) return fail(DSDF_E_INVALID, "gemm_tn test entry needs ldc == N <= 2048");
+  f.slabs = t.C; f.nsplit = nsplit; f.slab = slab; f.ldc = (int)ldc; f.colsum = nullptr; f.npart = 0; f.ldcs = 0;
+  f.dv = C; f.db = (float*)ws + (size_t)nsplit * slab;  // scratch row of M floats behind the slabs
+  if (ws_bytes < ((size_t)nsplit * slab + M) * 4) return fail(DSDF_E_WORKSPACE, "gemm_tn workspace too small");
+  f.out = (int)M; f.in = (int)N;
+  hipLaunchKernelGGL(finalize_layer_kernel, dim3((unsigned)M), dim3(256), 0, st, f);
+  LAUNCH_OK("finalize_layer_kernel(test)");
+  return 0;
+}
+
+int dsdf_dropout_mask(uint32_t key, float p, int64_t rows, int64_t cols, int64_t row_offset, uint8_t* out, void* stream) {
+  if (!out || rows <= 0 || cols <= 0) return fail(DSDF_E_INVALID, "bad arguments");
+  long thr = lround((double)p * 65536.0);
+  if (thr > 65535) thr = 65535;
+  const long long tot = rows * cols;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, key,
+                     (uint32_t)thr, (int)rows, (int)cols, (uint32_t)row_offset, out);
+  LAUNCH_OK("dropout_mask_kernel");
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,416 @@
+// kernels.hpp -- the HBM-bound kernels around the GEMMs (gfx950): latent renorm/gather/concat, weight-norm
+// materialisation, last-layer GEMV + tanh + clamped-L1 + its backward, split-K/weight-norm finalisation,
+// segmented latent-gradient reduction, fused Adam.  All reductions are deterministic (fixed order).
+#pragma once
+#include "common.hpp"
+
+namespace dsdf {
+
+// ---------------------------------------------------------------------------------------------------
+// K0a: max-norm renorm of every looked-up latent row, in place (torch embedding_renorm_,
+// train_deep_sdf.py:385,509).  One wave per segment; a segment whose scene already appears in an earlier
+// segment is skipped, so every distinct scene is scaled exactly once.
+__global__ void latent_renorm_kernel(float* __restrict__ table, int L, const int64_t* __restrict__ seg_scene,
+                                     int R, float max_norm) {
+  const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const int64_t j = seg_scene[r];
+  int dup = 0;
+  for (int q = lane; q < r; q += 64) dup |= (seg_scene[q] == j);
+  if (__any(dup)) return;
+  float* row = table + (size_t)j * L;
+  float ss = 0.f;
+  for (int c = lane; c < L; c += 64) { const float v = row[c]; ss += v * v; }
+  ss = wave_sum(ss);
+  const float nu = sqrtf(ss);
+  if (nu > max_norm) {
+    const float s = max_norm / (nu + 1e-7f);
+    for (int c = lane; c < L; c += 64) row[c] *= s;
+  }
+}
+
+// K0b: x0[n] = [E[scene(n)] || xyz[n]] written to up to 1 + popcount(skip_mask) destinations
+// (train_deep_sdf.py:509-511; the skip destinations realise deep_sdf_decoder.py:88-89 without a cat).
+struct GatherDst { float* ptr; int ld; int col0; };
+struct GatherArgs {
+  const float* table; int L; const float* xyz; int G;
+  const int64_t* seg_scene; const int64_t* seg_offset; int R;
+  const float* input; long long ld_in;  // module path: rows come from an explicit [n, L+G] input instead
+  int n; int ndst; GatherDst dst[DSDF_MAX_LAYERS + 1];
+};
+__global__ void gather_concat_kernel(const GatherArgs p) {
+  const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (n >= p.n) return;
+  const int W = p.L + p.G;
+  const float* src_lat;
+  const float* src_xyz;
+  if (p.input != nullptr) {
+    src_lat = p.input + (size_t)n * p.ld_in;
+    src_xyz = src_lat + p.L;
+  } else {
+    int lo = 0, hi = p.R;  // last segment with offset <= n
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p.seg_offset[mid] <= n) lo = mid; else hi = mid; }
+    src_lat = p.table + (size_t)p.seg_scene[lo] * p.L;
+    src_xyz = p.xyz + (size_t)n * p.G;
+  }
+  for (int c = lane; c < W; c += 64) {
+    const float v = c < p.L ? src_lat[c] : src_xyz[c - p.L];
+    for (int d = 0; d < p.ndst; ++d) p.dst[d].ptr[(size_t)n * p.dst[d].ld + p.dst[d].col0 + c] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K1: W = g * v / ||v||_row (torch._weight_norm(v, g, 0)) or plain copy; writes W [out][ldw] and
+// W^T [in][ldwt].  Block = 32 rows; transposed store goes through a 32x33 LDS tile.
+struct WnArgs { const float* v; const float* g; float* W; float* WT; int out, in, ldw, ldwt; int wn; };
+__global__ __launch_bounds__(256) void weight_norm_kernel(const WnArgs p) {
+  __shared__ float tile[32][33];
+  __shared__ float scale[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = blockIdx.x * 32;
+  for (int rr = wave; rr < 32; rr += 4) {
+    const int row = r0 + rr;
+    float s = 1.f;
+    if (p.wn && row < p.out) {
+      float ss = 0.f;
+      for (int c = lane; c < p.in; c += 64) { const float x = p.v[(size_t)row * p.in + c]; ss += x * x; }
+      ss = wave_sum(ss);
+      s = p.g[row] / sqrtf(ss);
+    }
+    if (lane == 0) scale[rr] = s;
+  }
+  __syncthreads();
+  const int tx = tid & 31, ty = tid >> 5;  // 32 x 8
+  for (int c0 = 0; c0 < p.in; c0 += 32) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rr = ty + 8 * k, row = r0 + rr, col = c0 + tx;
+      float w = 0.f;
+      if (row < p.out && col < p.in) {
+        w = p.v[(size_t)row * p.in + col] * scale[rr];
+        p.W[(size_t)row * p.ldw + col] = w;
+      }
+      tile[rr][tx] = w;
+    }
+    __syncthreads();
+    if (p.WT != nullptr) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int cc = ty + 8 * k, col = c0 + cc, row = r0 + tx;
+        if (col < p.in && row < p.out) p.WT[(size_t)col * p.ldwt + row] = tile[tx][cc];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K3: last layer.  One wave per point row (4 rows per block iteration).
+//   u = <a, w> + b ; t1 = use_tanh ? tanh(u) : u ; y = tanh(t1)               (deep_sdf_decoder.py:92-95,108-109)
+//   train: yh = clamp(y), th = clamp(gt); loss += |yh - th| / n_norm            (train_deep_sdf.py:493,517-521)
+//          dy = sign(yh - th) * [|y| <= delta] / n_norm ; du = dy (1-y^2) (1-t1^2 if use_tanh)
+//          dW_last partial += du * a ; db_last partial += du ; dp_prev = du * w * [a > 0] * mask_scale
+//          colsum_prev partial += dp_prev (bias gradient of the previous layer)
+//   module backward: dy comes from d_sdf instead of the loss.
+enum { LAST_FWD = 0, LAST_TRAIN = 1, LAST_BWD_EXT = 2 };
+struct LastArgs {
+  const float* a; int lda; int in; const float* w; const float* b; int n;
+  int use_tanh;
+  float* y_out;            // [n] (may be null)
+  float* u_save;           // [n] saved pre-tanh output (module path), may be null
+  const float* gt; float delta; float inv_n;
+  const float* d_sdf;      // LAST_BWD_EXT
+  const float* u_in;       // LAST_BWD_EXT: saved u
+  float* dp_prev; int lddp; float mask_scale;
+  float* part_dw;          // [nblk][ld_part]
+  int ld_part;
+  float* part_db;          // [nblk]
+  float* part_loss;        // [nblk]
+  float* part_colsum;      // [nblk][ld_part]
+};
+template <int MODE, int NCH>  // NCH float4 chunks per lane: in <= 256 * NCH
+__global__ __launch_bounds__(256) void last_layer_kernel(const LastArgs p) {
+  __shared__ float red[4][4];
+  __shared__ float redv[4][256 * NCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float4 w4[NCH];
+  bool cok[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = 4 * lane + 256 * c;
+    cok[c] = col < p.in;  // in is a multiple of 4 for every supported width (checked on the host)
+    w4[c] = cok[c] ? *reinterpret_cast<const float4*>(p.w + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float bias = p.b[0];
+  float4 dw[NCH], cs[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) { dw[c] = make_float4(0.f, 0.f, 0.f, 0.f); cs[c] = dw[c]; }
+  float loss = 0.f, db = 0.f;
+  const int stride = gridDim.x * 4;
+  for (int row = blockIdx.x * 4 + wave; row < p.n; row += stride) {
+    float4 a4[NCH];
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      a4[c] = cok[c] ? *reinterpret_cast<const float4*>(p.a + (size_t)row * p.lda + 4 * lane + 256 * c)
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+      dot += a4[c].x * w4[c].x + a4[c].y * w4[c].y + a4[c].z * w4[c].z + a4[c].w * w4[c].w;
+    }
+    float u;
+    if constexpr (MODE == LAST_BWD_EXT) u = p.u_in[row];
+    else u = wave_sum(dot) + bias;
+    const float t1 = p.use_tanh ? tanhf(u) : u;
+    const float y = tanhf(t1);
+    if constexpr (MODE != LAST_BWD_EXT) {
+      if (lane == 0) {
+        if (p.y_out) p.y_out[row] = y;
+        if (p.u_save) p.u_save[row] = u;
+      }
+    }
+    if constexpr (MODE != LAST_FWD) {
+      float dy;
+      if constexpr (MODE == LAST_TRAIN) {
+        const float yh = fminf(fmaxf(y, -p.delta), p.delta);
+        const float th = fminf(fmaxf(p.gt[row], -p.delta), p.delta);
+        const float diff = yh - th;
+        loss += fabsf(diff);
+        const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+        dy = (y >= -p.delta && y <= p.delta) ? sg * p.inv_n : 0.f;
+      } else {
+        dy = p.d_sdf[row];
+      }
+      float du = dy * (1.f - y * y);
+      if (p.use_tanh) du *= (1.f - t1 * t1);
+      db += du;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if (cok[c]) {
+          dw[c].x += du * a4[c].x; dw[c].y += du * a4[c].y; dw[c].z += du * a4[c].z; dw[c].w += du * a4[c].w;
+          float4 d;
+          d.x = a4[c].x > 0.f ? du * w4[c].x * p.mask_scale : 0.f;
+          d.y = a4[c].y > 0.f ? du * w4[c].y * p.mask_scale : 0.f;
+          d.z = a4[c].z > 0.f ? du * w4[c].z * p.mask_scale : 0.f;
+          d.w = a4[c].w > 0.f ? du * w4[c].w * p.mask_scale : 0.f;
+          if (p.dp_prev) *reinterpret_cast<float4*>(p.dp_prev + (size_t)row * p.lddp + 4 * lane + 256 * c) = d;
+          cs[c].x += d.x; cs[c].y += d.y; cs[c].z += d.z; cs[c].w += d.w;
+        }
+      }
+    }
+  }
+  if constexpr (MODE != LAST_FWD) {
+    // per-block partials, fixed order (wave 0..3)
+    if (lane == 0) { red[wave][0] = loss; red[wave][1] = db; }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(&redv[wave][4 * lane + 256 * c]) = dw[c];
+    __syncthreads();
+    if (tid == 0) {
+      p.part_loss[blockIdx.x] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+      p.part_db[blockIdx.x] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    }
+    for (int c = tid; c < p.in; c += 256)
+      p.part_dw[(size_t)blockIdx.x * p.ld_part + c] = (redv[0][c] + redv[1][c]) + (redv[2][c] + redv[3][c]);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(&redv[wave][4 * lane + 256 * c]) = cs[c];
+    __syncthreads();
+    if (p.part_colsum)
+      for (int c = tid; c < p.in; c += 256)
+        p.part_colsum[(size_t)blockIdx.x * p.ld_part + c] = (redv[0][c] + redv[1][c]) + (redv[2][c] + redv[3][c]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// F1: per layer, one block per output row i: dW[i,:] = sum over split slabs; weight-norm backward
+// (Appendix A.3: dg = <dW,v>/||v||, dv = g/||v|| dW - g dg/||v||^2 v); db[i] = sum of column partials.
+struct FinArgs {
+  const float* slabs; int nsplit; long long slab; int ldc;
+  const float* colsum; int npart; int ldcs;
+  const float* g; const float* v;   // parameters (g null for plain layers)
+  float* dg; float* dv; float* db;  // gradient arena slices
+  int out, in; int accumulate;
+};
+__global__ __launch_bounds__(256) void finalize_layer_kernel(const FinArgs p) {
+  __shared__ float red[4];
+  const int i = blockIdx.x, tid = threadIdx.x;
+  float dot = 0.f, ss = 0.f;
+  constexpr int MAXC = 8;  // in <= 2048
+  float dwr[MAXC];
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) {
+    const int c = tid + 256 * k;
+    float s = 0.f;
+    if (c < p.in) {
+      const float* q = p.slabs + (size_t)i * p.ldc + c;
+      for (int sp = 0; sp < p.nsplit; ++sp) s += q[(size_t)sp * p.slab];
+      if (p.g) { const float vv = p.v[(size_t)i * p.in + c]; dot += s * vv; ss += vv * vv; }
+    }
+    dwr[k] = s;
+  }
+  if (p.g) {
+    dot = block_sum_256(dot, red);
+    ss = block_sum_256(ss, red);
+    const float nrm = sqrtf(ss);
+    const float gi = p.g[i];
+    const float dgi = dot / nrm;
+    const float a = gi / nrm, b = gi * dgi / (nrm * nrm);
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      const int c = tid + 256 * k;
+      if (c < p.in) {
+        const size_t o = (size_t)i * p.in + c;
+        const float d = a * dwr[k] - b * p.v[o];
+        p.dv[o] = p.accumulate ? p.dv[o] + d : d;
+      }
+    }
+    if (tid == 0) p.dg[i] = p.accumulate ? p.dg[i] + dgi : dgi;
+  } else {
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      const int c = tid + 256 * k;
+      if (c < p.in) { const size_t o = (size_t)i * p.in + c; p.dv[o] = p.accumulate ? p.dv[o] + dwr[k] : dwr[k]; }
+    }
+  }
+  // bias gradient: fixed-order sum of the column partials
+  float s = 0.f;
+  for (int q = tid; q < p.npart; q += 256) s += p.colsum[(size_t)q * p.ldcs + i];
+  s = block_sum_256(s, red);
+  if (tid == 0) p.db[i] = p.accumulate ? p.db[i] + s : s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K5a: per segment r and 64-column chunk: segpart[r][c] = sum over the segment's rows of (dzA + dzB),
+// and (chunk 0) the norm of the segment's latent row for the regulariser.
+struct SegArgs {
+  const float* dzA; const float* dzB; int ldz;   // dzB may be null
+  const int64_t* seg_scene; const int64_t* seg_offset; int R; int L;
+  const float* table;
+  float* segpart;   // [R][L]
+  float* segnorm;   // [R]
+};
+__global__ __launch_bounds__(256) void seg_reduce_kernel(const SegArgs p) {
+  __shared__ float red[4][64];
+  const int r = blockIdx.x, c0 = blockIdx.y * 64;
+  const int tid = threadIdx.x, cx = tid & 63, ry = tid >> 6;
+  const int64_t beg = p.seg_offset[r], end = p.seg_offset[r + 1];
+  const int col = c0 + cx;
+  float s = 0.f;
+  if (col < p.L) {
+    for (int64_t n = beg + ry; n < end; n += 4) {
+      float v = p.dzA[(size_t)n * p.ldz + col];
+      if (p.dzB) v += p.dzB[(size_t)n * p.ldz + col];
+      s += v;
+    }
+  }
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && col < p.L) p.segpart[(size_t)r * p.L + col] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+  if (blockIdx.y == 0 && tid < 64) {
+    const float* row = p.table + (size_t)p.seg_scene[r] * p.L;
+    float ss = 0.f;
+    for (int c = tid; c < p.L; c += 64) { const float v = row[c]; ss += v * v; }
+    ss = wave_sum(ss);
+    if (tid == 0) p.segnorm[r] = sqrtf(ss);
+  }
+}
+
+// K5b: dlat[scene[r]] += segpart[r] + reg_coef/n_norm * count_r * E/||E||  in segment order (one thread
+// per column, so duplicates of a scene are summed deterministically); block 0 also emits the regulariser
+// loss  sum_r reg_coef/n_norm * count_r * ||E_r||  (train_deep_sdf.py:523-531).
+struct ScatterArgs {
+  const float* segpart; const float* segnorm; const int64_t* seg_scene; const int64_t* seg_offset; int R; int L;
+  const float* table; float* dlat; float creg; float* reg_loss;
+};
+__global__ void seg_scatter_kernel(const ScatterArgs p) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < p.L) {
+    for (int r = 0; r < p.R; ++r) {
+      const int64_t j = p.seg_scene[r];
+      float v = p.segpart[(size_t)r * p.L + c];
+      if (p.creg != 0.f) {
+        const float nrm = p.segnorm[r];
+        const float cnt = (float)(p.seg_offset[r + 1] - p.seg_offset[r]);
+        if (nrm > 0.f) v += p.creg * cnt * p.table[(size_t)j * p.L + c] / nrm;
+      }
+      p.dlat[(size_t)j * p.L + c] += v;
+    }
+  }
+  if (c == 0) {
+    float s = 0.f;
+    if (p.creg != 0.f)
+      for (int r = 0; r < p.R; ++r) s += p.creg * (float)(p.seg_offset[r + 1] - p.seg_offset[r]) * p.segnorm[r];
+    *p.reg_loss = s;
+  }
+}
+
+// loss_out (+)= sum(part_loss[0..n)) * scale + *extra
+__global__ __launch_bounds__(256) void loss_finish_kernel(const float* part, int n, float scale, const float* extra,
+                                                          float* out, int accumulate) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) {
+    float v = s * scale + (extra ? *extra : 0.f);
+    *out = accumulate ? *out + v : v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K7: Adam, torch/optim/adam.py single-tensor math: m = lerp(m, g, 1-b1); v = b2 v + (1-b2) g^2;
+// p -= step_size * m / (sqrt(v)/sqrt(bc2) + eps).
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long long n,
+                                                   float one_minus_b1, float b2, float one_minus_b2, float step_size,
+                                                   float bc2_sqrt, float eps, const float* gscale) {
+  const float gs = gscale ? *gscale : 1.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float gi = g[i] * gs;
+    const float mi = fmaf(one_minus_b1, gi - m[i], m[i]);
+    const float vi = b2 * v[i] + one_minus_b2 * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] = p[i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+  }
+}
+
+// K6: global L2 norm of the decoder gradient arena (clip_grad_norm_): two deterministic stages.
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* g, long long n, float* part) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += g[i] * g[i];
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void clip_coef_kernel(const float* part, int n, float max_norm, float* norm_out,
+                                                        float* coef_out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) {
+    const float nrm = sqrtf(s);
+    *norm_out = nrm;
+    *coef_out = fminf(1.f, max_norm / (nrm + 1e-6f));
+  }
+}
+
+// d_input[n][c] = dzA[n][c] + dzB[n][c]  (module path: d/d(input) = layer-0 dX + skip dX)
+__global__ void add2_kernel(const float* a, int lda, const float* b, int ldb, float* o, long long ldo, int n, int w) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)n * w) return;
+  const int r = (int)(i / w), c = (int)(i % w);
+  float v = a[(size_t)r * lda + c];
+  if (b) v += b[(size_t)r * ldb + c];
+  o[(size_t)r * ldo + c] = v;
+}
+
+__global__ void dropout_mask_kernel(uint32_t key, uint32_t thr, int rows, int cols, uint32_t row_offset, uint8_t* out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)rows * cols) return;
+  const uint32_t r = (uint32_t)(i / cols), c = (uint32_t)(i % cols);
+  const uint32_t g = row_offset + r;
+  out[i] = drop_keep(drop_pair_hash(drop_col_key(c, key), g), g, thr) ? 1 : 0;
+}
+
+}  // namespace dsdf

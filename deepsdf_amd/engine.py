@@ -1,0 +1,199 @@
+"""Device-side state of one decoder replica and the thin calls into libdsdf_hip.so.
+
+Everything the kernels touch lives in flat fp32 arenas on one GPU:
+  params / grads / exp_avg / exp_avg_sq  [n_params]   reference named_parameters() order (net.NetSpec.params)
+  packed                                  W and W^T of every layer in the padded MFMA layout
+  workspace                               activations, dP ping-pong, split-K slabs, partials (grown on demand)
+PyTorch only provides the memory and the stream.  There is no CPU path: every method needs a CUDA device.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from .net import NetSpec, dropout_layer_key
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Engine:
+    def __init__(self, spec: NetSpec, device="cuda"):
+        self.spec = spec
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.DsdfError("deepsdf_amd.Engine needs a CUDA/HIP device (no CPU fallback)")
+        self.lib = _lib.lib()
+        self.cnet = spec.c_struct()
+        lay = _lib.DsdfParamLayout()
+        _lib.check(self.lib.dsdf_param_layout(C.byref(self.cnet), C.byref(lay)))
+        if lay.total != spec.n_params:
+            raise _lib.DsdfError(f"param layout mismatch: C {lay.total} vs host {spec.n_params}")
+        for p in spec.params:
+            off = {"bias": lay.bias_off, "g": lay.g_off, "v": lay.v_off, "weight": lay.v_off}[p.kind][p.layer]
+            if off != p.offset:
+                raise _lib.DsdfError(f"param layout mismatch at {p.name}: C {off} vs host {p.offset}")
+        n = C.c_int64()
+        _lib.check(self.lib.dsdf_packed_floats(C.byref(self.cnet), C.byref(n)))
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.params = torch.zeros(spec.n_params, **f32)
+        self.grads = torch.zeros(spec.n_params, **f32)
+        self.exp_avg = torch.zeros(spec.n_params, **f32)
+        self.exp_avg_sq = torch.zeros(spec.n_params, **f32)
+        self.packed = torch.zeros(n.value, **f32)
+        self.loss = torch.zeros(1, **f32)
+        self.clip = torch.zeros(2, **f32)   # [norm, coef]
+        self._ws = None
+        self.step = 0
+        self.weights_dirty = True
+
+    # ---- parameter access ------------------------------------------------------------------------------
+    def view(self, arena, p):
+        return arena[p.offset:p.offset + p.numel].view(p.shape)
+
+    def named_views(self, arena=None):
+        arena = self.params if arena is None else arena
+        return {p.name: self.view(arena, p) for p in self.spec.params}
+
+    def load_params(self, state):
+        """state: dict reference-key -> tensor (any device); a leading 'module.' is accepted."""
+        for p in self.spec.params:
+            t = state.get(p.name, state.get("module." + p.name))
+            if t is None:
+                raise KeyError(f"missing parameter {p.name}")
+            if tuple(t.shape) != p.shape:
+                raise ValueError(f"shape mismatch for {p.name}: {tuple(t.shape)} vs {p.shape}")
+            self.view(self.params, p).copy_(t.to(self.device, torch.float32))
+        self.weights_dirty = True
+
+    def init_like_reference(self, generator=None):
+        """nn.Linear default init (kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(in)) for weight and bias), g = ||v||_row
+        (parametrizations.weight_norm initialises original0 to the row norms), deep_sdf_decoder.py:50-57."""
+        for l in range(self.spec.n_layers):
+            o, i = self.spec.out_dim[l], self.spec.in_dim[l]
+            bound = 1.0 / math.sqrt(i)
+            w = (torch.rand(o, i, generator=generator) * 2 - 1) * bound
+            b = (torch.rand(o, generator=generator) * 2 - 1) * bound
+            for p in self.spec.params:
+                if p.layer != l:
+                    continue
+                src = {"bias": b, "v": w, "weight": w, "g": w.norm(dim=1, keepdim=True)}[p.kind]
+                self.view(self.params, p).copy_(src.to(self.device))
+        self.weights_dirty = True
+
+    # ---- workspace ----------------------------------------------------------------------------------------
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def train_workspace(self, n_points, n_segments):
+        b = C.c_size_t()
+        _lib.check(self.lib.dsdf_workspace_bytes(C.byref(self.cnet), n_points, n_segments, C.byref(b)))
+        return self._workspace(b.value)
+
+    # ---- weights -----------------------------------------------------------------------------------------
+    def materialize(self):
+        _lib.check(self.lib.dsdf_materialize_weights(C.byref(self.cnet), _ptr(self.params), _ptr(self.packed), _stream()))
+        self.weights_dirty = False
+
+    def _fresh_weights(self):
+        if self.weights_dirty:
+            self.materialize()
+
+    # ---- inference ----------------------------------------------------------------------------------------
+    def decode(self, inputs, max_chunk=1 << 18):
+        """inputs [n, L+G] fp32 cuda -> sdf [n, 1] (eval-mode Decoder.forward / decode_sdf)."""
+        self._fresh_weights()
+        x = inputs.to(self.device, torch.float32)
+        if x.dim() != 2 or x.shape[1] != self.spec.in_dim[0]:
+            raise ValueError(f"expected input [n, {self.spec.in_dim[0]}], got {tuple(x.shape)}")
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        n = x.shape[0]
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        b = C.c_size_t()
+        _lib.check(self.lib.dsdf_decode_workspace_bytes(C.byref(self.cnet), min(n, max_chunk), C.byref(b)))
+        ws = self._workspace(b.value)
+        for s in range(0, n, max_chunk):
+            e = min(n, s + max_chunk)
+            xs = x[s:e]
+            _lib.check(self.lib.dsdf_decode(C.byref(self.cnet), _ptr(self.packed), _ptr(self.params), _ptr(xs),
+                                            xs.stride(0), e - s, C.c_void_p(out.data_ptr() + 4 * s), _ptr(ws),
+                                            ws.numel(), _stream()))
+        return out.view(n, 1)
+
+    # ---- module path (autograd) -----------------------------------------------------------------------------
+    def module_forward(self, x, training, seed=0, step=0):
+        self._fresh_weights()
+        n = x.shape[0]
+        ws = self.train_workspace(n, 0)
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        keys = (C.c_uint32 * _lib.MAX_LAYERS)(*[dropout_layer_key(seed, step, l) for l in range(_lib.MAX_LAYERS)])
+        _lib.check(self.lib.dsdf_module_forward(C.byref(self.cnet), _ptr(self.packed), _ptr(self.params), _ptr(x),
+                                                x.stride(0), n, int(training), keys, _ptr(out), _ptr(ws), ws.numel(),
+                                                _stream()))
+        return out.view(n, 1)
+
+    def module_backward(self, d_sdf, n, training, need_input_grad, accumulate):
+        ws = self.train_workspace(n, 0)
+        d_in = torch.empty(n, self.spec.in_dim[0], dtype=torch.float32, device=self.device) if need_input_grad else None
+        _lib.check(self.lib.dsdf_module_backward(C.byref(self.cnet), _ptr(self.packed), _ptr(self.params), _ptr(d_sdf), n,
+                                                 int(training), _ptr(self.grads), int(accumulate), _ptr(d_in),
+                                                 self.spec.in_dim[0], _ptr(ws), ws.numel(), _stream()))
+        return d_in
+
+    # ---- training --------------------------------------------------------------------------------------------
+    def train_forward_backward(self, latents, dlat, seg_scene, seg_offset, xyz, sdf_gt, *, n_norm, clamp_dist,
+                               reg_coef, code_bound, training=True, seed=0, row_offset=0, accumulate=False,
+                               sdf_out=None, step=None):
+        """One chunk of train_deep_sdf.py:509-533.  Gradients land in self.grads / dlat, loss in self.loss."""
+        self._fresh_weights()
+        n, R = xyz.shape[0], seg_scene.shape[0]
+        ws = self.train_workspace(n, R)
+        b = _lib.DsdfBatch(seg_scene.data_ptr(), seg_offset.data_ptr(), R, xyz.data_ptr(), sdf_gt.data_ptr(), n,
+                           int(n_norm), int(row_offset))
+        cfg = _lib.DsdfLossCfg()
+        cfg.clamp_dist, cfg.reg_coef = float(clamp_dist), float(reg_coef)
+        cfg.code_bound = float(code_bound) if code_bound is not None else -1.0
+        cfg.training = int(training)
+        st = self.step if step is None else step
+        for l in range(_lib.MAX_LAYERS):
+            cfg.dropout_key[l] = dropout_layer_key(seed, st, l)
+        _lib.check(self.lib.dsdf_train_forward_backward(
+            C.byref(self.cnet), _ptr(self.packed), _ptr(self.params), _ptr(latents), latents.shape[0], C.byref(b),
+            C.byref(cfg), _ptr(self.grads), _ptr(dlat), _ptr(self.loss), _ptr(sdf_out), int(accumulate), _ptr(ws),
+            ws.numel(), _stream()))
+
+    def grad_norm(self, max_norm):
+        """clip_grad_norm_ coefficient into self.clip[1] (device); returns the device tensor [norm, coef]."""
+        ws = self._workspace(1 << 16)
+        _lib.check(self.lib.dsdf_grad_norm(_ptr(self.grads), self.spec.n_params, float(max_norm), _ptr(self.clip),
+                                           C.c_void_p(self.clip.data_ptr() + 4), _ptr(ws), ws.numel(), _stream()))
+        return self.clip
+
+    def adam_step(self, latents, dlat, lat_m, lat_v, lr_decoder, lr_latent, *, clip=False, betas=(0.9, 0.999), eps=1e-8):
+        self.step += 1
+        cfg = _lib.DsdfAdamCfg(self.step, float(lr_decoder), float(lr_latent), betas[0], betas[1], eps,
+                               (self.clip.data_ptr() + 4) if clip else None)
+        nlat = latents.numel() if latents is not None else 0
+        _lib.check(self.lib.dsdf_adam_step(C.byref(self.cnet), _ptr(self.params), _ptr(self.grads), _ptr(self.exp_avg),
+                                           _ptr(self.exp_avg_sq), _ptr(latents), _ptr(dlat), _ptr(lat_m), _ptr(lat_v),
+                                           nlat, C.byref(cfg), _ptr(self.packed), _stream()))
+        self.weights_dirty = False
+
+
+def make_segments(indices):
+    """Per-point scene indices [N] (the reference's `indices.unsqueeze(-1).repeat(1, S)` layout, possibly chunked)
+    -> (seg_scene [R], seg_offset [R+1]) int64 on the same device."""
+    scenes, counts = torch.unique_consecutive(indices, return_counts=True)
+    off = torch.zeros(scenes.numel() + 1, dtype=torch.int64, device=indices.device)
+    off[1:] = torch.cumsum(counts, 0)
+    return scenes.to(torch.int64).contiguous(), off

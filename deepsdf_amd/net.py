@@ -1,0 +1,130 @@
+"""Architecture description shared by the host code and the C ABI.
+
+``NetSpec`` takes the reference Decoder's constructor arguments (deep_sdf/networks/deep_sdf_decoder.py:10-23),
+does its layer-size arithmetic (:29-48) and produces (a) the ``DsdfNet`` POD of include/dsdf.h and (b) the
+flat parameter-arena layout in the reference module's ``named_parameters()`` order, with the reference's
+state-dict key names (``lin{i}.bias``, ``lin{i}.parametrizations.weight.original0/1``, ``lin{i}.weight``).
+"""
+from dataclasses import dataclass
+from typing import List, Tuple
+
+from . import _lib
+
+
+@dataclass(frozen=True)
+class ParamInfo:
+    name: str            # reference state-dict key (without any "module." prefix)
+    shape: Tuple[int, ...]
+    offset: int          # floats from the start of the decoder arena
+    layer: int
+    kind: str            # "bias" | "g" | "v" | "weight"
+
+    @property
+    def numel(self):
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+
+class NetSpec:
+    """Validated architecture.  Variants the HIP path does not implement raise NotImplementedError here --
+    there is no silent fallback."""
+
+    def __init__(self, latent_size, dims, geom_dimension, dropout=None, dropout_prob=0.0, norm_layers=(),
+                 latent_in=(), weight_norm=False, xyz_in_all=None, use_tanh=False, latent_dropout=False):
+        if xyz_in_all:
+            raise NotImplementedError("xyz_in_all=True is not implemented by the HIP decoder (no shipped spec uses it)")
+        if latent_dropout:
+            raise NotImplementedError("latent_dropout=True is not implemented by the HIP decoder (no shipped spec uses it)")
+        norm_layers = tuple(norm_layers or ())
+        latent_in = tuple(latent_in or ())
+        if (not weight_norm) and len(norm_layers) > 0:
+            raise NotImplementedError("LayerNorm variant (norm_layers without weight_norm) is not implemented by the HIP decoder")
+        self.latent_size = int(latent_size)
+        self.geom_dimension = int(geom_dimension)
+        self.dims = [int(d) for d in dims]
+        self.dropout = None if dropout is None else tuple(int(d) for d in dropout)
+        self.dropout_prob = float(dropout_prob)
+        self.norm_layers = norm_layers
+        self.latent_in = latent_in
+        self.weight_norm = bool(weight_norm)
+        self.use_tanh = bool(use_tanh)
+        d = [self.latent_size + self.geom_dimension] + self.dims + [1]
+        self.n_layers = len(d) - 1
+        if self.n_layers > _lib.MAX_LAYERS:
+            raise NotImplementedError(f"more than {_lib.MAX_LAYERS} linear layers")
+        self.in_dim, self.out_dim = [], []
+        for l in range(self.n_layers):
+            self.in_dim.append(d[l])
+            self.out_dim.append(d[l + 1] - d[0] if (l + 1) in latent_in else d[l + 1])
+        self.wn = [bool(weight_norm and l in norm_layers) for l in range(self.n_layers)]
+        self.skip = [l in latent_in for l in range(self.n_layers)]
+        self.drop = [bool(self.dropout is not None and l in self.dropout and l < self.n_layers - 1)
+                     for l in range(self.n_layers)]
+        # parameter arena, named_parameters() order
+        self.params: List[ParamInfo] = []
+        off = 0
+        for l in range(self.n_layers):
+            o, i = self.out_dim[l], self.in_dim[l]
+            if self.wn[l]:
+                entries = [(f"lin{l}.bias", (o,), "bias"),
+                           (f"lin{l}.parametrizations.weight.original0", (o, 1), "g"),
+                           (f"lin{l}.parametrizations.weight.original1", (o, i), "v")]
+            else:
+                entries = [(f"lin{l}.weight", (o, i), "weight"), (f"lin{l}.bias", (o,), "bias")]
+            for name, shape, kind in entries:
+                p = ParamInfo(name, shape, off, l, kind)
+                self.params.append(p)
+                off += p.numel
+        self.n_params = off
+
+    def kwargs(self):
+        return dict(dims=self.dims, geom_dimension=self.geom_dimension, dropout=self.dropout,
+                    dropout_prob=self.dropout_prob, norm_layers=self.norm_layers, latent_in=self.latent_in,
+                    weight_norm=self.weight_norm, use_tanh=self.use_tanh)
+
+    def c_struct(self) -> "_lib.DsdfNet":
+        n = _lib.DsdfNet()
+        n.n_layers = self.n_layers
+        n.latent_size = self.latent_size
+        n.geom_dim = self.geom_dimension
+        wm = dm = sm = 0
+        for l in range(self.n_layers):
+            n.in_dim[l] = self.in_dim[l]
+            n.out_dim[l] = self.out_dim[l]
+            wm |= int(self.wn[l]) << l
+            dm |= int(self.drop[l]) << l
+            sm |= int(self.skip[l]) << l
+        n.weight_norm_mask, n.dropout_mask, n.skip_mask = wm, dm, sm
+        n.dropout_p = self.dropout_prob
+        n.use_tanh = int(self.use_tanh)
+        return n
+
+    @property
+    def w_mac(self):
+        """sum over layers of in*out: multiply-accumulates per point per forward pass."""
+        return sum(i * o for i, o in zip(self.in_dim, self.out_dim))
+
+
+# ---- dropout hash keys (host side; spec = oracle/deepsdf_oracle.py dropout_layer_key) -------------------
+
+def _lowbias32(x):
+    x &= 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
+def dropout_layer_key(seed: int, step: int, layer: int) -> int:
+    seed &= (1 << 64) - 1
+    step &= (1 << 64) - 1
+    k = _lowbias32((seed & 0xFFFFFFFF) ^ 0x9E3779B9)
+    k = _lowbias32(k ^ (seed >> 32))
+    k = _lowbias32(k + (step & 0xFFFFFFFF))
+    k = _lowbias32(k ^ (step >> 32))
+    k = _lowbias32(k + (layer + 1) * 0x9E3779B1)
+    return k

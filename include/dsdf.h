@@ -1,0 +1,162 @@
+/* dsdf.h -- C ABI of libdsdf_hip.so: the DeepSDF auto-decoder training step on MI355X (gfx950).
+ *
+ * The reference (mkofler96/DeepSDF) has NO C/FFI boundary for this path: its hot loop is inline Python
+ * (train_deep_sdf.py:481-545) over torch ops.  This header is therefore the boundary that a binding of
+ * that loop would target; every entry point names the reference lines it replaces.  The Python side of
+ * this repo (deepsdf_amd/_lib.py) binds it with ctypes; INTEGRATION.md shows the stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (DSDF_E_*); dsdf_last_error() returns a
+ *     thread-local message.  Nothing throws, nothing allocates device memory, nothing synchronises the
+ *     device: work is enqueued on the caller's stream (hipStream_t passed as void*).
+ *   - every pointer is a DEVICE pointer owned by the caller (a torch tensor kept alive by the caller),
+ *     16-byte aligned, unless marked [host].
+ *   - all tensors are row-major fp32; index arrays are int64.
+ *   - decoder parameters, their gradients and Adam moments live in flat "arenas" whose layout is the
+ *     reference module's named_parameters() order (dsdf_param_layout).
+ */
+#ifndef DSDF_H
+#define DSDF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSDF_MAX_LAYERS 16
+#define DSDF_ABI_VERSION 1
+
+enum {
+  DSDF_OK = 0,
+  DSDF_E_INVALID = -1,   /* bad argument (shape, alignment, unsupported NetworkSpecs variant) */
+  DSDF_E_WORKSPACE = -2, /* workspace too small */
+  DSDF_E_LAUNCH = -3     /* a HIP call failed */
+};
+
+/* Architecture of deep_sdf/networks/deep_sdf_decoder.py:10-73 after its layer-size arithmetic (:29-48).
+ * Layer l is Linear(in_dim[l] -> out_dim[l]); hidden layers apply ReLU (+dropout); the last layer
+ * (out_dim == 1) is followed by tanh (twice if use_tanh), :94-95,108-109. */
+typedef struct DsdfNet {
+  int32_t n_layers;                 /* number of Linear layers (= len(dims)+1) */
+  int32_t latent_size;              /* L  (CodeLength) */
+  int32_t geom_dim;                 /* G  (geom_dimension) */
+  int32_t in_dim[DSDF_MAX_LAYERS];
+  int32_t out_dim[DSDF_MAX_LAYERS];
+  uint32_t weight_norm_mask;        /* bit l: layer l is weight-normed (g = original0, v = original1) */
+  uint32_t dropout_mask;            /* bit l: F.dropout after layer l's ReLU (:105-106) */
+  uint32_t skip_mask;               /* bit l: layer l's input is [x || x0]  (latent_in, :88-89) */
+  float dropout_p;
+  int32_t use_tanh;
+} DsdfNet;
+
+/* Offsets (in floats) of every parameter tensor inside the decoder arena, named_parameters() order:
+ * weight-normed layer: bias, g [out,1], v [out,in];  plain layer: weight [out,in], bias. */
+typedef struct DsdfParamLayout {
+  int64_t total;
+  int64_t bias_off[DSDF_MAX_LAYERS];
+  int64_t g_off[DSDF_MAX_LAYERS];   /* -1 for plain layers */
+  int64_t v_off[DSDF_MAX_LAYERS];   /* v (weight-normed) or weight (plain) */
+} DsdfParamLayout;
+
+/* Batch of one optimiser (sub-)step, train_deep_sdf.py:483-501.  Points are grouped in R contiguous
+ * runs ("segments"), run r = points [seg_offset[r], seg_offset[r+1]) all of scene seg_scene[r]; this is
+ * the layout `indices.unsqueeze(-1).repeat(1, S)` (+ torch.chunk) always produces. */
+typedef struct DsdfBatch {
+  const int64_t* seg_scene;   /* [R]   row of the latent table */
+  const int64_t* seg_offset;  /* [R+1] seg_offset[0] = 0, seg_offset[R] = n_points */
+  int64_t n_segments;         /* R */
+  const float* xyz;           /* [n_points, G] */
+  const float* sdf_gt;        /* [n_points]  (unclamped; clamped inside, :493) or NULL for inference */
+  int64_t n_points;           /* N of this chunk */
+  int64_t n_norm;             /* loss normaliser: the FULL step's point count, also across ranks (:519) */
+  int64_t row_offset;         /* index of this chunk's first point inside the step (dropout hash) */
+} DsdfBatch;
+
+typedef struct DsdfLossCfg {
+  float clamp_dist;           /* ClampingDistance delta (:335,493,517) */
+  float reg_coef;             /* CodeRegularizationLambda * min(1, epoch/100), 0 disables (:523-527) */
+  float code_bound;           /* CodeBound (Embedding max_norm, :343,385); <= 0 disables the renorm */
+  int32_t training;           /* 1: dropout active (decoder.train(), :477) */
+  uint32_t dropout_key[DSDF_MAX_LAYERS]; /* [host-computed] per-layer hash keys (oracle: dropout_layer_key) */
+} DsdfLossCfg;
+
+typedef struct DsdfAdamCfg {
+  int64_t step;               /* 1-based, shared by every tensor (torch/optim/adam.py) */
+  float lr_decoder, lr_latent;/* LearningRateSchedule[0], [1] at this epoch (:315-318) */
+  float beta1, beta2, eps;    /* torch defaults 0.9, 0.999, 1e-8 (:400) */
+  const float* grad_scale;    /* optional device scalar multiplying decoder grads (grad clipping), or NULL */
+} DsdfAdamCfg;
+
+/* ---- introspection ------------------------------------------------------------------------------ */
+int dsdf_abi_version(void);
+const char* dsdf_last_error(void);
+int dsdf_param_layout(const DsdfNet* net, DsdfParamLayout* out);          /* [host] */
+int dsdf_packed_floats(const DsdfNet* net, int64_t* n_floats);            /* [host] size of the packed-weight buffer */
+int dsdf_workspace_bytes(const DsdfNet* net, int64_t n_points, int64_t n_segments, size_t* bytes); /* [host] train/module */
+int dsdf_decode_workspace_bytes(const DsdfNet* net, int64_t n_points, size_t* bytes);                /* [host] dsdf_decode */
+
+/* ---- weights -------------------------------------------------------------------------------------
+ * W = g * v / ||v||_row for weight-normed layers (torch._weight_norm via parametrizations.weight_norm,
+ * deep_sdf_decoder.py:50-55), plain copy otherwise; written as W [out,in] and W^T [in,out] in padded,
+ * MFMA-friendly layout.  Must be called after every parameter change (dsdf_adam_step does it itself). */
+int dsdf_materialize_weights(const DsdfNet* net, const float* params, float* packed, void* stream);
+
+/* ---- inference: deep_sdf/utils.py:54-65 decode_sdf / Decoder.forward in eval mode ------------------
+ * input [n, L+G] (latent first, xyz last) with row stride ld_in floats -> sdf [n]. */
+int dsdf_decode(const DsdfNet* net, const float* packed, const float* params, const float* input, int64_t ld_in,
+                int64_t n, float* sdf_out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- module path: Decoder.forward / autograd backward on an explicit input (plugin seam,
+ * train_deep_sdf.py:275,514).  forward keeps activations in ws; backward consumes them. */
+int dsdf_module_forward(const DsdfNet* net, const float* packed, const float* params, const float* input,
+                        int64_t ld_in, int64_t n, int32_t training, const uint32_t* dropout_key /*[host]*/,
+                        float* sdf_out, void* ws, size_t ws_bytes, void* stream);
+int dsdf_module_backward(const DsdfNet* net, const float* packed, const float* params, const float* d_sdf,
+                         int64_t n, int32_t training, float* grads /*arena, overwritten or accumulated*/,
+                         int32_t accumulate, float* d_input /*[n, ld_din] or NULL*/, int64_t ld_din,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/* ---- training step ---------------------------------------------------------------------------------
+ * dsdf_train_forward_backward = train_deep_sdf.py:509-533 for one chunk: max-norm renorm of the looked-up
+ * latent rows (in place), gather + concat, decoder forward, clamp, sum-L1 / n_norm, code regulariser,
+ * backward.  grads (decoder arena) and dlat [S_tot, L] are overwritten when accumulate == 0, added to
+ * otherwise (--batch_split).  loss_out: device float, same accumulate rule.  sdf_out may be NULL. */
+int dsdf_train_forward_backward(const DsdfNet* net, const float* packed, const float* params,
+                                float* latent_table, int64_t n_scenes, const DsdfBatch* batch,
+                                const DsdfLossCfg* cfg, float* grads, float* dlat, float* loss_out,
+                                float* sdf_out, int32_t accumulate, void* ws, size_t ws_bytes, void* stream);
+
+/* clip_grad_norm_ over the decoder arena (train_deep_sdf.py:541-543): writes total norm and the clip
+ * coefficient min(1, max_norm/(norm+1e-6)) to two device floats. */
+int dsdf_grad_norm(const float* grads, int64_t n, float max_norm, float* norm_out, float* coef_out,
+                   void* ws, size_t ws_bytes, void* stream);
+
+/* optimizer_all.step() (train_deep_sdf.py:545): fused Adam over the decoder arena (lr_decoder) and the
+ * WHOLE latent table (lr_latent; dense update, rows absent from the batch keep moving by momentum),
+ * then re-materialises the packed weights. */
+int dsdf_adam_step(const DsdfNet* net, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                   float* latent_table, const float* dlat, float* lat_exp_avg, float* lat_exp_avg_sq,
+                   int64_t n_latent_floats, const DsdfAdamCfg* cfg, float* packed, void* stream);
+
+/* latent-only Adam (frozen decoder; config 4): updates only the given latent arena. */
+int dsdf_adam_latent_only(float* latent, const float* dlat, float* exp_avg, float* exp_avg_sq, int64_t n,
+                          const DsdfAdamCfg* cfg, void* stream);
+
+/* ---- building blocks (exported for the parity tests and profiling; not needed by a trainer) --------- */
+/* C[M,N] = A[M,K] * B[N,K]^T (+bias) */
+int dsdf_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
+                 int64_t N, int64_t K, const float* bias, void* stream);
+/* C[M,N] = A[K,M]^T * B[K,N]  (split-K inside; ws holds the partial slabs) */
+int dsdf_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
+                 int64_t N, int64_t K, void* ws, size_t ws_bytes, void* stream);
+/* keep-mask of the dropout hash as 0/1 bytes [rows, cols] (spec: oracle/deepsdf_oracle.py dropout_keep) */
+int dsdf_dropout_mask(uint32_t key, float p, int64_t rows, int64_t cols, int64_t row_offset, uint8_t* out,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSDF_H */

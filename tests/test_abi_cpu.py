@@ -1,0 +1,72 @@
+"""CPU (no GPU needed): the C-ABI library builds, loads, and exports every symbol include/dsdf.h declares;
+host-side layout logic agrees with the library.  No compute call is made."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from deepsdf_amd.build import build_library
+    build_library()
+    from deepsdf_amd import _lib
+    return _lib.lib()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "dsdf.h")).read()
+    names = set(re.findall(r"\b(dsdf_[a-z_0-9]+)\s*\(", hdr))
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/dsdf.h but not exported"
+    from deepsdf_amd._lib import PROTOTYPES
+    assert names == set(PROTOTYPES) | {"dsdf_last_error"}
+
+
+def test_layout_and_sizes(lib):
+    from deepsdf_amd import _lib
+    from deepsdf_amd.net import NetSpec
+    spec = NetSpec(256, [512] * 8, 3, dropout=list(range(8)), dropout_prob=0.2, norm_layers=list(range(8)),
+                   latent_in=[4], weight_norm=True)
+    assert spec.n_params == 1843195 and spec.w_mac == 1835520
+    assert spec.out_dim[3] == 253 and spec.in_dim[4] == 512
+    net = spec.c_struct()
+    lay = _lib.DsdfParamLayout()
+    assert lib.dsdf_param_layout(C.byref(net), C.byref(lay)) == 0
+    assert lay.total == spec.n_params
+    for p in spec.params:
+        off = {"bias": lay.bias_off, "g": lay.g_off, "v": lay.v_off, "weight": lay.v_off}[p.kind][p.layer]
+        assert off == p.offset, p.name
+    b = C.c_size_t()
+    assert lib.dsdf_workspace_bytes(C.byref(net), 16384, 64, C.byref(b)) == 0
+    assert 300e6 < b.value < 600e6
+    assert lib.dsdf_decode_workspace_bytes(C.byref(net), 16384, C.byref(b)) == 0
+    assert b.value < 200e6
+
+
+def test_invalid_nets_rejected(lib):
+    from deepsdf_amd.net import NetSpec
+    with pytest.raises(NotImplementedError):
+        NetSpec(4, [32] * 2, 3, xyz_in_all=True)
+    with pytest.raises(NotImplementedError):
+        NetSpec(4, [32] * 2, 3, norm_layers=[0], weight_norm=False)
+    spec = NetSpec(4, [32, 32, 32], 3, latent_in=[1, 2])
+    b = C.c_size_t()
+    net = spec.c_struct()
+    assert lib.dsdf_workspace_bytes(C.byref(net), 8, 1, C.byref(b)) == -1
+    assert b"latent_in" in lib.dsdf_last_error()
+
+
+def test_param_names_match_oracle():
+    from deepsdf_amd.net import NetSpec
+    from oracle import deepsdf_oracle as orc
+    kw = dict(dims=[64] * 4, dropout=[0, 1, 2, 3], dropout_prob=0.2, norm_layers=[0, 1, 2, 3], latent_in=[2],
+              weight_norm=True, geom_dimension=3)
+    assert [p.name for p in NetSpec(4, **kw).params] == orc.param_names(orc.make_net(4, **kw))
+    from deepsdf_amd.net import dropout_layer_key
+    assert dropout_layer_key(1234, 5, 3) == orc.dropout_layer_key(1234, 5, 3)
+    assert dropout_layer_key((1 << 40) + 7, (1 << 33) + 1, 0) == orc.dropout_layer_key((1 << 40) + 7, (1 << 33) + 1, 0)

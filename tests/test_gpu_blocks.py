@@ -1,0 +1,87 @@
+"""-m gpu: building-block kernels through the C ABI against plain torch fp32 / the oracle's integer hash."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_io import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from deepsdf_amd import _lib as L
+    return L, L.lib()
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 512, 512), (300, 253, 259), (64, 1, 40), (1000, 260, 253),
+                                   (16384, 512, 512)])
+def test_gemm_nt(M, N, K):
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    lda = ldb = (K + 3) // 4 * 4
+    A = torch.zeros(M, lda); A[:, :K] = torch.randn(M, K, generator=g)
+    B = torch.zeros(N, ldb); B[:, :K] = torch.randn(N, K, generator=g)
+    if lda > K:  # poison the padding: the kernel must zero-fill beyond K itself
+        A[:, K:] = float("nan"); B[:, K:] = float("nan")
+    bias = torch.randn(N, generator=g)
+    Ad, Bd, bd = A.cuda(), B.cuda(), bias.cuda()
+    Cd = torch.full((M, N + 3), 7.0, device="cuda")
+    L.check(lib.dsdf_gemm_nt(Ad.data_ptr(), lda, Bd.data_ptr(), ldb, Cd.data_ptr(), N + 3, M, N, K, bd.data_ptr(), _s()))
+    ref = (A[:, :K].double() @ B[:, :K].double().t() + bias.double())
+    assert rel_err(Cd[:, :N].cpu(), ref) < 2e-6
+    assert bool((Cd[:, N:] == 7.0).all())  # nothing written outside [M, N]
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (512, 512, 16384), (253, 259, 1000), (1, 48, 96), (512, 259, 300)])
+def test_gemm_tn(M, N, K):
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    lda, ldb = (M + 3) // 4 * 4 + 4, (N + 3) // 4 * 4
+    A = torch.full((K, lda), float("nan")); A[:, :M] = torch.randn(K, M, generator=g)
+    B = torch.full((K, ldb), float("nan")); B[:, :N] = torch.randn(K, N, generator=g)
+    Ad, Bd = A.cuda(), B.cuda()
+    Cd = torch.zeros(M, N, device="cuda")
+    ws = torch.empty(64 * ((M * N + 63) // 64 * 64) * 4 + 4 * M + 1024, dtype=torch.uint8, device="cuda")
+    L.check(lib.dsdf_gemm_tn(Ad.data_ptr(), lda, Bd.data_ptr(), ldb, Cd.data_ptr(), N, M, N, K, ws.data_ptr(), ws.numel(), _s()))
+    ref = A[:, :M].double().t() @ B[:, :N].double()
+    assert rel_err(Cd.cpu(), ref) < 2e-6
+
+
+def test_gemm_nt_asymmetric_identity():
+    """A = I with an asymmetric B catches a transposed C write (guide section 3)."""
+    L, lib = _lib()
+    n = 128
+    A = torch.eye(n).cuda()
+    B = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 97).cuda()
+    Cd = torch.zeros(n, n, device="cuda")
+    L.check(lib.dsdf_gemm_nt(A.data_ptr(), n, B.data_ptr(), n, Cd.data_ptr(), n, n, n, n, None, _s()))
+    assert torch.equal(Cd, B.t())
+
+
+@pytest.mark.parametrize("row_offset", [0, 37, 4096])
+def test_dropout_hash_bit_exact(row_offset):
+    from oracle import deepsdf_oracle as orc
+    L, lib = _lib()
+    key = orc.dropout_layer_key(99, 3, 5)
+    rows, cols = 301, 512
+    out = torch.zeros(rows, cols, dtype=torch.uint8, device="cuda")
+    L.check(lib.dsdf_dropout_mask(key, 0.2, rows, cols, row_offset, out.data_ptr(), _s()))
+    ref = orc.dropout_keep(key, rows, cols, 0.2, row_offset)
+    assert np.array_equal(out.cpu().numpy().astype(bool), ref)
+
+
+def test_errors_are_reported():
+    L, lib = _lib()
+    from deepsdf_amd.net import NetSpec
+    spec = NetSpec(4, [32, 32], 3)
+    net = spec.c_struct()
+    net.out_dim[spec.n_layers - 1] = 2
+    b = C.c_size_t()
+    assert lib.dsdf_workspace_bytes(C.byref(net), 10, 1, C.byref(b)) == -1
+    assert b"out_dim 1" in lib.dsdf_last_error()

@@ -1,0 +1,140 @@
+"""-m gpu: the HIP path (through the C ABI) against the reference-generated goldens and the oracle.
+
+Tolerances (north_star): forward SDF <= 1e-5 rel, gradients <= 1e-4 rel (norm-wise), post-Adam state <= 1e-5 rel."""
+import math
+
+import pytest
+import torch
+
+from oracle import deepsdf_oracle as orc
+from tests.golden_io import Golden, rel_err
+from tests.hip_helpers import HipTrainer, spec_from_meta
+
+pytestmark = pytest.mark.gpu
+FWD_TOL, GRAD_TOL, PARAM_TOL = 1e-5, 1e-4, 1e-5
+
+TRAIN_CASES = ["g1a_tiny_full", "g1b_lastnorm_tanh", "g1c_plain_clip", "g2_8x512_slice", "g3a_dropout_tiny",
+               "g3b_dropout_8x512", "g4_batch_split2"]
+
+
+@pytest.mark.parametrize("name", TRAIN_CASES)
+def test_golden_train_cases(name):
+    g = Golden(name)
+    m = g.meta
+    spec = spec_from_meta(m)
+    net = orc.make_net(m["L"], **m["net_specs"])
+    params = g.group("params0") if m["store"] == "full" else orc.init_params(net, m["seed"])
+    tr = HipTrainer(spec, params, g.get("lat0/w"))
+    for si in range(m["n_steps"]):
+        i = g.group(f"step{si}/in")
+        r = tr.step(i["idx"], i["xyz"], i["gt"], delta=m["delta"], code_bound=m["code_bound"], code_reg=m["code_reg"],
+                    lam=m["lam"], epoch=m["epoch"], lr=m["lr"], batch_split=m["batch_split"], grad_clip=m["grad_clip"],
+                    seed=m["drop_seed"], want_y=True)
+        o = g.group(f"step{si}/out")
+        assert rel_err(r["y"], o["y"]) <= FWD_TOL, (name, si, "y")
+        assert abs(r["loss"] - float(o["loss"])) <= 1e-5 * abs(float(o["loss"])) + 1e-9, (name, si, "loss")
+        assert rel_err(r["dlat"], g.get(f"step{si}/dlat/w")) <= GRAD_TOL, (name, si, "dlat")
+        for k, ref in g.group(f"step{si}/grads").items():
+            if m["grad_clip"] is None:
+                assert rel_err(r["grads"][k], ref) <= GRAD_TOL, (name, si, k)
+        if m["grad_clip"] is not None:
+            assert abs(r["grad_norm"] - float(o["grad_norm"])) <= 1e-4 * float(o["grad_norm"])
+        for k, ref in g.group(f"step{si}/grads_fro").items():
+            assert abs(float(r["grads"][k].double().norm()) - float(ref)) <= GRAD_TOL * float(ref), (name, si, k)
+        for k, ref in g.group(f"step{si}/grads_corner").items():
+            scale = float(r["grads"][k].abs().max())
+            assert float((r["grads"][k][:8, :8] - ref).abs().max()) <= GRAD_TOL * scale, (name, si, k)
+        P = tr.params()
+        for k, ref in g.group(f"step{si}/params_after").items():
+            assert rel_err(P[k], ref) <= PARAM_TOL, (name, si, k)
+        for k, ref in g.group(f"step{si}/params_after_fro").items():
+            assert abs(float(P[k].double().norm()) - float(ref)) <= PARAM_TOL * float(ref), (name, si, k)
+        assert rel_err(tr.lat.cpu(), g.get(f"step{si}/lat_after/w")) <= PARAM_TOL, (name, si, "lat")
+        am, av = tr.adam_m(), tr.adam_v()
+        for k, ref in g.group(f"step{si}/adam_m").items():
+            mine = tr.lat_m.cpu() if k == "latent" else am[k]
+            assert rel_err(mine, ref) <= GRAD_TOL, (name, si, "m", k)
+        for k, ref in g.group(f"step{si}/adam_v").items():
+            mine = tr.lat_v.cpu() if k == "latent" else av[k]
+            assert rel_err(mine, ref) <= 2 * GRAD_TOL, (name, si, "v", k)
+
+
+@pytest.mark.parametrize("name", ["g8_eval_8x512", "g8_eval_6x128"])
+def test_golden_eval_forward(name):
+    from deepsdf_amd.engine import Engine
+    g = Golden(name)
+    net = orc.make_net(g.meta["L"], **g.meta["net_specs"])
+    eng = Engine(spec_from_meta(g.meta))
+    eng.load_params(orc.init_params(net, g.meta["seed"]))
+    y = eng.decode(g.get("in/x").cuda())
+    assert rel_err(y.cpu().reshape(-1), g.get("out/y")) <= FWD_TOL
+
+
+def test_real_weights_known_answer():
+    from deepsdf_amd.engine import Engine
+    g = Golden("g6_real_weights")
+    eng = Engine(spec_from_meta(g.meta))
+    eng.load_params(g.group("params"))
+    y = eng.decode(torch.zeros(1, g.meta["L"] + 3, device="cuda"))
+    assert abs(float(y) - g.meta["f0_survey"]) < 5e-5
+
+
+BIG = dict(dims=[512] * 8, dropout=list(range(8)), dropout_prob=0.2, norm_layers=list(range(8)), latent_in=[4],
+           xyz_in_all=False, use_tanh=False, latent_dropout=False, weight_norm=True, geom_dimension=3)
+
+
+def _big_batch(B, S, seed):
+    gen = torch.Generator().manual_seed(seed)
+    idx = torch.arange(B).repeat_interleave(S)
+    xyz = torch.rand(B * S, 3, generator=gen) * 2 - 1
+    c = (torch.rand(B, 3, generator=gen) - 0.5) * 0.6
+    r = 0.3 + 0.3 * torch.rand(B, 1, generator=gen)
+    gt = (xyz - c[idx]).norm(dim=1, keepdim=True) - r[idx]
+    return idx, xyz, gt
+
+
+def test_full_size_step_vs_oracle():
+    """BASELINE config 2 at full size: 64 scenes x 256 pts = 16384 pts, L=256, 8x512, dropout 0.2, against the
+    oracle (fp32 CPU) on identical seeded inputs; two optimiser steps."""
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    L, B, S = 256, 64, 256
+    net = orc.make_net(L, **BIG)
+    spec = spec_from_meta(dict(L=L, net_specs=BIG))
+    params = orc.init_params(net, 5)
+    gen = torch.Generator().manual_seed(6)
+    lat0 = torch.randn(B, L, generator=gen) / math.sqrt(L)
+    lat0[3] *= 2.5 / lat0[3].norm()
+    st = orc.TrainState.create({k: v.clone() for k, v in params.items()}, lat0.clone())
+    tr = HipTrainer(spec, params, lat0)
+    for step in range(2):
+        idx, xyz, gt = _big_batch(B, S, 100 + step)
+        ro = orc.train_step(net, st, idx, xyz, gt, delta=0.1, code_bound=1.0, epoch=57, seed=4242)
+        rh = tr.step(idx, xyz, gt, delta=0.1, code_bound=1.0, code_reg=True, lam=1e-4, epoch=57, lr=(5e-4, 1e-3), seed=4242)
+        assert abs(rh["loss"] - ro["loss"]) <= 1e-5 * abs(ro["loss"])
+        for k in ro["grads"]:
+            assert rel_err(rh["grads"][k], ro["grads"][k]) <= GRAD_TOL, (step, k)
+        assert rel_err(rh["dlat"], ro["dlat"]) <= GRAD_TOL
+        P = tr.params()
+        for k in st.params:
+            assert rel_err(P[k], st.params[k]) <= PARAM_TOL, (step, k)
+        assert rel_err(tr.lat.cpu(), st.latents) <= PARAM_TOL
+
+
+def test_full_size_properties():
+    """Size-independent properties at 16384 pts: bit-exact determinism, and batch_split=4 == unsplit."""
+    L, B, S = 256, 64, 256
+    net = orc.make_net(L, **BIG)
+    spec = spec_from_meta(dict(L=L, net_specs=BIG))
+    params = orc.init_params(net, 9)
+    lat0 = torch.randn(B, L, generator=torch.Generator().manual_seed(1)) / math.sqrt(L)
+    idx, xyz, gt = _big_batch(B, S, 77)
+    outs = []
+    for bs in (1, 1, 4):
+        tr = HipTrainer(spec, params, lat0)
+        outs.append(tr.step(idx, xyz, gt, delta=0.1, code_bound=1.0, code_reg=True, lam=1e-4, epoch=200, lr=(5e-4, 1e-3),
+                            batch_split=bs, seed=1, do_adam=False))
+    for k in outs[0]["grads"]:
+        assert torch.equal(outs[0]["grads"][k], outs[1]["grads"][k]), k          # deterministic reductions
+        assert rel_err(outs[2]["grads"][k], outs[0]["grads"][k]) <= 1e-5, k        # accumulation == one pass
+    assert torch.equal(outs[0]["dlat"], outs[1]["dlat"])
+    assert abs(outs[2]["loss"] - outs[0]["loss"]) <= 1e-6 * abs(outs[0]["loss"])
