@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- SDF point-samples/sec per training step (BASELINE.json metric) on MI355X.
+
+One "step" = one full optimiser step of the hot path over one synthetic batch resident in HBM:
+latent renorm + gather + concat -> 8x512 decoder forward (weight-norm, skip@4, dropout 0.2) -> clamped-L1 + code
+regulariser -> backward -> [N>1: RCCL all-reduce of decoder grads] -> Adam on decoder + latent table -> weight
+re-materialisation.  Workload at N=1 = BASELINE.json configs[1]; N>1 = configs[2] (512 scenes sharded, weak scaling).
+
+  python bench.py --gpus 1 --steps 50 --warmup 10
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = 157.3          # fp32 MFMA dense peak, MI355X_MICROARCH.md "Peak FP32 (matrix)"
+NET = dict(dims=[512] * 8, dropout=list(range(8)), dropout_prob=0.2, norm_layers=list(range(8)), latent_in=[4],
+           xyz_in_all=False, use_tanh=False, latent_dropout=False, weight_norm=True, geom_dimension=3)
+L, SCENES_PER_BATCH, SAMPLES = 256, 64, 256   # 64 x 256 = 16384 pts/step
+
+
+def synth_batches(n_batches, scene_lo, scene_hi, device, seed):
+    """Seeded sphere-SDF batches: every batch = SCENES_PER_BATCH scenes x SAMPLES points, staged on device."""
+    gen = torch.Generator().manual_seed(seed)
+    n_scenes = scene_hi - scene_lo
+    c = (torch.rand(n_scenes, 3, generator=gen) - 0.5) * 0.6
+    r = 0.3 + 0.3 * torch.rand(n_scenes, 1, generator=gen)
+    out = []
+    for b in range(n_batches):
+        scenes = (torch.randperm(n_scenes, generator=gen)[:SCENES_PER_BATCH]).sort().values if n_scenes > SCENES_PER_BATCH \
+            else torch.arange(n_scenes)
+        idx = scenes.repeat_interleave(SAMPLES)
+        half = idx.numel() // 2
+        xyz = torch.rand(idx.numel(), 3, generator=gen) * 2 - 1
+        d = torch.randn(idx.numel() - half, 3, generator=gen)
+        d = d / d.norm(dim=1, keepdim=True)
+        sel = torch.randperm(idx.numel(), generator=gen)[:idx.numel() - half]
+        xyz[sel] = c[idx[sel]] + r[idx[sel]] * d + 0.05 * torch.randn(sel.numel(), 3, generator=gen)
+        gt = (xyz - c[idx]).norm(dim=1, keepdim=True) - r[idx]
+        seg_off = torch.arange(0, idx.numel() + 1, SAMPLES, dtype=torch.int64)
+        out.append(dict(idx=idx, seg_scene=scenes.to(torch.int64).to(device), seg_offset=seg_off.to(device),
+                        xyz=xyz.to(device).contiguous(), gt=gt.reshape(-1).to(device).contiguous(),
+                        xyz_cpu=xyz, gt_cpu=gt))
+    return out
+
+
+def cpu_baseline(seconds=20.0):
+    """The oracle (CPU restatement, kind 'port') timed on this host's cores on a bounded sample of the SAME workload:
+    whole optimiser steps of config 2 (16384 pts), as many as fit in ~`seconds`."""
+    from oracle import deepsdf_oracle as orc
+    net = orc.make_net(L, **NET)
+    params = orc.init_params(net, 0)
+    gen = torch.Generator().manual_seed(1)
+    lat = torch.randn(SCENES_PER_BATCH, L, generator=gen) / math.sqrt(L)
+    st = orc.TrainState.create(params, lat)
+    b = synth_batches(1, 0, SCENES_PER_BATCH, "cpu", 7)[0]
+    masks = [orc.dropout_masks(net, 0, 0, b["idx"].numel())]
+    kw = dict(delta=0.1, code_bound=1.0, epoch=1, masks_per_chunk=masks)
+    orc.train_step(net, st, b["idx"], b["xyz_cpu"], b["gt_cpu"], **kw)   # warm-up (first call pages MKL in)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.train_step(net, st, b["idx"], b["xyz_cpu"], b["gt_cpu"], **kw)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 64:
+            break
+    return dict(value=n * b["idx"].numel() / dt, unit="point-samples/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n} full optimiser steps of the 16384-pt config-2 workload (oracle/deepsdf_oracle.py, torch CPU fp32, "
+                       f"dropout masks precomputed), {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event instrumented pass")
+    args = ap.parse_args()
+
+    from deepsdf_amd import _lib, dist
+    from deepsdf_amd.engine import Engine
+    from deepsdf_amd.net import NetSpec
+
+    rank, local, world = dist.init()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    spec = NetSpec(L, **NET)
+    eng = Engine(spec, dev)
+    eng.init_like_reference(torch.Generator().manual_seed(0))      # identical on every rank (replicated decoder)
+    total_scenes = SCENES_PER_BATCH if world == 1 else 512          # configs[1] / configs[2]
+    lo, hi = dist.owned_scenes(total_scenes, rank, world)
+    gen = torch.Generator().manual_seed(100 + rank)
+    lat = (torch.randn(hi - lo, L, generator=gen) / math.sqrt(L)).to(dev)
+    dlat, lat_m, lat_v = torch.zeros_like(lat), torch.zeros_like(lat), torch.zeros_like(lat)
+    batches = synth_batches(8, lo, hi, dev, 1000 + rank)
+    n_local = SCENES_PER_BATCH * SAMPLES
+    n_global = n_local * world
+
+    def step(i):
+        b = batches[i % len(batches)]
+        eng.train_forward_backward(lat, dlat, b["seg_scene"], b["seg_offset"], b["xyz"], b["gt"], n_norm=n_global,
+                                   clamp_dist=0.1, reg_coef=1e-4 * min(1, 1 / 100), code_bound=1.0, training=True,
+                                   seed=rank, row_offset=0)
+        dist.allreduce_sum_(eng.grads)
+        eng.adam_step(lat, dlat, lat_m, lat_v, 5e-4, 1e-3)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = dist.max_over_ranks(time.perf_counter() - t0, dev)
+    loss = float(eng.loss.item())
+    if not math.isfinite(loss):
+        raise SystemExit("non-finite loss in the timed region")
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = n_global * args.steps / elapsed
+    flop_per_pt = 6 * spec.w_mac
+    step_tflops = flop_per_pt * (value / world) / 1e12
+
+    # ---- instrumented pass: HIP events around every launch of each kernel class, same steps, same stream ----
+    roofline = None
+    if not args.no_profile:
+        lib = _lib.lib()
+        lib.dsdf_profile_enable(1)
+        for i in range(args.steps):
+            step(args.warmup + i)
+        torch.cuda.synchronize()
+        prof = _lib.DsdfProfile()
+        _lib.check(lib.dsdf_profile_read(C.byref(prof)))
+        lib.dsdf_profile_enable(0)
+        kern = {}
+        for c, name in enumerate(_lib.PROF_NAMES):
+            if prof.count[c]:
+                kern[name] = dict(launches_per_step=prof.count[c] / args.steps, avg_us=1e3 * prof.ms[c] / prof.count[c],
+                                  ms_per_step=prof.ms[c] / args.steps,
+                                  tflops=prof.flops[c] / (prof.ms[c] * 1e-3) / 1e12 if prof.ms[c] > 0 else None)
+        dom = max(kern, key=lambda k: kern[k]["ms_per_step"])
+        roofline = dict(bound="mfma", kernel=dom, achieved=kern[dom]["tflops"], peak=PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=kern[dom]["tflops"] / PEAK_TFLOPS, traffic=None,
+                        avg_launch_us=kern[dom]["avg_us"], launches_per_step=kern[dom]["launches_per_step"],
+                        step_achieved=step_tflops, step_frac=step_tflops / PEAK_TFLOPS, kernels=kern,
+                        note="achieved = executed 2*M*N*K of the kernel's launches / HIP-event time around them; "
+                             "step_* = 6*W_mac*pts/s (SURVEY 8d algorithmic FLOPs) over the un-instrumented timed region")
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        print(json.dumps({
+            "metric": "SDF point-samples/sec per training step (8x512 decoder, 16384 pts)", "value": value,
+            "unit": "point-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("configs[1]: 64 synthetic sphere-SDF scenes, latent_dim=256, 8x512 decoder + layer-4 skip, "
+                                    "weight-norm, dropout 0.2, 16384 pts/step, fp32" if world == 1 else
+                                    f"configs[2]: 512 scenes sharded over {world} ranks, 16384 pts/step/rank, RCCL all-reduce of "
+                                    "decoder grads"),
+                       "points_per_step_per_gpu": n_local, "parallelism": f"dp{world}", "final_loss": loss},
+            "roofline": roofline, "cpu_baseline": cpu}))
+
+
+if __name__ == "__main__":
+    main()

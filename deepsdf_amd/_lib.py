@@ -37,6 +37,15 @@ class DsdfAdamCfg(C.Structure):
                 ("beta2", C.c_float), ("eps", C.c_float), ("grad_scale", C.c_void_p)]
 
 
+PROF_CLASSES = 4
+PROF_NAMES = ("gemm_nt_kernel", "gemm_tn_kernel", "last_layer_kernel", "other")
+
+
+class DsdfProfile(C.Structure):
+    _fields_ = [("ms", C.c_double * PROF_CLASSES), ("flops", C.c_double * PROF_CLASSES),
+                ("count", C.c_int64 * PROF_CLASSES), ("dropped", C.c_int32)]
+
+
 class DsdfError(RuntimeError):
     pass
 
@@ -60,6 +69,8 @@ PROTOTYPES = {
     "dsdf_grad_norm": [_P, _I64, _F, _P, _P, _P, _SZ, _P],
     "dsdf_adam_step": [_NET, _P, _P, _P, _P, _P, _P, _P, _P, _I64, C.POINTER(DsdfAdamCfg), _P, _P],
     "dsdf_adam_latent_only": [_P, _P, _P, _P, _I64, C.POINTER(DsdfAdamCfg), _P],
+    "dsdf_profile_enable": [_I32],
+    "dsdf_profile_read": [C.POINTER(DsdfProfile)],
     "dsdf_gemm_nt": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P],
     "dsdf_gemm_tn": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _SZ, _P],
     "dsdf_dropout_mask": [C.c_uint32, _F, _I64, _I64, _I64, _P, _P],

@@ -41,6 +41,37 @@ int fail(int code, const char* fmt, ...) {
     if (rc_ != 0) return rc_; \
   } while (0)
 
+// ---- optional per-kernel-class timing with HIP events (diagnostics; off by default) ----------------
+struct Prof {
+  bool on = false;
+  static constexpr int NCLS = DSDF_PROF_CLASSES, POOL = 8192;
+  hipEvent_t ev[POOL][2];
+  int cls[POOL];
+  int created = 0, used = 0;
+  double flops[NCLS] = {0};
+};
+thread_local Prof g_prof;
+
+struct ProfScope {
+  int slot = -1;
+  hipStream_t st;
+  ProfScope(int cls, double flops, hipStream_t s) : st(s) {
+    Prof& P = g_prof;
+    if (!P.on || P.used >= Prof::POOL) return;
+    if (P.used >= P.created) {
+      if (hipEventCreate(&P.ev[P.created][0]) != hipSuccess || hipEventCreate(&P.ev[P.created][1]) != hipSuccess) return;
+      ++P.created;
+    }
+    slot = P.used++;
+    P.cls[slot] = cls;
+    P.flops[cls] += flops;
+    (void)hipEventRecord(P.ev[slot][0], st);
+  }
+  ~ProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_prof.ev[slot][1], st);
+  }
+};
+
 inline int64_t rup(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -192,6 +223,7 @@ int launch_nt(const NtArgs& a, hipStream_t st) {
     return fail(DSDF_E_INVALID, "gemm_nt: operands must be 16-byte aligned with ld %% 4 == 0");
   if (a.lda < rup(a.K, 4) || a.ldb < rup(a.K, 4)) return fail(DSDF_E_INVALID, "gemm_nt: ld smaller than K rounded up to 4");
   const int grid = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  ProfScope ps(DSDF_PROF_GEMM_NT, 2.0 * a.M * a.N * a.K, st);
   hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(grid), dim3(256), 0, st, a);
   LAUNCH_OK("gemm_nt_kernel");
   return 0;
@@ -204,6 +236,7 @@ int launch_tn(const TnArgs& a, int nsplit, hipStream_t st) {
   if (a.lda < rup(a.M, 4) || a.ldb < rup(a.N, 4)) return fail(DSDF_E_INVALID, "gemm_tn: ld smaller than the tile width");
   if (a.kchunk % BK) return fail(DSDF_E_INVALID, "gemm_tn: kchunk must be a multiple of %d", BK);
   const int grid = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * nsplit;
+  ProfScope ps(DSDF_PROF_GEMM_TN, 2.0 * a.M * a.N * a.K, st);
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(256), 0, st, a);
   LAUNCH_OK("gemm_tn_kernel");
   return 0;
@@ -213,6 +246,7 @@ template <int MODE>
 int launch_last(const LastArgs& a, int blocks, hipStream_t st) {
   if (a.n <= 0) return 0;
   const int in = a.in;
+  ProfScope ps(DSDF_PROF_LAST, (MODE == LAST_FWD ? 2.0 : 6.0) * a.n * a.in, st);
   if (in <= 256) hipLaunchKernelGGL((last_layer_kernel<MODE, 1>), dim3(blocks), dim3(256), 0, st, a);
   else if (in <= 512) hipLaunchKernelGGL((last_layer_kernel<MODE, 2>), dim3(blocks), dim3(256), 0, st, a);
   else if (in <= 1024) hipLaunchKernelGGL((last_layer_kernel<MODE, 4>), dim3(blocks), dim3(256), 0, st, a);
@@ -630,6 +664,31 @@ int dsdf_adam_latent_only(float* latent, const float* dlat, float* exp_avg, floa
   if (!latent || !dlat || !exp_avg || !exp_avg_sq || !cfg || n <= 0) return fail(DSDF_E_INVALID, "bad arguments");
   if (cfg->step < 1) return fail(DSDF_E_INVALID, "Adam step must be >= 1");
   return adam_launch(latent, dlat, exp_avg, exp_avg_sq, n, cfg->lr_latent, cfg, nullptr, (hipStream_t)stream);
+}
+
+int dsdf_profile_enable(int32_t on) {
+  g_prof.on = on != 0;
+  g_prof.used = 0;
+  for (int c = 0; c < Prof::NCLS; ++c) g_prof.flops[c] = 0;
+  return 0;
+}
+
+int dsdf_profile_read(DsdfProfile* out) {
+  if (!out) return fail(DSDF_E_INVALID, "out is NULL");
+  memset(out, 0, sizeof(*out));
+  Prof& P = g_prof;
+  for (int i = 0; i < P.used; ++i) {
+    HIP_OK(hipEventSynchronize(P.ev[i][1]));
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, P.ev[i][0], P.ev[i][1]));
+    out->ms[P.cls[i]] += ms;
+    out->count[P.cls[i]] += 1;
+  }
+  for (int c = 0; c < Prof::NCLS; ++c) out->flops[c] = P.flops[c];
+  out->dropped = P.used >= Prof::POOL;
+  P.used = 0;
+  for (int c = 0; c < Prof::NCLS; ++c) P.flops[c] = 0;
+  return 0;
 }
 
 int dsdf_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,

@@ -145,6 +145,19 @@ int dsdf_adam_step(const DsdfNet* net, float* params, const float* grads, float*
 int dsdf_adam_latent_only(float* latent, const float* dlat, float* exp_avg, float* exp_avg_sq, int64_t n,
                           const DsdfAdamCfg* cfg, void* stream);
 
+/* ---- diagnostics: per-kernel-class device time from HIP events recorded on the caller's stream around every
+ * launch of that class (bench.py's roofline object).  Off by default; thread-local; read synchronises. */
+#define DSDF_PROF_CLASSES 4
+enum { DSDF_PROF_GEMM_NT = 0, DSDF_PROF_GEMM_TN = 1, DSDF_PROF_LAST = 2, DSDF_PROF_OTHER = 3 };
+typedef struct DsdfProfile {
+  double ms[DSDF_PROF_CLASSES];     /* summed event-to-event time per class */
+  double flops[DSDF_PROF_CLASSES];  /* summed 2*M*N*K (executed, incl. tile padding excluded) per class */
+  int64_t count[DSDF_PROF_CLASSES]; /* launches per class */
+  int32_t dropped;                  /* 1 if the event pool overflowed (results incomplete) */
+} DsdfProfile;
+int dsdf_profile_enable(int32_t on);
+int dsdf_profile_read(DsdfProfile* out);
+
 /* ---- building blocks (exported for the parity tests and profiling; not needed by a trainer) --------- */
 /* C[M,N] = A[M,K] * B[N,K]^T (+bias) */
 int dsdf_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,

@@ -93,10 +93,32 @@ def _big_batch(B, S, seed):
     return idx, xyz, gt
 
 
+def _safe_batch(net, st64, B, S, seed, delta, code_bound, drop_seed, margin=2e-5):
+    """Seeded batch whose clamp / sign decisions are robust: points with | |y|-delta | or |clamp(y)-clamp(t)| within
+    `margin` (decided by the float64 oracle) are re-drawn.  A flip of one such point moves 1/N of the gradient
+    (6e-5 at N=16384), which is discontinuity noise, not kernel error."""
+    idx, xyz, gt = _big_batch(B, S, seed)
+    gen = torch.Generator().manual_seed(seed + 999)
+    lat = st64.latents.clone()
+    orc.renorm_rows_(lat, idx, code_bound)
+    masks = orc.dropout_masks(net, drop_seed, st64.step, xyz.shape[0])
+    for _ in range(4):
+        x0 = torch.cat([lat[idx], xyz.double()], 1)
+        y, _sv = orc.decoder_forward(net, st64.params, x0, training=True, masks=masks)
+        d = torch.clamp(y, -delta, delta) - torch.clamp(gt.double(), -delta, delta)
+        risky = (((y.abs() - delta).abs() < margin) | ((d != 0) & (d.abs() < margin))).reshape(-1)
+        if not bool(risky.any()):
+            return idx, xyz, gt
+        k = int(risky.sum())
+        xyz[risky] = torch.rand(k, 3, generator=gen) * 2 - 1
+        gt[risky] = (torch.rand(k, 1, generator=gen) - 0.5) * 0.4
+    raise RuntimeError("could not build a margin-safe batch")
+
+
 def test_full_size_step_vs_oracle():
-    """BASELINE config 2 at full size: 64 scenes x 256 pts = 16384 pts, L=256, 8x512, dropout 0.2, against the
-    oracle (fp32 CPU) on identical seeded inputs; two optimiser steps."""
-    torch.set_num_threads(max(1, torch.get_num_threads()))
+    """BASELINE config 2 at full size: 64 scenes x 256 pts = 16384 pts, L=256, 8x512, dropout 0.2: two optimiser
+    steps of the HIP path against the oracle run in float64 (the truth) on identical seeded inputs; the fp32
+    oracle's own distance from that truth is printed for scale."""
     L, B, S = 256, 64, 256
     net = orc.make_net(L, **BIG)
     spec = spec_from_meta(dict(L=L, net_specs=BIG))
@@ -104,20 +126,25 @@ def test_full_size_step_vs_oracle():
     gen = torch.Generator().manual_seed(6)
     lat0 = torch.randn(B, L, generator=gen) / math.sqrt(L)
     lat0[3] *= 2.5 / lat0[3].norm()
-    st = orc.TrainState.create({k: v.clone() for k, v in params.items()}, lat0.clone())
+    st64 = orc.TrainState.create({k: v.double() for k, v in params.items()}, lat0.double())
+    st32 = orc.TrainState.create({k: v.clone() for k, v in params.items()}, lat0.clone())
     tr = HipTrainer(spec, params, lat0)
     for step in range(2):
-        idx, xyz, gt = _big_batch(B, S, 100 + step)
-        ro = orc.train_step(net, st, idx, xyz, gt, delta=0.1, code_bound=1.0, epoch=57, seed=4242)
+        idx, xyz, gt = _safe_batch(net, st64, B, S, 100 + step, 0.1, 1.0, 4242)
+        r64 = orc.train_step(net, st64, idx, xyz.double(), gt.double(), delta=0.1, code_bound=1.0, epoch=57, seed=4242)
+        r32 = orc.train_step(net, st32, idx, xyz, gt, delta=0.1, code_bound=1.0, epoch=57, seed=4242)
         rh = tr.step(idx, xyz, gt, delta=0.1, code_bound=1.0, code_reg=True, lam=1e-4, epoch=57, lr=(5e-4, 1e-3), seed=4242)
-        assert abs(rh["loss"] - ro["loss"]) <= 1e-5 * abs(ro["loss"])
-        for k in ro["grads"]:
-            assert rel_err(rh["grads"][k], ro["grads"][k]) <= GRAD_TOL, (step, k)
-        assert rel_err(rh["dlat"], ro["dlat"]) <= GRAD_TOL
+        assert abs(rh["loss"] - r64["loss"]) <= 1e-5 * abs(r64["loss"])
+        worst_h = max(rel_err(rh["grads"][k], r64["grads"][k]) for k in r64["grads"])
+        worst_o = max(rel_err(r32["grads"][k], r64["grads"][k]) for k in r64["grads"])
+        print(f"step {step}: max grad rel err vs fp64 truth: HIP {worst_h:.2e}, fp32 CPU oracle {worst_o:.2e}")
+        for k in r64["grads"]:
+            assert rel_err(rh["grads"][k], r64["grads"][k]) <= GRAD_TOL, (step, k)
+        assert rel_err(rh["dlat"], r64["dlat"]) <= GRAD_TOL
         P = tr.params()
-        for k in st.params:
-            assert rel_err(P[k], st.params[k]) <= PARAM_TOL, (step, k)
-        assert rel_err(tr.lat.cpu(), st.latents) <= PARAM_TOL
+        for k in st64.params:
+            assert rel_err(P[k], st64.params[k]) <= PARAM_TOL, (step, k)
+        assert rel_err(tr.lat.cpu(), st64.latents) <= PARAM_TOL
 
 
 def test_full_size_properties():
