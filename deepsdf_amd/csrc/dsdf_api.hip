@@ -105,6 +105,7 @@ int validate(const DsdfNet* n) {
 struct Packed {
   int64_t w_off[DSDF_MAX_LAYERS], wt_off[DSDF_MAX_LAYERS];
   int ldw[DSDF_MAX_LAYERS], ldwt[DSDF_MAX_LAYERS];
+  int64_t scale_off;   // per-row weight-norm scales of all layers
   int64_t total;
 };
 Packed packed_layout(const DsdfNet* n) {
@@ -116,7 +117,9 @@ Packed packed_layout(const DsdfNet* n) {
     p.w_off[l] = o;  o += rup((int64_t)n->out_dim[l] * p.ldw[l], 64);
     p.wt_off[l] = o; o += rup((int64_t)n->in_dim[l] * p.ldwt[l], 64);
   }
-  p.total = o;
+  p.scale_off = o;
+  for (int l = 0; l < n->n_layers; ++l) o += n->out_dim[l];
+  p.total = rup(o, 64);
   return p;
 }
 
@@ -275,17 +278,27 @@ int materialize(const DsdfNet* net, const float* params, float* packed, hipStrea
   DsdfParamLayout L;
   param_layout(net, &L);
   const Packed pk = packed_layout(net);
+  WnAll a;
+  memset(&a, 0, sizeof(a));
+  a.nl = net->n_layers;
+  a.scale = packed + pk.scale_off;
+  int rows = 0, tiles = 0;
   for (int l = 0; l < net->n_layers; ++l) {
-    WnArgs a;
-    a.v = params + L.v_off[l];
-    a.g = L.g_off[l] >= 0 ? params + L.g_off[l] : nullptr;
-    a.W = packed + pk.w_off[l];
-    a.WT = (l == net->n_layers - 1) ? nullptr : packed + pk.wt_off[l];
-    a.out = net->out_dim[l]; a.in = net->in_dim[l]; a.ldw = pk.ldw[l]; a.ldwt = pk.ldwt[l];
-    a.wn = a.g != nullptr;
-    hipLaunchKernelGGL(weight_norm_kernel, dim3((a.out + 31) / 32), dim3(256), 0, st, a);
-    LAUNCH_OK("weight_norm_kernel");
+    WnLayer& y = a.ly[l];
+    y.v = params + L.v_off[l];
+    y.g = L.g_off[l] >= 0 ? params + L.g_off[l] : nullptr;
+    y.W = packed + pk.w_off[l];
+    y.WT = (l == net->n_layers - 1) ? nullptr : packed + pk.wt_off[l];
+    y.out = net->out_dim[l]; y.in = net->in_dim[l]; y.ldw = pk.ldw[l]; y.ldwt = pk.ldwt[l];
+    y.row0 = rows; y.tile0 = tiles; y.tcols = (y.in + 31) / 32;
+    rows += y.out;
+    tiles += ((y.out + 31) / 32) * y.tcols;
   }
+  a.total_rows = rows; a.total_tiles = tiles;
+  hipLaunchKernelGGL(wn_scale_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a);
+  LAUNCH_OK("wn_scale_kernel");
+  hipLaunchKernelGGL(wn_tiles_kernel, dim3(tiles), dim3(256), 0, st, a);
+  LAUNCH_OK("wn_tiles_kernel");
   return 0;
 }
 
@@ -605,7 +618,7 @@ int dsdf_train_forward_backward(const DsdfNet* net, const float* packed, const f
   sc.segpart = s.segpart; sc.segnorm = s.segnorm; sc.seg_scene = b->seg_scene; sc.seg_offset = b->seg_offset;
   sc.R = (int)R; sc.L = Lc; sc.table = latent_table; sc.dlat = dlat;
   sc.creg = cfg->reg_coef / (float)b->n_norm; sc.reg_loss = at<float>(ws, P.regloss_off);
-  hipLaunchKernelGGL(seg_scatter_kernel, dim3((Lc + 255) / 256), dim3(256), 0, st, sc);
+  hipLaunchKernelGGL(seg_scatter_kernel, dim3((unsigned)R), dim3(256), 0, st, sc);
   LAUNCH_OK("seg_scatter_kernel");
   hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, at<float>(ws, P.partloss_off), P.last_blocks,
                      1.0f / (float)b->n_norm, at<float>(ws, P.regloss_off), loss_out, accumulate);

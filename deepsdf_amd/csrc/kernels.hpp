@@ -62,47 +62,55 @@ __global__ void gather_concat_kernel(const GatherArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K1: W = g * v / ||v||_row (torch._weight_norm(v, g, 0)) or plain copy; writes W [out][ldw] and
-// W^T [in][ldwt].  Block = 32 rows; transposed store goes through a 32x33 LDS tile.
-struct WnArgs { const float* v; const float* g; float* W; float* WT; int out, in, ldw, ldwt; int wn; };
-__global__ __launch_bounds__(256) void weight_norm_kernel(const WnArgs p) {
-  __shared__ float tile[32][33];
-  __shared__ float scale[32];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r0 = blockIdx.x * 32;
-  for (int rr = wave; rr < 32; rr += 4) {
-    const int row = r0 + rr;
-    float s = 1.f;
-    if (p.wn && row < p.out) {
-      float ss = 0.f;
-      for (int c = lane; c < p.in; c += 64) { const float x = p.v[(size_t)row * p.in + c]; ss += x * x; }
-      ss = wave_sum(ss);
-      s = p.g[row] / sqrtf(ss);
-    }
-    if (lane == 0) scale[rr] = s;
+// K1: W = g * v / ||v||_row (torch._weight_norm(v, g, 0)) or plain copy, for ALL layers in two launches:
+//   wn_scale_kernel : one wave per (layer,row): scale = g / ||v_row||  (1 for plain layers)
+//   wn_tiles_kernel : one block per 32x32 tile: W tile (coalesced) and W^T tile through a 32x33 LDS transpose.
+struct WnLayer { const float* v; const float* g; float* W; float* WT; int out, in, ldw, ldwt; int row0; int tile0; int tcols; };
+struct WnAll { int nl; int total_rows; int total_tiles; float* scale; WnLayer ly[DSDF_MAX_LAYERS]; };
+
+__global__ __launch_bounds__(256) void wn_scale_kernel(const WnAll p) {
+  const int gr = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (gr >= p.total_rows) return;
+  int l = 0;
+  while (l + 1 < p.nl && gr >= p.ly[l + 1].row0) ++l;
+  const WnLayer& L = p.ly[l];
+  const int row = gr - L.row0;
+  float s = 1.f;
+  if (L.g != nullptr) {
+    const float* vr = L.v + (size_t)row * L.in;
+    float ss = 0.f;
+    for (int c = lane; c < L.in; c += 64) { const float x = vr[c]; ss += x * x; }
+    ss = wave_sum(ss);
+    s = L.g[row] / sqrtf(ss);
   }
+  if (lane == 0) p.scale[gr] = s;
+}
+
+__global__ __launch_bounds__(256) void wn_tiles_kernel(const WnAll p) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.x;
+  int l = 0;
+  while (l + 1 < p.nl && t >= p.ly[l + 1].tile0) ++l;
+  const WnLayer& L = p.ly[l];
+  const int tt = t - L.tile0;
+  const int r0 = (tt / L.tcols) * 32, c0 = (tt % L.tcols) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int rr = ty + 8 * k, row = r0 + rr, col = c0 + tx;
+    float w = 0.f;
+    if (row < L.out && col < L.in) {
+      w = L.v[(size_t)row * L.in + col] * p.scale[L.row0 + row];
+      L.W[(size_t)row * L.ldw + col] = w;
+    }
+    tile[rr][tx] = w;
+  }
+  if (L.WT == nullptr) return;
   __syncthreads();
-  const int tx = tid & 31, ty = tid >> 5;  // 32 x 8
-  for (int c0 = 0; c0 < p.in; c0 += 32) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int rr = ty + 8 * k, row = r0 + rr, col = c0 + tx;
-      float w = 0.f;
-      if (row < p.out && col < p.in) {
-        w = p.v[(size_t)row * p.in + col] * scale[rr];
-        p.W[(size_t)row * p.ldw + col] = w;
-      }
-      tile[rr][tx] = w;
-    }
-    __syncthreads();
-    if (p.WT != nullptr) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int cc = ty + 8 * k, col = c0 + cc, row = r0 + tx;
-        if (col < p.in && row < p.out) p.WT[(size_t)col * p.ldwt + row] = tile[tx][cc];
-      }
-    }
-    __syncthreads();
+  for (int k = 0; k < 4; ++k) {
+    const int cc = ty + 8 * k, col = c0 + cc, row = r0 + tx;
+    if (col < L.in && row < L.out) L.WT[(size_t)col * L.ldwt + row] = tile[tx][cc];
   }
 }
 
@@ -243,7 +251,15 @@ __global__ __launch_bounds__(256) void finalize_layer_kernel(const FinArgs p) {
     float s = 0.f;
     if (c < p.in) {
       const float* q = p.slabs + (size_t)i * p.ldc + c;
-      for (int sp = 0; sp < p.nsplit; ++sp) s += q[(size_t)sp * p.slab];
+      int sp = 0;
+      for (; sp + 8 <= p.nsplit; sp += 8) {  // 8 independent loads in flight, summed in fixed order
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = q[(size_t)(sp + u) * p.slab];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += t[u];
+      }
+      for (; sp < p.nsplit; ++sp) s += q[(size_t)sp * p.slab];
       if (p.g) { const float vv = p.v[(size_t)i * p.in + c]; dot += s * vv; ss += vv * vv; }
     }
     dwr[k] = s;
@@ -315,32 +331,45 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(const SegArgs p) {
   }
 }
 
-// K5b: dlat[scene[r]] += segpart[r] + reg_coef/n_norm * count_r * E/||E||  in segment order (one thread
-// per column, so duplicates of a scene are summed deterministically); block 0 also emits the regulariser
-// loss  sum_r reg_coef/n_norm * count_r * ||E_r||  (train_deep_sdf.py:523-531).
+// K5b: dlat[scene] += sum over the segments of that scene (in segment order) of
+//   segpart[r] + reg_coef/n_norm * count_r * E/||E||.   One block per segment; the FIRST segment of a scene owns
+// the sum over all its later duplicates, so the result is deterministic and needs no atomics.
+// Block 0 also emits the regulariser loss  sum_r reg_coef/n_norm * count_r * ||E_r||  (train_deep_sdf.py:523-531).
 struct ScatterArgs {
   const float* segpart; const float* segnorm; const int64_t* seg_scene; const int64_t* seg_offset; int R; int L;
   const float* table; float* dlat; float creg; float* reg_loss;
 };
-__global__ void seg_scatter_kernel(const ScatterArgs p) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < p.L) {
-    for (int r = 0; r < p.R; ++r) {
-      const int64_t j = p.seg_scene[r];
-      float v = p.segpart[(size_t)r * p.L + c];
-      if (p.creg != 0.f) {
-        const float nrm = p.segnorm[r];
-        const float cnt = (float)(p.seg_offset[r + 1] - p.seg_offset[r]);
-        if (nrm > 0.f) v += p.creg * cnt * p.table[(size_t)j * p.L + c] / nrm;
-      }
-      p.dlat[(size_t)j * p.L + c] += v;
-    }
-  }
-  if (c == 0) {
+__global__ __launch_bounds__(256) void seg_scatter_kernel(const ScatterArgs p) {
+  __shared__ float red[4];
+  __shared__ int dup;
+  const int r = blockIdx.x, tid = threadIdx.x;
+  if (r == 0) {
     float s = 0.f;
     if (p.creg != 0.f)
-      for (int r = 0; r < p.R; ++r) s += p.creg * (float)(p.seg_offset[r + 1] - p.seg_offset[r]) * p.segnorm[r];
-    *p.reg_loss = s;
+      for (int q = tid; q < p.R; q += 256) s += p.creg * (float)(p.seg_offset[q + 1] - p.seg_offset[q]) * p.segnorm[q];
+    s = block_sum_256(s, red);
+    if (tid == 0) *p.reg_loss = s;
+  }
+  const int64_t j = p.seg_scene[r];
+  if (tid == 0) dup = 0;
+  __syncthreads();
+  int d = 0;
+  for (int q = tid; q < r; q += 256) d |= (p.seg_scene[q] == j);
+  if (d) dup = 1;
+  __syncthreads();
+  if (dup) return;
+  for (int c = tid; c < p.L; c += 256) {
+    float acc = 0.f;
+    for (int q = r; q < p.R; ++q) {
+      if (q != r && p.seg_scene[q] != j) continue;
+      float v = p.segpart[(size_t)q * p.L + c];
+      if (p.creg != 0.f) {
+        const float nrm = p.segnorm[q];
+        if (nrm > 0.f) v += p.creg * (float)(p.seg_offset[q + 1] - p.seg_offset[q]) * p.table[(size_t)j * p.L + c] / nrm;
+      }
+      acc += v;
+    }
+    p.dlat[(size_t)j * p.L + c] += acc;
   }
 }
 

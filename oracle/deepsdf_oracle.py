@@ -239,10 +239,11 @@ class Saved:
     u: Optional[torch.Tensor] = None                           # last linear output [N,1]
     t1: Optional[torch.Tensor] = None                          # tanh(u) if use_tanh
     y: Optional[torch.Tensor] = None                           # network output [N,1]
+    min_abs_pre: Optional[torch.Tensor] = None                 # [N] min |hidden pre-activation| (margin checks in tests)
 
 
 def decoder_forward(net: Net, params, x0: torch.Tensor, training: bool = False,
-                    masks: Optional[Sequence[Optional[torch.Tensor]]] = None):
+                    masks: Optional[Sequence[Optional[torch.Tensor]]] = None, track_margin: bool = False):
     """x0: [N, L+G] (latent first, coordinates last).  Returns (y [N,1], Saved)."""
     Wb = effective_weights(net, params)
     sv = Saved(x0=x0)
@@ -256,6 +257,9 @@ def decoder_forward(net: Net, params, x0: torch.Tensor, training: bool = False,
         W, b = Wb[l]
         x = x @ W.t() + b
         if l < n_lin - 1:
+            if track_margin:
+                mn = x.abs().amin(dim=1)
+                sv.min_abs_pre = mn if sv.min_abs_pre is None else torch.minimum(sv.min_abs_pre, mn)
             x = torch.clamp_min(x, 0.0)
             if training and ly.dropout and net.dropout_prob > 0.0:
                 if masks is None or masks[l] is None:

@@ -93,20 +93,23 @@ def _big_batch(B, S, seed):
     return idx, xyz, gt
 
 
-def _safe_batch(net, st64, B, S, seed, delta, code_bound, drop_seed, margin=2e-5):
-    """Seeded batch whose clamp / sign decisions are robust: points with | |y|-delta | or |clamp(y)-clamp(t)| within
-    `margin` (decided by the float64 oracle) are re-drawn.  A flip of one such point moves 1/N of the gradient
-    (6e-5 at N=16384), which is discontinuity noise, not kernel error."""
+def _safe_batch(net, st64, B, S, seed, delta, code_bound, drop_seed, margin=2e-5, relu_margin=1e-6):
+    """Seeded batch whose clamp / sign / ReLU decisions are robust: points with | |y|-delta | or |clamp(y)-clamp(t)|
+    within `margin`, or any hidden pre-activation within `relu_margin` of 0 (decided by the float64 oracle), are
+    re-drawn.  A clamp/sign flip of one point moves 1/N of the gradient (6e-5 at N=16384); ~10 ReLU flips out of 67 M
+    pre-activations put BOTH fp32 implementations (HIP and the CPU oracle) 1.5e-4 from the fp64 truth.  That is
+    discontinuity noise, not kernel error, so the comparison is made on a margin-safe batch."""
     idx, xyz, gt = _big_batch(B, S, seed)
     gen = torch.Generator().manual_seed(seed + 999)
     lat = st64.latents.clone()
     orc.renorm_rows_(lat, idx, code_bound)
     masks = orc.dropout_masks(net, drop_seed, st64.step, xyz.shape[0])
-    for _ in range(4):
+    for _ in range(12):
         x0 = torch.cat([lat[idx], xyz.double()], 1)
-        y, _sv = orc.decoder_forward(net, st64.params, x0, training=True, masks=masks)
+        y, sv = orc.decoder_forward(net, st64.params, x0, training=True, masks=masks, track_margin=True)
         d = torch.clamp(y, -delta, delta) - torch.clamp(gt.double(), -delta, delta)
         risky = (((y.abs() - delta).abs() < margin) | ((d != 0) & (d.abs() < margin))).reshape(-1)
+        risky |= sv.min_abs_pre < relu_margin
         if not bool(risky.any()):
             return idx, xyz, gt
         k = int(risky.sum())
