@@ -1,0 +1,1 @@
+from deepsdf_amd.data import *  # noqa: F401,F403

@@ -1,0 +1,168 @@
+"""SDF sample files -> training batches.
+
+Host side mirrors the reference's deep_sdf/data.py (get_instance_filenames :15-33, remove_nans :61-63,
+unpack_sdf_samples :74-110, SDFSamples :142-194): ``.npz`` files with arrays ``pos`` / ``neg`` of shape [*, G+1]
+(xyz..., sdf), NaN rows filtered, balanced positive/negative subsample without replacement.
+
+``DeviceSampleCache`` is the MI355X-side replacement of the DataLoader: every scene's filtered
+samples are uploaded ONCE into HBM (288 GB holds thousands of 50k-point scenes) and each step's balanced
+subsample is drawn on the device, so no per-step np.load / H2D copy remains.
+"""
+import logging
+import os
+import random
+
+import numpy as np
+import torch
+import torch.utils.data
+
+from . import workspace as ws
+
+
+def get_instance_filenames(data_source, split):
+    npzfiles = []
+    for dataset in split:
+        for class_name in split[dataset]:
+            for instance_name in split[dataset][class_name]:
+                instance_filename = os.path.join(dataset, class_name, instance_name + ".npz")
+                if not os.path.isfile(os.path.join(data_source, ws.sdf_samples_subdir, instance_filename)):
+                    logging.warning("Requested non-existent file '{}'".format(instance_filename))
+                npzfiles += [instance_filename]
+    return npzfiles
+
+
+def remove_nans(tensor, geom_dimension):
+    keep = ~torch.isnan(tensor[:, geom_dimension])
+    return tensor[keep, :].float()
+
+
+def _balanced_counts(n_pos, n_neg, subsample):
+    """deep_sdf/data.py:83-91: half each, a shortfall on one sign is taken from the other."""
+    half = int(subsample / 2)
+    if n_pos < half:
+        return n_pos, 2 * half - n_pos
+    if n_neg < half:
+        return 2 * half - n_neg, n_neg
+    return half, half
+
+
+def read_sdf_samples_into_ram(filename):
+    npz = np.load(filename)
+    return [torch.from_numpy(npz["pos"]).float(), torch.from_numpy(npz["neg"]).float()]
+
+
+def unpack_sdf_samples(filename, geom_dimension, subsample=None):
+    npz = np.load(filename)
+    pos = remove_nans(torch.from_numpy(npz["pos"]), geom_dimension)
+    neg = remove_nans(torch.from_numpy(npz["neg"]), geom_dimension)
+    if subsample is None:
+        return torch.cat([pos, neg], 0)
+    n_pos, n_neg = _balanced_counts(len(pos), len(neg), subsample)
+    sel_pos = torch.randperm(len(pos))[:n_pos]
+    sel_neg = torch.randperm(len(neg))[:n_neg]
+    return torch.cat([torch.index_select(pos, 0, sel_pos), torch.index_select(neg, 0, sel_neg)], 0)
+
+
+def unpack_sdf_samples_from_ram(data, subsample=None):
+    if subsample is None:
+        return torch.cat(data, 0)
+    pos, neg = data
+    half = int(subsample / 2)
+    p0 = random.randint(0, pos.shape[0] - half)
+    sample_pos = pos[p0:p0 + half]
+    if neg.shape[0] <= half:
+        sample_neg = torch.index_select(neg, 0, (torch.rand(half) * neg.shape[0]).long())
+    else:
+        n0 = random.randint(0, neg.shape[0] - half)
+        sample_neg = neg[n0:n0 + half]
+    return torch.cat([sample_pos, sample_neg], 0)
+
+
+class SDFSamples(torch.utils.data.Dataset):
+    """Host-side dataset with the reference's constructor and item format ``(samples [S, G+1], idx)``."""
+
+    def __init__(self, data_source, split, subsample, geom_dimension, load_ram=False, print_filename=False,
+                 num_files=1000000):
+        self.subsample = subsample
+        self.geom_dimension = geom_dimension
+        self.data_source = data_source
+        self.npyfiles = get_instance_filenames(data_source, split)
+        logging.debug("using " + str(len(self.npyfiles)) + " shapes from data source " + data_source)
+        self.load_ram = load_ram
+        if load_ram:
+            self.loaded_data = []
+            for f in self.npyfiles:
+                npz = np.load(self._path(f))
+                pos = remove_nans(torch.from_numpy(npz["pos"]), geom_dimension)
+                neg = remove_nans(torch.from_numpy(npz["neg"]), geom_dimension)
+                self.loaded_data.append([pos[torch.randperm(pos.shape[0])], neg[torch.randperm(neg.shape[0])]])
+
+    def _path(self, f):
+        return os.path.join(self.data_source, ws.sdf_samples_subdir, f)
+
+    def __len__(self):
+        return len(self.npyfiles)
+
+    def __getitem__(self, idx):
+        if self.load_ram:
+            return unpack_sdf_samples_from_ram(self.loaded_data[idx], self.subsample), idx
+        return unpack_sdf_samples(self._path(self.npyfiles[idx]), self.geom_dimension, self.subsample), idx
+
+
+class DeviceSampleCache:
+    """All scenes' samples resident in HBM; balanced without-replacement subsampling on the device.
+
+    Layout: one [total_rows, G+1] fp32 tensor; scene k's positives are rows [pos_start[k], pos_start[k]+n_pos[k]),
+    negatives likewise.  ``sample(scene_ids, S)`` draws, per scene, the first n of a random permutation of each sign
+    (random keys + batched sort = the reference's ``randperm(len)[:n]``) and returns xyz [B*S, G], sdf [B*S].
+    """
+
+    def __init__(self, tensors_pos_neg, geom_dimension, device):
+        self.G = geom_dimension
+        self.device = torch.device(device)
+        rows, self.n_pos, self.n_neg, self.pos_start, self.neg_start = [], [], [], [], []
+        off = 0
+        for pos, neg in tensors_pos_neg:
+            self.pos_start.append(off); self.n_pos.append(pos.shape[0]); off += pos.shape[0]
+            self.neg_start.append(off); self.n_neg.append(neg.shape[0]); off += neg.shape[0]
+            rows += [pos, neg]
+        self.data = torch.cat(rows, 0).to(self.device, torch.float32).contiguous()
+        self.max_len = max(max(self.n_pos), max(self.n_neg))
+        as_dev = lambda x: torch.tensor(x, dtype=torch.int64, device=self.device)  # noqa: E731
+        self.n_pos_d, self.n_neg_d = as_dev(self.n_pos), as_dev(self.n_neg)
+        self.pos_start_d, self.neg_start_d = as_dev(self.pos_start), as_dev(self.neg_start)
+        self._ar = torch.arange(self.max_len, device=self.device)
+
+    @staticmethod
+    def from_files(data_source, npzfiles, geom_dimension, device):
+        items = []
+        for f in npzfiles:
+            npz = np.load(os.path.join(data_source, ws.sdf_samples_subdir, f))
+            items.append((remove_nans(torch.from_numpy(npz["pos"]), geom_dimension),
+                          remove_nans(torch.from_numpy(npz["neg"]), geom_dimension)))
+        return DeviceSampleCache(items, geom_dimension, device)
+
+    def __len__(self):
+        return len(self.n_pos)
+
+    def _draw(self, start, length, count, generator):
+        """For every scene b: `count[b]` distinct rows out of [start[b], start[b]+length[b]) -> list of row ids."""
+        B = start.shape[0]
+        keys = torch.rand(B, self.max_len, device=self.device, generator=generator)
+        keys.masked_fill_(self._ar[None, :] >= length[:, None], 2.0)       # invalid slots sort last
+        order = torch.argsort(keys, dim=1)
+        return order + start[:, None], count
+
+    def sample(self, scene_ids, subsample, generator=None):
+        scene_ids = torch.as_tensor(scene_ids, dtype=torch.int64)
+        counts = [_balanced_counts(self.n_pos[k], self.n_neg[k], subsample) for k in scene_ids.tolist()]
+        sid = scene_ids.to(self.device)
+        prow, _ = self._draw(self.pos_start_d[sid], self.n_pos_d[sid], None, generator)
+        nrow, _ = self._draw(self.neg_start_d[sid], self.n_neg_d[sid], None, generator)
+        if all(c == counts[0] for c in counts):      # the regular case: one gather
+            cp, cn = counts[0]
+            rows = torch.cat([prow[:, :cp], nrow[:, :cn]], 1).reshape(-1)
+        else:
+            rows = torch.cat([torch.cat([prow[b, :cp], nrow[b, :cn]]) for b, (cp, cn) in enumerate(counts)])
+        smp = self.data.index_select(0, rows)
+        return smp[:, :self.G].contiguous(), smp[:, self.G].contiguous()

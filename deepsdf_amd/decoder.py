@@ -1,0 +1,163 @@
+"""``Decoder`` -- drop-in for the reference's ``deep_sdf.networks.deep_sdf_decoder.Decoder`` (the plugin seam of
+train_deep_sdf.py:275 / deep_sdf/workspace.py:56-58), computing on MI355X through libdsdf_hip.so.
+
+Same constructor, same ``.geom_dimension`` attribute, same ``forward(input[N, L+G]) -> [N, 1]``, same
+``state_dict`` keys and shapes (``lin{i}.bias``, ``lin{i}.parametrizations.weight.original0/1``, ``lin{i}.weight``),
+so checkpoints move freely between this class and the reference class.  All parameters are views of ONE flat fp32
+arena (the layout the HIP kernels and the fused Adam use); gradients land in a second arena.
+
+There is no CPU fallback: ``forward`` on a non-CUDA tensor raises.  Variants no shipped spec uses (LayerNorm
+without weight_norm, xyz_in_all, latent_dropout) raise NotImplementedError at construction.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .engine import Engine
+from .net import NetSpec
+
+
+class _Originals(nn.Module):
+    """Holds original0 (g) and original1 (v) like torch's ParametrizationList does."""
+
+    def __init__(self):
+        super().__init__()
+        self.register_parameter("original0", None)
+        self.register_parameter("original1", None)
+
+
+class _Linear(nn.Module):
+    def __init__(self, weight_normed):
+        super().__init__()
+        if weight_normed:
+            self.register_parameter("bias", None)  # first: named_parameters order is bias, original0, original1
+            self.parametrizations = nn.ModuleDict({"weight": _Originals()})
+        else:
+            self.register_parameter("weight", None)
+            self.register_parameter("bias", None)
+
+
+class _DecoderFn(torch.autograd.Function):
+    """Autograd bridge of the module path (dsdf_module_forward / dsdf_module_backward)."""
+
+    @staticmethod
+    def forward(ctx, dec, x, *params):
+        eng = dec._engine_for(x.device)
+        training = dec.training
+        dec._fwd_calls += 1
+        y = eng.module_forward(x, training, seed=dec.dropout_seed, step=dec._fwd_calls)
+        ctx.dec, ctx.n, ctx.training, ctx.token = dec, x.shape[0], training, dec._fwd_calls
+        ctx.need_x = x.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dec = ctx.dec
+        if ctx.token != dec._fwd_calls:
+            raise RuntimeError("deepsdf_amd.Decoder: backward() after a newer forward(): activations live in one "
+                               "workspace per module; call backward before the next forward")
+        eng = dec._engine
+        d_sdf = dy.reshape(-1).contiguous().to(torch.float32)
+        d_in = eng.module_backward(d_sdf, ctx.n, ctx.training, ctx.need_x, accumulate=False)
+        grads = tuple(eng.view(eng.grads, p).clone() for p in dec.spec.params)
+        return (None, d_in) + grads
+
+
+class Decoder(nn.Module):
+    def __init__(self, latent_size, dims, geom_dimension, dropout=None, dropout_prob=0.0, norm_layers=(), latent_in=(),
+                 weight_norm=False, xyz_in_all=None, use_tanh=False, latent_dropout=False):
+        super().__init__()
+        self.spec = NetSpec(latent_size, dims, geom_dimension, dropout=dropout, dropout_prob=dropout_prob,
+                            norm_layers=norm_layers, latent_in=latent_in, weight_norm=weight_norm,
+                            xyz_in_all=xyz_in_all, use_tanh=use_tanh, latent_dropout=latent_dropout)
+        s = self.spec
+        self.num_layers = s.n_layers + 1
+        self.geom_dimension = s.geom_dimension
+        self.norm_layers, self.latent_in, self.weight_norm = s.norm_layers, s.latent_in, s.weight_norm
+        self.dropout, self.dropout_prob, self.use_tanh = s.dropout, s.dropout_prob, s.use_tanh
+        self.dropout_seed = int(torch.initial_seed() & 0x7FFFFFFFFFFFFFFF)
+        self._fwd_calls = 0
+        self._engine = None
+        for l in range(s.n_layers):
+            setattr(self, f"lin{l}", _Linear(s.wn[l]))
+        arena = torch.zeros(s.n_params, dtype=torch.float32)
+        self._bind(arena)
+        self._init_parameters()
+
+    # ---- arena <-> nn.Parameter plumbing ------------------------------------------------------------------
+    def _slot(self, p):
+        lin = getattr(self, f"lin{p.layer}")
+        if p.kind == "g":
+            return lin.parametrizations["weight"], "original0"
+        if p.kind == "v":
+            return lin.parametrizations["weight"], "original1"
+        return lin, p.kind
+
+    def _bind(self, arena):
+        """(Re)create every nn.Parameter as a view of `arena`."""
+        object.__setattr__(self, "_arena", arena)
+        object.__setattr__(self, "_grad_arena", None)
+        for p in self.spec.params:
+            mod, attr = self._slot(p)
+            old = getattr(mod, attr, None)
+            view = arena[p.offset:p.offset + p.numel].view(p.shape)
+            par = nn.Parameter(view, requires_grad=True if old is None else old.requires_grad)
+            mod._parameters[attr] = par
+        self._engine = None
+
+    def _init_parameters(self):
+        import math
+        with torch.no_grad():
+            for l in range(self.spec.n_layers):
+                o, i = self.spec.out_dim[l], self.spec.in_dim[l]
+                w = torch.empty(o, i)
+                nn.init.kaiming_uniform_(w, a=math.sqrt(5))          # nn.Linear.reset_parameters
+                b = torch.empty(o).uniform_(-1 / math.sqrt(i), 1 / math.sqrt(i))
+                for p in self.spec.params:
+                    if p.layer == l:
+                        src = {"bias": b, "v": w, "weight": w, "g": w.norm(dim=1, keepdim=True)}[p.kind]
+                        self._arena[p.offset:p.offset + p.numel].view(p.shape).copy_(src)
+
+    def _apply(self, fn, recurse=True):
+        new = fn(self._arena)
+        if new.dtype != torch.float32:
+            raise TypeError("deepsdf_amd.Decoder is fp32 only")
+        self._bind(new.contiguous())
+        return self
+
+    def _engine_for(self, device):
+        if device.type != "cuda":
+            raise _lib.DsdfError("deepsdf_amd.Decoder.forward needs CUDA tensors: the HIP path has no CPU fallback")
+        if self._arena.device != device:
+            raise RuntimeError(f"Decoder parameters are on {self._arena.device}, input on {device}")
+        if self._engine is None:
+            object.__setattr__(self, "_grad_arena", torch.zeros_like(self._arena))
+            self._engine = Engine(self.spec, device, params=self._arena, grads=self._grad_arena)
+        return self._engine
+
+    def engine(self):
+        """The Engine bound to this module's arenas (fused training path); the module must be on a GPU."""
+        return self._engine_for(self._arena.device)
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        out = super().load_state_dict(state_dict, strict=strict, assign=False)
+        if self._engine is not None:
+            self._engine.weights_dirty = True
+        return out
+
+    # ---- forward ---------------------------------------------------------------------------------------------
+    def forward(self, input):
+        if input.dim() != 2 or input.shape[1] != self.spec.in_dim[0]:
+            raise ValueError(f"expected input [N, {self.spec.in_dim[0]}], got {tuple(input.shape)}")
+        x = input.to(torch.float32)
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        eng = self._engine_for(x.device)
+        eng.weights_dirty = True   # parameters may have been changed by any optimizer since the last call
+        params = tuple(p for p in self.parameters())
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+            return _DecoderFn.apply(self, x, *params)
+        if self.training and self.spec.dropout_prob > 0 and any(self.spec.drop):
+            self._fwd_calls += 1
+            return eng.module_forward(x, True, seed=self.dropout_seed, step=self._fwd_calls)
+        return eng.decode(x)

@@ -24,7 +24,7 @@ def _stream():
 
 
 class Engine:
-    def __init__(self, spec: NetSpec, device="cuda"):
+    def __init__(self, spec: NetSpec, device="cuda", params=None, grads=None):
         self.spec = spec
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -42,8 +42,12 @@ class Engine:
         n = C.c_int64()
         _lib.check(self.lib.dsdf_packed_floats(C.byref(self.cnet), C.byref(n)))
         f32 = dict(dtype=torch.float32, device=self.device)
-        self.params = torch.zeros(spec.n_params, **f32)
-        self.grads = torch.zeros(spec.n_params, **f32)
+        # the Decoder nn.Module hands in its own arenas (its nn.Parameters are views of them)
+        self.params = params if params is not None else torch.zeros(spec.n_params, **f32)
+        self.grads = grads if grads is not None else torch.zeros(spec.n_params, **f32)
+        for t in (self.params, self.grads):
+            if t.device != self.device or t.dtype != torch.float32 or t.numel() != spec.n_params or not t.is_contiguous():
+                raise _lib.DsdfError("parameter/gradient arena must be a contiguous fp32 tensor on the engine's device")
         self.exp_avg = torch.zeros(spec.n_params, **f32)
         self.exp_avg_sq = torch.zeros(spec.n_params, **f32)
         self.packed = torch.zeros(n.value, **f32)

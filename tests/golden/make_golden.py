@@ -388,10 +388,41 @@ def main():
     case_real_weights("g6_real_weights")
     case_latent_only(Decoder, "g7_latent_only", L=8, net_specs=dict(wn4, latent_in=[2]), N=96, iters=5, seed=71)
     case_forward_eval(Decoder, "g8_eval_8x512", L=256, net_specs=bigd, N=128, seed=81)
+    case_checkpoint_layout(Decoder, "g9_checkpoint_layout")
     case_forward_eval(Decoder, "g8_eval_6x128", L=1, net_specs=dict(
         dims=[128] * 6, dropout=list(range(8)), dropout_prob=0.2, norm_layers=list(range(8)), latent_in=[2],
         xyz_in_all=False, use_tanh=False, latent_dropout=False, weight_norm=True, geom_dimension=3), N=100, seed=82)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--layout-only" not in sys.argv:
     main()
+
+
+def case_checkpoint_layout(Decoder, name):
+    """G9: the KEY LAYOUT of the reference's checkpoints (train_deep_sdf.py:96-143): model_state_dict under
+    nn.DataParallel, optimizer_state_dict of Adam with the two param groups after one step, latent_codes."""
+    specs = dict(dims=[16] * 2, dropout=[0, 1], dropout_prob=0.0, norm_layers=[0, 1], latent_in=(), xyz_in_all=False,
+                 use_tanh=False, latent_dropout=False, weight_norm=True, geom_dimension=3)
+    dec = torch.nn.DataParallel(Decoder(3, **specs))
+    lat = torch.nn.Embedding(5, 3, max_norm=1.0)
+    opt = torch.optim.Adam([{"params": dec.parameters(), "lr": 5e-4}, {"params": lat.parameters(), "lr": 1e-3}])
+    x = torch.cat([lat(torch.tensor([0, 1, 1])), torch.rand(3, 3)], 1)
+    dec(x).sum().backward()
+    opt.step()
+    osd = opt.state_dict()
+    out = {
+        "model_state_dict": {k: list(v.shape) for k, v in dec.state_dict().items()},
+        "latent_codes": {k: list(v.shape) for k, v in lat.state_dict().items()},
+        "optimizer_param_groups": [{k: (v if k != "params" else list(v)) for k, v in g.items()} for g in osd["param_groups"]],
+        "optimizer_state": {str(i): {k: (list(v.shape) if torch.is_tensor(v) else v) for k, v in st.items()}
+                            for i, st in osd["state"].items()},
+        "optimizer_step_value": float(osd["state"][0]["step"]),
+        "optimizer_step_dtype": str(osd["state"][0]["step"].dtype),
+    }
+    with open(os.path.join(HERE, name + ".json"), "w") as f:
+        json.dump(out, f, indent=1, default=lambda o: list(o) if isinstance(o, tuple) else str(o))
+    print("wrote", name)
+
+
+if __name__ == "__main__" and "--layout-only" in sys.argv:
+    case_checkpoint_layout(ref_decoder_cls(), "g9_checkpoint_layout")

@@ -1,0 +1,155 @@
+"""CPU: host-side mirror of the reference API -- LR schedules, data pipeline, experiment directory, checkpoint
+layout (against the layout the reference itself writes, tests/golden/g9_checkpoint_layout.json)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_io import GOLDEN, Golden
+
+SMALL = dict(dims=[16] * 2, dropout=[0, 1], dropout_prob=0.0, norm_layers=[0, 1], latent_in=(), xyz_in_all=False,
+             use_tanh=False, latent_dropout=False, weight_norm=True, geom_dimension=3)
+
+
+def test_lr_schedules_match_golden():
+    from deepsdf_amd.train import get_learning_rate_schedules
+    d = json.load(open(os.path.join(GOLDEN, "g5_lr_schedules.json")))
+    sched = get_learning_rate_schedules({"LearningRateSchedule": d["specs"]})
+    for s, row in zip(sched, d["values"]):
+        for e, v in zip(d["epochs"], row):
+            assert s.get_learning_rate(e) == v
+    with pytest.raises(Exception, match='no known learning rate schedule of type "Cosine"'):
+        get_learning_rate_schedules({"LearningRateSchedule": [{"Type": "Cosine"}]})
+
+
+def _write_scene(root, name, n_pos, n_neg, nan_rows=0, dtype=np.float64):
+    rng = np.random.default_rng(hash(name) % 1000)
+    pos = np.concatenate([rng.uniform(-1, 1, (n_pos, 3)), rng.uniform(0.0, 0.5, (n_pos, 1))], 1).astype(dtype)
+    neg = np.concatenate([rng.uniform(-1, 1, (n_neg, 3)), -rng.uniform(0.0, 0.5, (n_neg, 1))], 1).astype(dtype)
+    if nan_rows:
+        pos[:nan_rows, 3] = np.nan
+    d = os.path.join(root, "SdfSamples", "ds", "cls")
+    os.makedirs(d, exist_ok=True)
+    np.savez(os.path.join(d, name + ".npz"), pos=pos, neg=neg)
+
+
+def test_data_pipeline(tmp_path, caplog):
+    from deepsdf_amd import data
+    root = str(tmp_path)
+    _write_scene(root, "a", 500, 400, nan_rows=7)
+    _write_scene(root, "b", 30, 600, dtype=np.float32)          # positive shortfall
+    split = {"ds": {"cls": ["a", "b", "missing"]}}
+    files = data.get_instance_filenames(root, split)              # missing files only warn (data.py:23-31)
+    assert len(files) == 3 and "non-existent file" in caplog.text
+    s = data.unpack_sdf_samples(os.path.join(root, "SdfSamples", files[0]), 3, 100)
+    assert s.shape == (100, 4) and s.dtype == torch.float32 and not torch.isnan(s).any()
+    assert int((s[:, 3] > 0).sum()) == 50
+    s = data.unpack_sdf_samples(os.path.join(root, "SdfSamples", files[1]), 3, 100)
+    assert int((s[:, 3] > 0).sum()) == 30 and s.shape[0] == 100    # 30 pos + 70 neg
+    full = data.unpack_sdf_samples(os.path.join(root, "SdfSamples", files[0]), 3)
+    assert full.shape[0] == 500 - 7 + 400
+    ds = data.SDFSamples(root, {"ds": {"cls": ["a", "b"]}}, 64, 3)
+    smp, idx = ds[1]
+    assert smp.shape == (64, 4) and idx == 1
+    cache = data.DeviceSampleCache.from_files(root, files[:2], 3, "cpu")
+    g = torch.Generator().manual_seed(0)
+    xyz, sdf = cache.sample(torch.tensor([0, 1, 0]), 100, generator=g)
+    assert xyz.shape == (300, 3) and sdf.shape == (300,)
+    assert int((sdf[:100] > 0).sum()) == 50 and int((sdf[100:200] > 0).sum()) == 30
+    rows = torch.cat([xyz, sdf[:, None]], 1)[:100]
+    assert torch.unique(rows, dim=0).shape[0] == 100                # without replacement
+    assert not torch.equal(cache.sample(torch.tensor([0]), 100, generator=g)[0], xyz[:100])
+
+
+def test_workspace_errors_and_dirs(tmp_path):
+    from deepsdf_amd import workspace as ws
+    with pytest.raises(Exception, match="does not include specifications file"):
+        ws.load_experiment_specifications(str(tmp_path))
+    with pytest.raises(Exception, match="does not exist"):
+        ws.load_model_parameters(str(tmp_path), "latest", None)
+    with pytest.raises(Exception, match="does not include a latent code file"):
+        ws.load_latent_vectors(str(tmp_path), "latest")
+    assert os.path.isdir(ws.get_model_params_dir(str(tmp_path), True))
+    assert ws.get_reconstructed_code_filename("e", 5, "d", "c", "i") == os.path.join("e", "Reconstructions", "5", "Codes", "d", "c", "i.pth")
+    import deep_sdf.workspace as ws2
+    assert ws2.logs_filename == "Logs.pth" and ws2.specifications_filename == "specs.json"
+
+
+class _FakeEngine:
+    """Host stand-in with the arena interface AdamStateBridge uses (no GPU involved)."""
+
+    def __init__(self, spec):
+        self.spec = spec
+        self.exp_avg = torch.arange(spec.n_params, dtype=torch.float32)
+        self.exp_avg_sq = torch.arange(spec.n_params, dtype=torch.float32) * 2
+        self.step = 1
+
+    def view(self, arena, p):
+        return arena[p.offset:p.offset + p.numel].view(p.shape)
+
+
+def test_checkpoint_layout_matches_reference(tmp_path):
+    from deepsdf_amd import train
+    from deepsdf_amd.decoder import Decoder
+    ref = json.load(open(os.path.join(GOLDEN, "g9_checkpoint_layout.json")))
+    dec = Decoder(3, **SMALL)
+    exp = str(tmp_path)
+    train.save_model(exp, "latest.pth", dec, 7)
+    m = torch.load(os.path.join(exp, "ModelParameters", "latest.pth"), weights_only=True)
+    assert m["epoch"] == 7
+    assert {k: list(v.shape) for k, v in m["model_state_dict"].items()} == ref["model_state_dict"]
+    assert list(m["model_state_dict"].keys()) == list(ref["model_state_dict"].keys())
+    lat = torch.randn(5, 3)
+    train.save_latent_vectors(exp, "latest.pth", lat, 7)
+    c = torch.load(os.path.join(exp, "LatentCodes", "latest.pth"), weights_only=True)
+    assert {k: list(v.shape) for k, v in c["latent_codes"].items()} == ref["latent_codes"]
+    eng = _FakeEngine(dec.spec)
+    lm, lv = torch.ones(5, 3), torch.ones(5, 3) * 3
+    bridge = train.AdamStateBridge(dec, eng, torch.nn.Parameter(lat), lm, lv, 5e-4, 1e-3)
+    train.save_optimizer(exp, "latest.pth", bridge, 7)
+    o = torch.load(os.path.join(exp, "OptimizerParameters", "latest.pth"), weights_only=True)["optimizer_state_dict"]
+    groups = [{k: (list(v) if isinstance(v, (tuple, list)) else v) for k, v in g.items()} for g in o["param_groups"]]
+    assert groups == ref["optimizer_param_groups"]
+    assert {str(i): {k: (list(v.shape) if torch.is_tensor(v) else v) for k, v in st.items()} for i, st in o["state"].items()} \
+        == ref["optimizer_state"]
+    assert float(o["state"][0]["step"]) == ref["optimizer_step_value"] and str(o["state"][0]["step"].dtype) == ref["optimizer_step_dtype"]
+    # round trip into a fresh bridge restores the arenas and the step counter
+    eng2 = _FakeEngine(dec.spec)
+    eng2.exp_avg.zero_(); eng2.exp_avg_sq.zero_(); eng2.step = 0
+    lm2, lv2 = torch.zeros(5, 3), torch.zeros(5, 3)
+    b2 = train.AdamStateBridge(dec, eng2, torch.nn.Parameter(lat.clone()), lm2, lv2, 0.0, 0.0)
+    assert train.load_optimizer(exp, "latest.pth", b2) == 7
+    assert eng2.step == 1 and torch.equal(eng2.exp_avg, eng.exp_avg) and torch.equal(lv2, lv)
+    with pytest.raises(Exception, match="optimizer state dict .* does not exist"):
+        train.load_optimizer(exp, "nope.pth", b2)
+    full = torch.zeros(4, 3)
+    with pytest.raises(Exception, match="num latent codes mismatched"):
+        train.load_latent_vectors(exp, "latest.pth", full)
+
+
+def test_decoder_state_dict_roundtrip_with_reference_keys():
+    from deepsdf_amd.decoder import Decoder
+    g = Golden("g1a_tiny_full")
+    dec = Decoder(g.meta["L"], **g.meta["net_specs"])
+    params = g.group("params0")
+    dec.load_state_dict(params)
+    sd = dec.state_dict()
+    assert list(sd.keys()) == list(params.keys())
+    for k in params:
+        assert torch.equal(sd[k], params[k])
+    # DataParallel-prefixed keys (what the reference's checkpoints carry) load through a DataParallel wrapper
+    torch.nn.DataParallel(dec).load_state_dict({"module." + k: v * 2 for k, v in params.items()})
+    assert torch.equal(dec.state_dict()["lin0.bias"], params["lin0.bias"] * 2)
+    assert dec.geom_dimension == 3
+    assert sum(p.numel() for p in dec.parameters()) == dec.spec.n_params
+    with pytest.raises(Exception, match="no CPU fallback"):
+        dec(torch.zeros(2, g.meta["L"] + 3))
+
+
+def test_clip_logs_and_magnitudes():
+    from deepsdf_amd import train
+    ll, lr, tl, lm, pm = train.clip_logs(list(range(12)), [[1, 1]] * 4, [0.1] * 4, [0.5] * 4, {"a": [1, 2, 3, 4]}, 2)
+    assert ll == list(range(6)) and len(lr) == 2 and pm == {"a": [1, 2]}
+    assert train.get_spec_with_default({"a": 1}, "b", 5) == 5
