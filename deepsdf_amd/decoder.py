@@ -99,10 +99,13 @@ class Decoder(nn.Module):
         object.__setattr__(self, "_grad_arena", None)
         for p in self.spec.params:
             mod, attr = self._slot(p)
-            old = getattr(mod, attr, None)
+            old = mod._parameters.get(attr)
             view = arena[p.offset:p.offset + p.numel].view(p.shape)
-            par = nn.Parameter(view, requires_grad=True if old is None else old.requires_grad)
-            mod._parameters[attr] = par
+            if old is None:
+                mod._parameters[attr] = nn.Parameter(view, requires_grad=True)
+            else:                      # keep Parameter identity (optimizers hold references), like nn.Module._apply
+                old.data = view
+                old.grad = None
         self._engine = None
 
     def _init_parameters(self):
@@ -122,7 +125,8 @@ class Decoder(nn.Module):
         new = fn(self._arena)
         if new.dtype != torch.float32:
             raise TypeError("deepsdf_amd.Decoder is fp32 only")
-        self._bind(new.contiguous())
+        if new is not self._arena:     # .cuda()/.to() on a module already in place must not drop the engine
+            self._bind(new.contiguous())
         return self
 
     def _engine_for(self, device):
