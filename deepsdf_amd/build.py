@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "dsdf_api.hip")
 DEPS = [os.path.join(HERE, "csrc", f) for f in ("dsdf_api.hip", "gemm.hpp", "kernels.hpp", "common.hpp")] + [
     os.path.join(os.path.dirname(HERE), "include", "dsdf.h")]
-LIB = os.path.join(HERE, "libdsdf_hip.so")
+LIB = os.environ.get("DSDF_LIB_PATH") or os.path.join(HERE, "libdsdf_hip.so")   # override: lab builds only
 
 
 def hipcc_path():

@@ -8,6 +8,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <stdlib.h>
+
+#include "fused.hpp"
 #include "gemm.hpp"
 #include "kernels.hpp"
 
@@ -106,6 +109,9 @@ struct Packed {
   int64_t w_off[DSDF_MAX_LAYERS], wt_off[DSDF_MAX_LAYERS];
   int ldw[DSDF_MAX_LAYERS], ldwt[DSDF_MAX_LAYERS];
   int64_t scale_off;   // per-row weight-norm scales of all layers
+  // fragment-ordered copies for the fused kernels: Wf (n = out, k = in), WTf (n = in, k = out)
+  int64_t wf_off[DSDF_MAX_LAYERS], wtf_off[DSDF_MAX_LAYERS];
+  int uf[DSDF_MAX_LAYERS], utf[DSDF_MAX_LAYERS];   // k-units of 16 per n-tile
   int64_t total;
 };
 Packed packed_layout(const DsdfNet* n) {
@@ -119,6 +125,14 @@ Packed packed_layout(const DsdfNet* n) {
   }
   p.scale_off = o;
   for (int l = 0; l < n->n_layers; ++l) o += n->out_dim[l];
+  o = rup(o, 64);
+  for (int l = 0; l < n->n_layers; ++l) {
+    const int64_t ntw = rup((n->out_dim[l] + 31) / 32, 4), ntt = rup((n->in_dim[l] + 31) / 32, 4);
+    p.uf[l] = 2 * ((n->in_dim[l] + 31) / 32);
+    p.utf[l] = 2 * ((n->out_dim[l] + 31) / 32);
+    p.wf_off[l] = o;  o += ntw * p.uf[l] * 512;
+    p.wtf_off[l] = o; o += ntt * p.utf[l] * 512;
+  }
   p.total = rup(o, 64);
   return p;
 }
@@ -291,6 +305,10 @@ int materialize(const DsdfNet* net, const float* params, float* packed, hipStrea
     y.WT = (l == net->n_layers - 1) ? nullptr : packed + pk.wt_off[l];
     y.out = net->out_dim[l]; y.in = net->in_dim[l]; y.ldw = pk.ldw[l]; y.ldwt = pk.ldwt[l];
     y.row0 = rows; y.tile0 = tiles; y.tcols = (y.in + 31) / 32;
+    const bool last = l == net->n_layers - 1;
+    y.Wf = last ? nullptr : packed + pk.wf_off[l];
+    y.WTf = (last || l == 0) ? nullptr : packed + pk.wtf_off[l];
+    y.Uf = pk.uf[l]; y.UTf = pk.utf[l];
     rows += y.out;
     tiles += ((y.out + 31) / 32) * y.tcols;
   }
@@ -316,6 +334,83 @@ int run_gather(const DsdfNet* net, const Plan& P, void* ws, const float* table, 
     if ((net->skip_mask >> l) & 1) g.dst[g.ndst++] = GatherDst{at<float>(ws, P.in_off[l]), P.ld_in[l], net->out_dim[l - 1]};
   hipLaunchKernelGGL(gather_concat_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, g);
   LAUNCH_OK("gather_concat_kernel");
+  return 0;
+}
+
+bool fused_enabled() {
+  const char* e = getenv("DSDF_NO_FUSED");
+  return !(e && e[0] == '1');
+}
+
+bool fused_eligible(const DsdfNet* net) {
+  if (net->in_dim[0] > FMAXW) return false;
+  for (int l = 0; l < net->n_layers - 1; ++l)
+    if (net->in_dim[l] > FMAXW || net->out_dim[l] > FMAXW) return false;
+  return net->in_dim[net->n_layers - 1] <= FMAXW;
+}
+
+// all hidden layers + the last layer's forward in ONE launch (fused.hpp).  store_act: keep global copies of the
+// activations (training / module path) or not (inference).
+int run_fused_forward(const DsdfNet* net, const Plan& P, void* ws, const float* packed, const float* params, int64_t n,
+                      int training, const uint32_t* keys, uint32_t row_offset, bool store_act, float* y_out, float* u_out,
+                      hipStream_t st) {
+  DsdfParamLayout L;
+  param_layout(net, &L);
+  const Packed pk = packed_layout(net);
+  const int last = net->n_layers - 1;
+  FusedFwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.n_hidden = last; a.N = (int)n; a.W0 = net->in_dim[0];
+  a.x0 = at<float>(ws, P.in_off[0]); a.ldx0 = P.ld_in[0];
+  a.row_offset = row_offset;
+  for (int l = 0; l < last; ++l) {
+    FusedLayer& y = a.ly[l];
+    y.wf = packed + pk.wf_off[l];
+    y.bias = params + L.bias_off[l];
+    y.out = store_act ? at<float>(ws, P.in_off[l + 1]) : nullptr;
+    y.ld_out = P.ld_in[l + 1];
+    y.in = net->in_dim[l]; y.out_dim = net->out_dim[l]; y.U = pk.uf[l];
+    const bool drop = training && ((net->dropout_mask >> l) & 1) && net->dropout_p > 0.f;
+    if (drop) {
+      long thr = lround((double)net->dropout_p * 65536.0);
+      if (thr > 65535) thr = 65535;
+      y.drop_thr = (uint32_t)thr; y.drop_key = keys[l]; y.drop_scale = 1.0f / (1.0f - net->dropout_p);
+    }
+    y.x0_col = ((net->skip_mask >> (l + 1)) & 1) ? net->out_dim[l] : -1;
+  }
+  a.w_last = packed + pk.w_off[last]; a.b_last = params + L.bias_off[last]; a.in_last = net->in_dim[last];
+  a.use_tanh = net->use_tanh; a.y_out = y_out; a.u_out = u_out;
+  double wmac = 0;
+  for (int l = 0; l < last; ++l) wmac += (double)net->in_dim[l] * net->out_dim[l];
+  ProfScope ps(DSDF_PROF_FUSED_FWD, 2.0 * (double)n * wmac, st);
+  #ifdef DSDF_LAB
+  static unsigned long long* dbg = nullptr;
+  if (!dbg && getenv("DSDF_LAB_DBG")) { (void)hipMalloc(&dbg, 8192 * 64 * 8); }
+  a.dbg = dbg;
+#endif
+  static const int ablate = getenv("DSDF_LAB_ABLATE") ? atoi(getenv("DSDF_LAB_ABLATE")) : 0;   // lab only
+  const dim3 grid((unsigned)((n + FROWS - 1) / FROWS));
+  switch (ablate) {
+    case 1: hipLaunchKernelGGL(fused_forward_kernel<1>, grid, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(fused_forward_kernel<2>, grid, dim3(256), 0, st, a); break;
+    case 3: hipLaunchKernelGGL(fused_forward_kernel<3>, grid, dim3(256), 0, st, a); break;
+    case 5: hipLaunchKernelGGL(fused_forward_kernel<5>, grid, dim3(256), 0, st, a); break;
+    case 7: hipLaunchKernelGGL(fused_forward_kernel<7>, grid, dim3(256), 0, st, a); break;
+    case 8: hipLaunchKernelGGL(fused_forward_kernel<8>, grid, dim3(256), 0, st, a); break;
+    case 16: hipLaunchKernelGGL(fused_forward_kernel<16>, grid, dim3(256), 0, st, a); break;
+    case 24: hipLaunchKernelGGL(fused_forward_kernel<24>, grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL(fused_forward_kernel<0>, grid, dim3(256), 0, st, a); break;
+  }
+#ifdef DSDF_LAB
+  if (dbg && getenv("DSDF_LAB_DBG")) {
+    (void)hipDeviceSynchronize();
+    static unsigned long long h[8192 * 64];
+    (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+    FILE* f = fopen(getenv("DSDF_LAB_DBG"), "wb");
+    if (f) { fwrite(h, 1, sizeof(h), f); fclose(f); }
+  }
+#endif
+  LAUNCH_OK("fused_forward_kernel");
   return 0;
 }
 
@@ -489,6 +584,8 @@ int dsdf_decode(const DsdfNet* net, const float* packed, const float* params, co
   if (ws_bytes < P.total) return fail(DSDF_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, P.total);
   hipStream_t st = (hipStream_t)stream;
   TRY(run_gather(net, P, ws, nullptr, nullptr, input, ld_in, n, st));
+  if (fused_enabled() && fused_eligible(net))
+    return run_fused_forward(net, P, ws, packed, params, n, 0, nullptr, 0, false, sdf_out, nullptr, st);
   TRY(run_hidden_forward(net, P, ws, packed, params, n, 0, nullptr, 0, st));
   DsdfParamLayout L;
   param_layout(net, &L);
@@ -515,6 +612,8 @@ int dsdf_module_forward(const DsdfNet* net, const float* packed, const float* pa
   if (ws_bytes < P.total) return fail(DSDF_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, P.total);
   hipStream_t st = (hipStream_t)stream;
   TRY(run_gather(net, P, ws, nullptr, nullptr, input, ld_in, n, st));
+  if (fused_enabled() && fused_eligible(net))
+    return run_fused_forward(net, P, ws, packed, params, n, training, dropout_key, 0, true, sdf_out, at<float>(ws, P.u_off), st);
   TRY(run_hidden_forward(net, P, ws, packed, params, n, training, dropout_key, 0, st));
   DsdfParamLayout L;
   param_layout(net, &L);
@@ -585,7 +684,11 @@ int dsdf_train_forward_backward(const DsdfNet* net, const float* packed, const f
     LAUNCH_OK("latent_renorm_kernel");
   }
   TRY(run_gather(net, P, ws, latent_table, b, nullptr, 0, n, st));
-  TRY(run_hidden_forward(net, P, ws, packed, params, n, cfg->training, cfg->dropout_key, (uint32_t)b->row_offset, st));
+  if (fused_enabled() && fused_eligible(net))
+    TRY(run_fused_forward(net, P, ws, packed, params, n, cfg->training, cfg->dropout_key, (uint32_t)b->row_offset, true,
+                          nullptr, nullptr, st));
+  else
+    TRY(run_hidden_forward(net, P, ws, packed, params, n, cfg->training, cfg->dropout_key, (uint32_t)b->row_offset, st));
 
   DsdfParamLayout L;
   param_layout(net, &L);

@@ -65,7 +65,11 @@ __global__ void gather_concat_kernel(const GatherArgs p) {
 // K1: W = g * v / ||v||_row (torch._weight_norm(v, g, 0)) or plain copy, for ALL layers in two launches:
 //   wn_scale_kernel : one wave per (layer,row): scale = g / ||v_row||  (1 for plain layers)
 //   wn_tiles_kernel : one block per 32x32 tile: W tile (coalesced) and W^T tile through a 32x33 LDS transpose.
-struct WnLayer { const float* v; const float* g; float* W; float* WT; int out, in, ldw, ldwt; int row0; int tile0; int tcols; };
+struct WnLayer {
+  const float* v; const float* g; float* W; float* WT; int out, in, ldw, ldwt; int row0; int tile0; int tcols;
+  float* Wf; float* WTf;   // fragment-ordered copies for the fused kernels (see fused.hpp), or nullptr
+  int Uf, UTf;             // k-units (of 16) allocated per n-tile in Wf / WTf
+};
 struct WnAll { int nl; int total_rows; int total_tiles; float* scale; WnLayer ly[DSDF_MAX_LAYERS]; };
 
 __global__ __launch_bounds__(256) void wn_scale_kernel(const WnAll p) {
@@ -86,6 +90,9 @@ __global__ __launch_bounds__(256) void wn_scale_kernel(const WnAll p) {
   if (lane == 0) p.scale[gr] = s;
 }
 
+// Fragment order (fused.hpp): for an operand matrix B[n][k] (n = output column of the product, k = contraction):
+//   Bf[((nt * U + u) * 2 + i) * 256 + lane * 4 + e] = B[32 nt + (lane & 31)][16 u + 8 (lane >> 5) + 4 i + e]
+// so that a wave's MFMA B-operand for k-unit u of n-tile nt is two perfectly coalesced 1-KiB dwordx4 loads.
 __global__ __launch_bounds__(256) void wn_tiles_kernel(const WnAll p) {
   __shared__ float tile[32][33];
   const int t = blockIdx.x;
@@ -93,7 +100,8 @@ __global__ __launch_bounds__(256) void wn_tiles_kernel(const WnAll p) {
   while (l + 1 < p.nl && t >= p.ly[l + 1].tile0) ++l;
   const WnLayer& L = p.ly[l];
   const int tt = t - L.tile0;
-  const int r0 = (tt / L.tcols) * 32, c0 = (tt % L.tcols) * 32;
+  const int rb = tt / L.tcols, cb = tt % L.tcols;
+  const int r0 = rb * 32, c0 = cb * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -105,12 +113,24 @@ __global__ __launch_bounds__(256) void wn_tiles_kernel(const WnAll p) {
     }
     tile[rr][tx] = w;
   }
-  if (L.WT == nullptr) return;
+  if (L.WT == nullptr && L.Wf == nullptr) return;
   __syncthreads();
+  if (L.WT != nullptr) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int cc = ty + 8 * k, col = c0 + cc, row = r0 + tx;
-    if (col < L.in && row < L.out) L.WT[(size_t)col * L.ldwt + row] = tile[tx][cc];
+    for (int k = 0; k < 4; ++k) {
+      const int cc = ty + 8 * k, col = c0 + cc, row = r0 + tx;
+      if (col < L.in && row < L.out) L.WT[(size_t)col * L.ldwt + row] = tile[tx][cc];
+    }
+  }
+  const int uu = threadIdx.x >> 7, i = (threadIdx.x >> 6) & 1, lane = threadIdx.x & 63;
+  const int fr = lane & 31, fh = lane >> 5, kk = 16 * uu + 8 * fh + 4 * i;
+  if (L.Wf != nullptr) {   // B = W: n = out index (tile rows), k = in index (tile cols)
+    float4 v4 = make_float4(tile[fr][kk], tile[fr][kk + 1], tile[fr][kk + 2], tile[fr][kk + 3]);
+    *reinterpret_cast<float4*>(L.Wf + ((size_t)(rb * L.Uf + 2 * cb + uu) * 2 + i) * 256 + lane * 4) = v4;
+  }
+  if (L.WTf != nullptr) {  // B = W^T: n = in index (tile cols), k = out index (tile rows)
+    float4 v4 = make_float4(tile[kk][fr], tile[kk + 1][fr], tile[kk + 2][fr], tile[kk + 3][fr]);
+    *reinterpret_cast<float4*>(L.WTf + ((size_t)(cb * L.UTf + 2 * rb + uu) * 2 + i) * 256 + lane * 4) = v4;
   }
 }
 

@@ -29,6 +29,8 @@ class Engine:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.DsdfError("deepsdf_amd.Engine needs a CUDA/HIP device (no CPU fallback)")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.lib = _lib.lib()
         self.cnet = spec.c_struct()
         lay = _lib.DsdfParamLayout()

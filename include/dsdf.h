@@ -101,7 +101,9 @@ int dsdf_decode_workspace_bytes(const DsdfNet* net, int64_t n_points, size_t* by
 /* ---- weights -------------------------------------------------------------------------------------
  * W = g * v / ||v||_row for weight-normed layers (torch._weight_norm via parametrizations.weight_norm,
  * deep_sdf_decoder.py:50-55), plain copy otherwise; written as W [out,in] and W^T [in,out] in padded,
- * MFMA-friendly layout.  Must be called after every parameter change (dsdf_adam_step does it itself). */
+ * MFMA-friendly layouts (row-major W and W^T, plus fragment-ordered copies for the fused kernels).  `packed` must be
+ * ZERO-INITIALISED once by the caller (padding tiles are never written).  Must be called after every parameter
+ * change (dsdf_adam_step does it itself). */
 int dsdf_materialize_weights(const DsdfNet* net, const float* params, float* packed, void* stream);
 
 /* ---- inference: deep_sdf/utils.py:54-65 decode_sdf / Decoder.forward in eval mode ------------------
@@ -147,8 +149,9 @@ int dsdf_adam_latent_only(float* latent, const float* dlat, float* exp_avg, floa
 
 /* ---- diagnostics: per-kernel-class device time from HIP events recorded on the caller's stream around every
  * launch of that class (bench.py's roofline object).  Off by default; thread-local; read synchronises. */
-#define DSDF_PROF_CLASSES 4
-enum { DSDF_PROF_GEMM_NT = 0, DSDF_PROF_GEMM_TN = 1, DSDF_PROF_LAST = 2, DSDF_PROF_OTHER = 3 };
+#define DSDF_PROF_CLASSES 6
+enum { DSDF_PROF_GEMM_NT = 0, DSDF_PROF_GEMM_TN = 1, DSDF_PROF_LAST = 2, DSDF_PROF_FUSED_FWD = 3, DSDF_PROF_FUSED_BWD = 4,
+       DSDF_PROF_OTHER = 5 };
 typedef struct DsdfProfile {
   double ms[DSDF_PROF_CLASSES];     /* summed event-to-event time per class */
   double flops[DSDF_PROF_CLASSES];  /* summed 2*M*N*K (executed, incl. tile padding excluded) per class */
