@@ -388,19 +388,7 @@ int run_fused_forward(const DsdfNet* net, const Plan& P, void* ws, const float* 
   if (!dbg && getenv("DSDF_LAB_DBG")) { (void)hipMalloc(&dbg, 8192 * 64 * 8); }
   a.dbg = dbg;
 #endif
-  static const int ablate = getenv("DSDF_LAB_ABLATE") ? atoi(getenv("DSDF_LAB_ABLATE")) : 0;   // lab only
-  const dim3 grid((unsigned)((n + FROWS - 1) / FROWS));
-  switch (ablate) {
-    case 1: hipLaunchKernelGGL(fused_forward_kernel<1>, grid, dim3(256), 0, st, a); break;
-    case 2: hipLaunchKernelGGL(fused_forward_kernel<2>, grid, dim3(256), 0, st, a); break;
-    case 3: hipLaunchKernelGGL(fused_forward_kernel<3>, grid, dim3(256), 0, st, a); break;
-    case 5: hipLaunchKernelGGL(fused_forward_kernel<5>, grid, dim3(256), 0, st, a); break;
-    case 7: hipLaunchKernelGGL(fused_forward_kernel<7>, grid, dim3(256), 0, st, a); break;
-    case 8: hipLaunchKernelGGL(fused_forward_kernel<8>, grid, dim3(256), 0, st, a); break;
-    case 16: hipLaunchKernelGGL(fused_forward_kernel<16>, grid, dim3(256), 0, st, a); break;
-    case 24: hipLaunchKernelGGL(fused_forward_kernel<24>, grid, dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL(fused_forward_kernel<0>, grid, dim3(256), 0, st, a); break;
-  }
+  hipLaunchKernelGGL(fused_forward_kernel, dim3((unsigned)((n + FROWS - 1) / FROWS)), dim3(256), 0, st, a);
 #ifdef DSDF_LAB
   if (dbg && getenv("DSDF_LAB_DBG")) {
     (void)hipDeviceSynchronize();

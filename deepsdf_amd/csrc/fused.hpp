@@ -1,15 +1,17 @@
 // fused.hpp -- layer-fused persistent kernels (gfx950): one workgroup walks ALL hidden layers for its own
-// 32-row slab of points, so inter-layer activations never make an HBM round trip inside the pass and the
-// per-layer prologue/epilogue bursts of the layer-by-layer GEMM launches disappear.
+// 64-row slab of points, so inter-layer activations never make an HBM round trip inside the pass and the
+// per-layer prologue/epilogue bursts of layer-by-layer GEMM launches disappear.
 //
-// Geometry: workgroup = 4 waves = 32 points.  The layer input (<= 512 wide) lives in LDS as S[32][516] fp32
-// (2064-B rows: 16 distinct rows hit 16 distinct 16-B bank slots -> conflict-free ds_read_b128).  Wave w owns
-// output n-tiles {w, w+4, w+8, w+12} (32 columns each, up to 512 outputs): 4 x v_mfma_f32_32x32x2_f32
-// accumulators = 64 VGPRs.  The B operand (weights) is NOT staged in LDS: it is pre-packed in "fragment order"
-// (kernels.hpp wn_tiles_kernel) so each k-unit of 16 is two perfectly coalesced 1-KiB dwordx4 loads per n-tile,
-// issued one unit ahead (L2-resident: every workgroup streams the same 1 MB per layer).  Two workgroups per CU
-// (2 x 66 KB LDS, <= 256 VGPRs) run the same program; their epilogues (VALU + stores) overlap the other one's
-// MFMA stream.
+// Geometry: workgroup = 4 waves = 64 points, ONE workgroup per CU = ONE wave per SIMD.  The layer input (<= 512 wide)
+// lives in LDS as S[64][516] fp32 (132 KB; 2064-B rows: 16 distinct rows hit 16 distinct 16-B bank slots ->
+// conflict-free ds_read_b128).  Wave w owns all 64 rows (2 m-tiles) of output n-tiles {w, w+4, w+8, w+12}:
+// 2 x 4 v_mfma_f32_32x32x2_f32 accumulators = 128 registers (the compiler keeps them in AGPRs).  The B operand
+// (weights) is NOT staged in LDS: it is pre-packed in "fragment order" (kernels.hpp wn_tiles_kernel) so each k-unit
+// of 16 is two perfectly coalesced 1-KiB dwordx4 loads per n-tile, issued one unit ahead (L2-resident: every
+// workgroup streams the same 1 MB per layer; each B register feeds 2 MFMAs, each A register 4).
+// Why one wave per SIMD: measured on MI355X (tools/lab/mfma_peak.hip) this k-loop sustains 145 TFLOP/s at 2.34 GHz;
+// the same work as 2 waves per SIMD (either 2 x 32-row workgroups or 8 waves) pulls the clock down to 1.9-2.1 GHz
+// (109-127 TFLOP/s): the bare fp32 MFMA stream saturates from a single wave, so extra waves only add power.
 //
 // k-permutation: within a unit of 16, lane (r, h) holds k = 16u + 8h + j (j = 0..7) for BOTH operands, so MFMA j
 // contracts k in {16u + j, 16u + 8 + j}: a permutation of the sum order only.
@@ -20,7 +22,7 @@
 
 namespace dsdf {
 
-constexpr int FROWS = 32;        // points per workgroup
+constexpr int FROWS = 64;        // points per workgroup
 constexpr int FLD = 516;         // slab row stride in floats
 constexpr int FMAXW = 512;       // widest layer the fused kernels handle
 
@@ -44,32 +46,35 @@ struct FusedFwdArgs {
   unsigned long long* dbg;   // lab builds (-DDSDF_LAB): per-workgroup s_memtime stamps, else unused
 };
 
+// rows of x0 into slab columns [col0, col0 + W0).  All 16-byte loads of a pass are issued back-to-back BEFORE the
+// first LDS write: a load-use-load-use loop would pay the HBM latency dozens of times in a row.
 __device__ __forceinline__ void fused_load_x0(float* S, const float* x0, int ldx0, int W0, int row0, int N, int col0) {
-  // rows of x0 into slab columns [col0, col0 + W0).  All (<= 16) 16-byte loads of a thread are issued back-to-back
-  // BEFORE the first LDS write: a load-use-load-use loop would pay the HBM latency 30+ times in a row.
-  const int cpr = (W0 + 3) >> 2;            // float4 chunks per row (ldx0 is a multiple of 4: the tail chunk is in bounds)
+  constexpr int XCH = 20;                   // float4 chunks per thread per pass
+  const int cpr = (W0 + 3) >> 2;            // chunks per row (ldx0 is a multiple of 4: the tail chunk is in bounds)
   const int total = FROWS * cpr;
-  float4 v[16];
+  for (int base = 0; base < total; base += 256 * XCH) {
+    float4 v[XCH];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int ci = threadIdx.x + 256 * k;
-    v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ci < total) {
-      const int r = ci / cpr, c = ci - r * cpr;
-      if (row0 + r < N) v[k] = *reinterpret_cast<const float4*>(x0 + (size_t)(row0 + r) * ldx0 + 4 * c);
+    for (int k = 0; k < XCH; ++k) {
+      const int ci = base + threadIdx.x + 256 * k;
+      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ci < total) {
+        const int r = ci / cpr, c = ci - r * cpr;
+        if (row0 + r < N) v[k] = *reinterpret_cast<const float4*>(x0 + (size_t)(row0 + r) * ldx0 + 4 * c);
+      }
     }
-  }
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int ci = threadIdx.x + 256 * k;
-    if (ci < total) {
-      const int r = ci / cpr, c = ci - r * cpr;
-      float* d = S + r * FLD + col0 + 4 * c;
-      const int rem = W0 - 4 * c;
-      d[0] = v[k].x;
-      if (rem > 1) d[1] = v[k].y;
-      if (rem > 2) d[2] = v[k].z;
-      if (rem > 3) d[3] = v[k].w;
+    for (int k = 0; k < XCH; ++k) {
+      const int ci = base + threadIdx.x + 256 * k;
+      if (ci < total) {
+        const int r = ci / cpr, c = ci - r * cpr;
+        float* d = S + r * FLD + col0 + 4 * c;
+        const int rem = W0 - 4 * c;
+        d[0] = v[k].x;
+        if (rem > 1) d[1] = v[k].y;
+        if (rem > 2) d[2] = v[k].z;
+        if (rem > 3) d[3] = v[k].w;
+      }
     }
   }
 }
@@ -77,11 +82,11 @@ __device__ __forceinline__ void fused_load_x0(float* S, const float* x0, int ldx
 // C-layout rows of a 32x32 MFMA tile held by one lane: reg -> (reg & 3) + 8 (reg >> 2) (+ 4 * (lane >> 5))
 __device__ __forceinline__ constexpr int crow(int reg) { return (reg & 3) + 8 * (reg >> 2); }
 
-// Forward epilogue of one wave: bias + ReLU (+ dropout) on its 4 accumulators, written to the LDS slab (next layer's
-// input) and to the global activation copy.  Lean by construction: global stores are buffer stores (hardware bounds
-// check drops rows >= N and masked columns; row offsets are SCALAR), LDS stores use immediate offsets.
+// Forward epilogue of one wave: bias + ReLU (+ dropout) on its 2x4 accumulators, written to the LDS slab (next
+// layer's input) and to the global activation copy.  Lean by construction: global stores are buffer stores (hardware
+// bounds check drops rows >= N and masked columns; row offsets are SCALAR), LDS stores use immediate offsets.
 template <bool DROP, bool EVEN>
-__device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[4], const float (&biasv)[4], float* S,
+__device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[2][4], const float (&biasv)[4], float* S,
                                                    const FusedLayer& L, int w, int fr, int fh, int row0, int N,
                                                    uint32_t row_offset) {
   const int rows_here = min(FROWS, N - row0);
@@ -103,60 +108,112 @@ __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[4], const
     }
     if (cok) {
 #pragma unroll
-      for (int rp = 0; rp < 8; ++rp) {
-        constexpr int dummy = 0; (void)dummy;
-        const int rc = crow(2 * rp);             // compile-time: 0,2,8,10,16,18,24,26
-        float v0 = fmaxf(acc[ni][2 * rp] + bv, 0.f), v1 = fmaxf(acc[ni][2 * rp + 1] + bv, 0.f);
-        if constexpr (DROP) {
-          if constexpr (EVEN) {   // rows rc, rc+1 share one pair hash
-            const uint32_t h = lowbias32(ck ^ (pm + (uint32_t)(rc >> 1) * 0x9E3779B1u));
-            v0 = (h & 0xFFFFu) >= L.drop_thr ? v0 * L.drop_scale : 0.f;
-            v1 = (h >> 16) >= L.drop_thr ? v1 * L.drop_scale : 0.f;
-          } else {                // global row of rc is odd: rc -> high half of pair q, rc+1 -> low half of pair q+1
-            const uint32_t ha = lowbias32(ck ^ (pm + (uint32_t)(rc >> 1) * 0x9E3779B1u));
-            const uint32_t hb = lowbias32(ck ^ (pm + (uint32_t)((rc >> 1) + 1) * 0x9E3779B1u));
-            v0 = (ha >> 16) >= L.drop_thr ? v0 * L.drop_scale : 0.f;
-            v1 = (hb & 0xFFFFu) >= L.drop_thr ? v1 * L.drop_scale : 0.f;
+      for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int rp = 0; rp < 8; ++rp) {
+          const int rc = 32 * m + crow(2 * rp);    // compile-time local row (without the 4*fh lane term); even
+          float v0 = fmaxf(acc[m][ni][2 * rp] + bv, 0.f), v1 = fmaxf(acc[m][ni][2 * rp + 1] + bv, 0.f);
+          if constexpr (DROP) {
+            if constexpr (EVEN) {   // rows rc, rc+1 share one pair hash
+              const uint32_t h = lowbias32(ck ^ (pm + (uint32_t)(rc >> 1) * 0x9E3779B1u));
+              v0 = (h & 0xFFFFu) >= L.drop_thr ? v0 * L.drop_scale : 0.f;
+              v1 = (h >> 16) >= L.drop_thr ? v1 * L.drop_scale : 0.f;
+            } else {                // global row of rc is odd: rc -> high half of pair q, rc+1 -> low half of pair q+1
+              const uint32_t ha = lowbias32(ck ^ (pm + (uint32_t)(rc >> 1) * 0x9E3779B1u));
+              const uint32_t hb = lowbias32(ck ^ (pm + (uint32_t)((rc >> 1) + 1) * 0x9E3779B1u));
+              v0 = (ha >> 16) >= L.drop_thr ? v0 * L.drop_scale : 0.f;
+              v1 = (hb & 0xFFFFu) >= L.drop_thr ? v1 * L.drop_scale : 0.f;
+            }
           }
+          sp[rc * FLD] = v0;
+          sp[(rc + 1) * FLD] = v1;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rsrc, voff, rc * ldb, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rsrc, voff, (rc + 1) * ldb, 0);
         }
-        sp[rc * FLD] = v0;
-        sp[(rc + 1) * FLD] = v1;
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rsrc, voff, rc * ldb, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rsrc, voff, (rc + 1) * ldb, 0);
       }
     }
   }
 }
 
-// ABLATE (lab builds only; product = 0): 1 = reuse unit-0 B registers (no weight streaming), 2 = skip the epilogue's
-// stores/hash, 4 = read the A fragment once per layer (no LDS streaming)
-template <int ABLATE>
+// The shared k-loop: acc[m][ni] += S[64 rows][K] * Bf[n-tiles of this wave][K]; NACT = existing n-tiles of this wave.
+template <int NACT>
+__device__ __forceinline__ void fused_kloop(f32x16 (&acc)[2][4], const float* ap, const float* const (&bp)[4], int nu) {
+  float4 b0[NACT][2], b1[NACT][2];
+  auto loadB = [&](float4 (&b)[NACT][2], int u) {
+#pragma unroll
+    for (int ni = 0; ni < NACT; ++ni) {
+      b[ni][0] = *reinterpret_cast<const float4*>(bp[ni] + (size_t)u * 512);
+      b[ni][1] = *reinterpret_cast<const float4*>(bp[ni] + (size_t)u * 512 + 256);
+    }
+  };
+  auto compute = [&](const float4 (&b)[NACT][2], int u) {
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const float4 a0 = *reinterpret_cast<const float4*>(ap + 16 * u + 4 * hf);
+      const float4 a1 = *reinterpret_cast<const float4*>(ap + 32 * FLD + 16 * u + 4 * hf);
+      const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int ni = 0; ni < NACT; ++ni) {
+          const float4 bq = b[ni][hf];
+          const float bv = e == 0 ? bq.x : (e == 1 ? bq.y : (e == 2 ? bq.z : bq.w));
+          acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv, acc[0][ni], 0, 0, 0);
+          acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv, acc[1][ni], 0, 0, 0);
+        }
+      }
+    }
+  };
+  loadB(b0, 0);
+  int u = 0;
+  for (; u + 1 < nu; u += 2) {
+    loadB(b1, u + 1);
+    compute(b0, u);
+    if (u + 2 < nu) loadB(b0, u + 2);
+    compute(b1, u + 1);
+  }
+  if (u < nu) compute(b0, u);
+}
+
+__device__ __forceinline__ void fused_kloop_dispatch(f32x16 (&acc)[2][4], const float* ap, const float* const (&bp)[4],
+                                                     int nu, int nact) {
+  switch (nact) {
+    case 4: fused_kloop<4>(acc, ap, bp, nu); break;
+    case 3: fused_kloop<3>(acc, ap, bp, nu); break;
+    case 2: fused_kloop<2>(acc, ap, bp, nu); break;
+    case 1: fused_kloop<1>(acc, ap, bp, nu); break;
+    default: break;
+  }
+}
+
+__device__ __forceinline__ void fused_zero_pad(float* S, int nin) {   // columns [nin, roundup16(nin)) of every slab row
+  const int zc = ((nin + 15) & ~15) - nin;
+  for (int i = threadIdx.x; i < FROWS * zc; i += 256) S[(i / zc) * FLD + nin + (i % zc)] = 0.f;
+}
+
 __global__ __launch_bounds__(256, 2) void fused_forward_kernel(const FusedFwdArgs p) {
   __shared__ __attribute__((aligned(16))) float S[FROWS * FLD];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int row0 = blockIdx.x * FROWS;
 
-  // layer-0 input: [x0 | zeros up to the next multiple of 16]
   fused_load_x0(S, p.x0, p.ldx0, p.W0, row0, p.N, 0);
-  {
-    const int zc = ((p.W0 + 15) & ~15) - p.W0;
-    for (int i = tid; i < FROWS * zc; i += 256) S[(i / zc) * FLD + p.W0 + (i % zc)] = 0.f;
-  }
+  fused_zero_pad(S, p.W0);
   __syncthreads();
-
 #ifdef DSDF_LAB
   if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 0] = __builtin_amdgcn_s_memtime();
 #endif
+
   for (int l = 0; l < p.n_hidden; ++l) {
     const FusedLayer& L = p.ly[l];
     const int nu = (L.in + 15) >> 4;
-    f32x16 acc[4];
+    f32x16 acc[2][4];
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
-    // this wave's four n-tiles: nt = w + 4 ni
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][ni][r] = 0.f;
     const float* bp[4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) bp[ni] = L.wf + (size_t)(w + 4 * ni) * L.U * 512 + lane * 4;
@@ -169,64 +226,11 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(const FusedFwdArg
       const int col = 32 * (w + 4 * ni) + fr;
       biasv[ni] = col < L.out_dim ? L.bias[col] : 0.f;
     }
-
-    // B prefetch one k-unit ahead, two NAMED register sets (no copies, so the compiler can use counted vmcnt waits).
-    // NACT = how many of this wave's n-tiles {w, w+4, w+8, w+12} exist in this layer (wave-uniform).
-    auto kloop = [&](auto nact_c) {
-      constexpr int NACT = decltype(nact_c)::value;
-      float4 b0[NACT][2], b1[NACT][2];
-      auto loadB = [&](float4 (&b)[NACT][2], int u) {
-#pragma unroll
-        for (int ni = 0; ni < NACT; ++ni) {
-          b[ni][0] = *reinterpret_cast<const float4*>(bp[ni] + (size_t)u * 512);
-          b[ni][1] = *reinterpret_cast<const float4*>(bp[ni] + (size_t)u * 512 + 256);
-        }
-      };
-      auto compute = [&](const float4 (&b)[NACT][2], int u) {
-        const float4 a0 = *reinterpret_cast<const float4*>(ap + 16 * u);
-        const float4 a1 = *reinterpret_cast<const float4*>(ap + 16 * u + 4);
-        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-#pragma unroll
-          for (int ni = 0; ni < NACT; ++ni) {
-            const float4 bq = b[ni][j >> 2];
-            const float bv = (j & 3) == 0 ? bq.x : ((j & 3) == 1 ? bq.y : ((j & 3) == 2 ? bq.z : bq.w));
-            acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv, acc[ni], 0, 0, 0);
-          }
-        }
-      };
-      loadB(b0, 0);
-      int u = 0;
-      if constexpr ((ABLATE & 1) != 0) {
-        loadB(b1, 1);
-        for (; u + 1 < nu; u += 2) { compute(b0, (ABLATE & 4) ? 0 : u); compute(b1, (ABLATE & 4) ? 0 : u + 1); }
-      } else {
-        for (; u + 1 < nu; u += 2) {
-          loadB(b1, u + 1);
-          if constexpr ((ABLATE & 8) != 0) __builtin_amdgcn_sched_barrier(0);   // lab: pin the prefetch ahead of the MFMAs
-          if constexpr ((ABLATE & 16) != 0) { if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-          compute(b0, (ABLATE & 4) ? 0 : u);
-          if (u + 2 < nu) loadB(b0, u + 2);
-          if constexpr ((ABLATE & 8) != 0) __builtin_amdgcn_sched_barrier(0);
-          if constexpr ((ABLATE & 16) != 0) { if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
-          compute(b1, (ABLATE & 4) ? 0 : u + 1);
-        }
-      }
-      if (u < nu) compute(b0, u);
-    };
     {
       const int ntl = (L.out_dim + 31) >> 5;
       const int nact = ntl > w ? min(4, (ntl - w + 3) >> 2) : 0;
-      switch (nact) {
-        case 4: kloop(std::integral_constant<int, 4>{}); break;
-        case 3: kloop(std::integral_constant<int, 3>{}); break;
-        case 2: kloop(std::integral_constant<int, 2>{}); break;
-        case 1: kloop(std::integral_constant<int, 1>{}); break;
-        default: break;
-      }
+      fused_kloop_dispatch(acc, ap, bp, nu, nact);
     }
-
 #ifdef DSDF_LAB
     if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 1 + 3 * l] = __builtin_amdgcn_s_memtime();
 #endif
@@ -238,24 +242,18 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(const FusedFwdArg
     {
       const bool drop = L.drop_thr != 0u;
       const bool even = ((p.row_offset + (uint32_t)row0) & 1u) == 0u;   // 4*fh and crow(2rp) are even
-      if constexpr (ABLATE & 2) {
-        if (acc[0][0] == 123.456f) S[tid] = acc[1][1] + acc[2][2] + acc[3][3];   // keep the accumulators alive
-      } else if (!drop) fused_fwd_epilogue<false, true>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+      if (!drop) fused_fwd_epilogue<false, true>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
       else if (even) fused_fwd_epilogue<true, true>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
       else fused_fwd_epilogue<true, false>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
     }
-    {  // zero the k-padding of the next layer's input (columns [next_in, roundup16(next_in)))
-      const int nin = L.x0_col >= 0 ? L.x0_col + p.W0 : L.out_dim;
-      const int zc = ((nin + 15) & ~15) - nin;
-      for (int i = tid; i < FROWS * zc; i += 256) S[(i / zc) * FLD + nin + (i % zc)] = 0.f;
-    }
+    fused_zero_pad(S, L.x0_col >= 0 ? L.x0_col + p.W0 : L.out_dim);
     __syncthreads();
 #ifdef DSDF_LAB
     if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 3 + 3 * l] = __builtin_amdgcn_s_memtime();
 #endif
   }
 
-  // last layer: 8 rows per wave, a row's `in_last` (<= 512) floats spread over the 64 lanes as two float4 chunks
+  // last layer: 16 rows per wave, a row's `in_last` (<= 512) floats spread over the 64 lanes as two float4 chunks
   float4 qv[2];
 #pragma unroll
   for (int cc = 0; cc < 2; ++cc) {
@@ -263,8 +261,8 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(const FusedFwdArg
     qv[cc] = c < p.in_last ? *reinterpret_cast<const float4*>(p.w_last + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const float blast = p.b_last[0];
-  for (int rr = 0; rr < 8; ++rr) {
-    const int row = 8 * w + rr;
+  for (int rr = 0; rr < FROWS / 4; ++rr) {
+    const int row = (FROWS / 4) * w + rr;
     float dot = 0.f;
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
