@@ -163,6 +163,9 @@ struct Plan {
   long long slab;
   size_t u_off, y_off, dp_off[2], dzA_off, dzB_off, slab_off, colsum_off, part_off, part2_off, partdb_off,
       partloss_off, segpart_off, segnorm_off, regloss_off, gnorm_off, total;
+  // fused backward: per hidden layer l a global dP_l buffer, the forward's mask bits and per-workgroup column sums
+  size_t dpl_off[DSDF_MAX_LAYERS], mask_off[DSDF_MAX_LAYERS], cs_off[DSDF_MAX_LAYERS];
+  int nwg;
 };
 
 Plan make_plan(const DsdfNet* n, int64_t N, int64_t R, bool inference) {
@@ -224,6 +227,12 @@ Plan make_plan(const DsdfNet* n, int64_t N, int64_t R, bool inference) {
   P.segnorm_off = take((size_t)(R > 0 ? R : 1) * 4);
   P.regloss_off = take(256);
   P.gnorm_off = take(1024 * 4);
+  P.nwg = (int)((N + FROWS - 1) / FROWS);
+  for (int l = 0; l < P.nl - 1; ++l) {
+    P.dpl_off[l] = take((size_t)N * maxw * 4 + 4096);
+    P.mask_off[l] = take((size_t)P.nwg * 256 * 16);
+    P.cs_off[l] = take((size_t)P.nwg * P.ldcs * 4);
+  }
   P.total = o;
   return P;
 }
@@ -307,7 +316,7 @@ int materialize(const DsdfNet* net, const float* params, float* packed, hipStrea
     y.row0 = rows; y.tile0 = tiles; y.tcols = (y.in + 31) / 32;
     const bool last = l == net->n_layers - 1;
     y.Wf = last ? nullptr : packed + pk.wf_off[l];
-    y.WTf = (last || l == 0) ? nullptr : packed + pk.wtf_off[l];
+    y.WTf = last ? nullptr : packed + pk.wtf_off[l];
     y.Uf = pk.uf[l]; y.UTf = pk.utf[l];
     rows += y.out;
     tiles += ((y.out + 31) / 32) * y.tcols;
@@ -377,6 +386,7 @@ int run_fused_forward(const DsdfNet* net, const Plan& P, void* ws, const float* 
       y.drop_thr = (uint32_t)thr; y.drop_key = keys[l]; y.drop_scale = 1.0f / (1.0f - net->dropout_p);
     }
     y.x0_col = ((net->skip_mask >> (l + 1)) & 1) ? net->out_dim[l] : -1;
+    y.maskbits = store_act ? at<uint32_t>(ws, P.mask_off[l]) : nullptr;
   }
   a.w_last = packed + pk.w_off[last]; a.b_last = params + L.bias_off[last]; a.in_last = net->in_dim[last];
   a.use_tanh = net->use_tanh; a.y_out = y_out; a.u_out = u_out;
@@ -512,6 +522,88 @@ int run_backward(const DsdfNet* net, const Plan& P, void* ws, const float* packe
   return 0;
 }
 
+// Backward with the fused dX chain (fused.hpp): K3's second stage + last layer finalize, ONE launch for the whole
+// dX chain (writes every dP_l, column sums, latent-gradient inputs), then dW (split-K) + finalize per layer.
+int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float* packed, const float* params, int64_t n,
+                       int training, float* grads, int accumulate, int ncols_dz, bool* used_dzB, hipStream_t st) {
+  DsdfParamLayout L;
+  param_layout(net, &L);
+  const Packed pk = packed_layout(net);
+  const int nl = net->n_layers, last = nl - 1;
+  {
+    const int w = P.ld_part;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((w + 63) / 64, LAST_GROUPS), dim3(256), 0, st,
+                       at<float>(ws, P.part_off), P.last_blocks, P.ld_part, w, at<float>(ws, P.part2_off), LAST_GROUPS);
+    LAUNCH_OK("reduce_rows_kernel");
+    FinArgs f;
+    memset(&f, 0, sizeof(f));
+    f.slabs = at<float>(ws, P.part2_off); f.nsplit = LAST_GROUPS; f.slab = P.ld_part; f.ldc = P.ld_part;
+    f.colsum = at<float>(ws, P.partdb_off); f.npart = P.last_blocks; f.ldcs = 1;
+    f.g = L.g_off[last] >= 0 ? params + L.g_off[last] : nullptr;
+    f.v = params + L.v_off[last];
+    f.dg = L.g_off[last] >= 0 ? grads + L.g_off[last] : nullptr;
+    f.dv = grads + L.v_off[last];
+    f.db = grads + L.bias_off[last];
+    f.out = 1; f.in = net->in_dim[last]; f.accumulate = accumulate;
+    hipLaunchKernelGGL(finalize_layer_kernel, dim3(1), dim3(256), 0, st, f);
+    LAUNCH_OK("finalize_layer_kernel(last)");
+  }
+  *used_dzB = false;
+  FusedBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.N = (int)n;
+  a.dp_in = at<float>(ws, P.dpl_off[last - 1]); a.ld_in = P.ld_dp; a.w_in = net->out_dim[last - 1];
+  int cnt = 0;
+  double wmac = 0;
+  for (int l = last - 1; l >= 0; --l) {
+    if (l == 0 && ncols_dz <= 0) break;
+    FusedBwdLayer& y = a.ly[cnt++];
+    y.wtf = packed + pk.wtf_off[l]; y.U = pk.utf[l]; y.K = net->out_dim[l];
+    if (l > 0) {
+      const bool skip = (net->skip_mask >> l) & 1;
+      y.mask_cols = net->out_dim[l - 1];
+      y.mask_scale = mask_scale_of(net, l - 1, training);
+      y.maskbits = at<uint32_t>(ws, P.mask_off[l - 1]);
+      y.dp_out = at<float>(ws, P.dpl_off[l - 1]); y.ld_dp = P.ld_dp;
+      y.colsum = at<float>(ws, P.cs_off[l - 1]); y.ldcs = P.ldcs;
+      if (skip && ncols_dz > 0) { y.dz_out = at<float>(ws, P.dzB_off); y.ldz = P.ldz; y.dz_cols = ncols_dz; *used_dzB = true; }
+      y.ncols = y.mask_cols + y.dz_cols;
+    } else {
+      y.mask_cols = 0; y.mask_scale = 1.f;
+      y.dz_out = at<float>(ws, P.dzA_off); y.ldz = P.ldz; y.dz_cols = ncols_dz; y.ncols = ncols_dz;
+    }
+    wmac += (double)y.K * y.ncols;
+  }
+  a.n_layers = cnt;
+  if (cnt > 0) {
+    ProfScope ps(DSDF_PROF_FUSED_BWD, 2.0 * (double)n * wmac, st);
+    hipLaunchKernelGGL(fused_backward_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, a);
+    LAUNCH_OK("fused_backward_kernel");
+  }
+  for (int l = last - 1; l >= 0; --l) {
+    TnArgs t;
+    memset(&t, 0, sizeof(t));
+    t.A = at<float>(ws, P.dpl_off[l]); t.lda = P.ld_dp; t.B = at<float>(ws, P.in_off[l]); t.ldb = P.ld_in[l];
+    t.C = at<float>(ws, P.slab_off); t.ldc = P.ld_in[l]; t.M = net->out_dim[l]; t.N = net->in_dim[l]; t.K = (int)n;
+    t.kchunk = P.kchunk; t.slab = P.slab;
+    TRY(launch_tn(t, P.nsplit, st));
+    FinArgs f;
+    memset(&f, 0, sizeof(f));
+    f.slabs = t.C; f.nsplit = P.nsplit; f.slab = P.slab; f.ldc = t.ldc;
+    if (l == last - 1) { f.colsum = at<float>(ws, P.part2_off) + P.ld_in[last]; f.npart = LAST_GROUPS; f.ldcs = P.ld_part; }
+    else { f.colsum = at<float>(ws, P.cs_off[l]); f.npart = P.nwg; f.ldcs = P.ldcs; }
+    f.g = L.g_off[l] >= 0 ? params + L.g_off[l] : nullptr;
+    f.v = params + L.v_off[l];
+    f.dg = L.g_off[l] >= 0 ? grads + L.g_off[l] : nullptr;
+    f.dv = grads + L.v_off[l];
+    f.db = grads + L.bias_off[l];
+    f.out = net->out_dim[l]; f.in = net->in_dim[l]; f.accumulate = accumulate;
+    hipLaunchKernelGGL(finalize_layer_kernel, dim3(f.out), dim3(256), 0, st, f);
+    LAUNCH_OK("finalize_layer_kernel");
+  }
+  return 0;
+}
+
 int check_common(const DsdfNet* net, const void* packed, const void* params, const void* ws) {
   TRY(validate(net));
   if (!packed || !params || !ws) return fail(DSDF_E_INVALID, "NULL packed/params/workspace pointer");
@@ -634,13 +726,16 @@ int dsdf_module_backward(const DsdfNet* net, const float* packed, const float* p
   a.a = at<float>(ws, P.in_off[last]); a.lda = P.ld_in[last]; a.in = net->in_dim[last];
   a.w = packed + pk.w_off[last]; a.b = params + L.bias_off[last]; a.n = (int)n; a.use_tanh = net->use_tanh;
   a.d_sdf = d_sdf; a.u_in = at<float>(ws, P.u_off);
-  a.dp_prev = at<float>(ws, P.dp_off[0]); a.lddp = P.ld_dp; a.mask_scale = mask_scale_of(net, last - 1, training);
+  const bool fusedb = fused_enabled() && fused_eligible(net);
+  a.dp_prev = fusedb ? at<float>(ws, P.dpl_off[last - 1]) : at<float>(ws, P.dp_off[0]);
+  a.lddp = P.ld_dp; a.mask_scale = mask_scale_of(net, last - 1, training);
   a.part_dw = at<float>(ws, P.part_off); a.ld_part = P.ld_part;
   a.part_colsum = at<float>(ws, P.part_off) + P.ld_in[last];
   a.part_db = at<float>(ws, P.partdb_off); a.part_loss = at<float>(ws, P.partloss_off);
   TRY(launch_last<LAST_BWD_EXT>(a, P.last_blocks, st));
   bool used_dzB = false;
-  TRY(run_backward(net, P, ws, packed, params, n, training, grads, accumulate, d_input ? P.W0 : 0, &used_dzB, st));
+  if (fusedb) TRY(run_backward_fused(net, P, ws, packed, params, n, training, grads, accumulate, d_input ? P.W0 : 0, &used_dzB, st));
+  else TRY(run_backward(net, P, ws, packed, params, n, training, grads, accumulate, d_input ? P.W0 : 0, &used_dzB, st));
   if (d_input) {
     const long long tot = (long long)n * P.W0;
     hipLaunchKernelGGL(add2_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, at<float>(ws, P.dzA_off), P.ldz,
@@ -687,14 +782,17 @@ int dsdf_train_forward_backward(const DsdfNet* net, const float* packed, const f
   a.a = at<float>(ws, P.in_off[last]); a.lda = P.ld_in[last]; a.in = net->in_dim[last];
   a.w = packed + pk.w_off[last]; a.b = params + L.bias_off[last]; a.n = (int)n; a.use_tanh = net->use_tanh;
   a.y_out = sdf_out; a.gt = b->sdf_gt; a.delta = cfg->clamp_dist; a.inv_n = 1.0f / (float)b->n_norm;
-  a.dp_prev = at<float>(ws, P.dp_off[0]); a.lddp = P.ld_dp; a.mask_scale = mask_scale_of(net, last - 1, cfg->training);
+  const bool fusedb = fused_enabled() && fused_eligible(net);
+  a.dp_prev = fusedb ? at<float>(ws, P.dpl_off[last - 1]) : at<float>(ws, P.dp_off[0]);
+  a.lddp = P.ld_dp; a.mask_scale = mask_scale_of(net, last - 1, cfg->training);
   a.part_dw = at<float>(ws, P.part_off); a.ld_part = P.ld_part;
   a.part_colsum = at<float>(ws, P.part_off) + P.ld_in[last];
   a.part_db = at<float>(ws, P.partdb_off); a.part_loss = at<float>(ws, P.partloss_off);
   TRY(launch_last<LAST_TRAIN>(a, P.last_blocks, st));
 
   bool used_dzB = false;
-  TRY(run_backward(net, P, ws, packed, params, n, cfg->training, grads, accumulate, Lc, &used_dzB, st));
+  if (fusedb) TRY(run_backward_fused(net, P, ws, packed, params, n, cfg->training, grads, accumulate, Lc, &used_dzB, st));
+  else TRY(run_backward(net, P, ws, packed, params, n, cfg->training, grads, accumulate, Lc, &used_dzB, st));
 
   SegArgs s;
   memset(&s, 0, sizeof(s));

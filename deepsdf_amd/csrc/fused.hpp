@@ -33,6 +33,7 @@ struct FusedLayer {
   int in, out_dim, U;              // K, N, k-units allocated per n-tile in wf
   uint32_t drop_key, drop_thr; float drop_scale;
   int x0_col;                      // >= 0: after this layer, columns [x0_col, x0_col + W0) of the slab are refilled with x0
+  uint32_t* maskbits;              // [n_wg][256 threads][4]: bit (32 m + 16 (ni&1) + reg) of word 2m + (ni>>1) = output > 0; or nullptr
 };
 
 struct FusedFwdArgs {
@@ -94,6 +95,7 @@ __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[2][4], co
       L.out != nullptr ? (void*)(L.out + (size_t)row0 * L.ld_out) : (void*)S, 0,
       L.out != nullptr ? rows_here * L.ld_out * 4 : 0, 0x00020000);
   const int ldb = L.ld_out * 4;   // bytes per global row (wave-uniform)
+  uint32_t mq[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
     const int col = 32 * (w + 4 * ni) + fr;
@@ -101,6 +103,7 @@ __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[2][4], co
     const uint32_t voff = cok ? (uint32_t)((4 * fh) * ldb + col * 4) : 0x7FFFFFFFu;
     float* sp = S + (4 * fh) * FLD + col;
     const float bv = biasv[ni];
+    uint32_t mb[2] = {0u, 0u};   // this n-tile's keep bits for m = 0, 1
     uint32_t ck = 0, pm = 0;
     if constexpr (DROP) {
       ck = drop_col_key((uint32_t)col, L.drop_key);
@@ -129,10 +132,16 @@ __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[2][4], co
           sp[(rc + 1) * FLD] = v1;
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rsrc, voff, rc * ldb, 0);
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rsrc, voff, (rc + 1) * ldb, 0);
+          mb[m] |= (v0 > 0.f ? 1u : 0u) << (2 * rp);
+          mb[m] |= (v1 > 0.f ? 1u : 0u) << (2 * rp + 1);
         }
       }
     }
+    mq[0 + (ni >> 1)] |= mb[0] << (16 * (ni & 1));
+    mq[2 + (ni >> 1)] |= mb[1] << (16 * (ni & 1));
   }
+  if (L.maskbits != nullptr)
+    *reinterpret_cast<uint4*>(L.maskbits + ((size_t)blockIdx.x * 256 + threadIdx.x) * 4) = make_uint4(mq[0], mq[1], mq[2], mq[3]);
 }
 
 // The shared k-loop: acc[m][ni] += S[64 rows][K] * Bf[n-tiles of this wave][K]; NACT = existing n-tiles of this wave.
@@ -278,6 +287,111 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(const FusedFwdArg
       if (p.y_out) p.y_out[row0 + row] = tanhf(t1);
       if (p.u_out) p.u_out[row0 + row] = u;
     }
+  }
+}
+
+// ===================================================================================================================
+// Fused backward dX chain.  Slab = dP_l [64][out_l]; per layer l = last-1 .. 1:
+//   dP_{l-1}[:, c] = (dP_l W_l)[:, c] * [a_l[:, c] > 0] * scale      c <  mask_cols (= out_{l-1})   -> slab, global dP_{l-1},
+//                                                                                                     column sums (db_{l-1})
+//   dx0_skip[:, c - mask_cols] = (dP_l W_l)[:, c]                      mask_cols <= c < mask_cols + dz_cols (skip layer)
+// and for l = 0 only the latent columns of d/dx0 (no mask).  The ReLU/dropout mask comes from the forward's mask bits
+// (same lane <-> element mapping), so no activation is re-read here.
+struct FusedBwdLayer {
+  const float* wtf; int U;         // fragment-ordered W^T (n = in index, k = out index)
+  int K;                           // out_l
+  int ncols;                       // output columns to compute (mask_cols + dz_cols)
+  int mask_cols; float mask_scale; const uint32_t* maskbits;
+  float* dp_out; int ld_dp;        // global dP_{l-1} [N][ld_dp] (read later by the dW kernel)
+  float* colsum; int ldcs;         // [n_wg][ldcs] per-workgroup column sums of dP_{l-1}
+  float* dz_out; int ldz; int dz_cols;
+};
+struct FusedBwdArgs {
+  int n_layers, N;                 // entries of ly[], processed in order (deepest layer first)
+  const float* dp_in; int ld_in; int w_in;   // dP of the deepest hidden layer [N][ld_in], w_in columns
+  FusedBwdLayer ly[DSDF_MAX_LAYERS];
+};
+
+__device__ __forceinline__ void fused_bwd_epilogue(const f32x16 (&acc)[2][4], float* S, const FusedBwdLayer& L, int w, int fr,
+                                                   int fh, int row0, int N, const uint4 mq) {
+  const int rows_here = min(FROWS, N - row0);
+  __amdgpu_buffer_rsrc_t rdp = __builtin_amdgcn_make_buffer_rsrc(
+      L.dp_out != nullptr ? (void*)(L.dp_out + (size_t)row0 * L.ld_dp) : (void*)S, 0,
+      L.dp_out != nullptr ? rows_here * L.ld_dp * 4 : 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t rdz = __builtin_amdgcn_make_buffer_rsrc(
+      L.dz_out != nullptr ? (void*)(L.dz_out + (size_t)row0 * L.ldz) : (void*)S, 0,
+      L.dz_out != nullptr ? rows_here * L.ldz * 4 : 0, 0x00020000);
+  const int ldb = L.ld_dp * 4, ldzb = L.ldz * 4;
+  const uint32_t mw[4] = {mq.x, mq.y, mq.z, mq.w};
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int col = 32 * (w + 4 * ni) + fr;
+    float cs = 0.f;
+    if (col < L.mask_cols) {
+      const uint32_t voff = (uint32_t)((4 * fh) * ldb + col * 4);
+      float* sp = S + (4 * fh) * FLD + col;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const uint32_t bits = mw[2 * m + (ni >> 1)] >> (16 * (ni & 1));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rc = 32 * m + crow(r);
+          const float v = ((bits >> r) & 1u) ? acc[m][ni][r] * L.mask_scale : 0.f;
+          sp[rc * FLD] = v;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rdp, voff, rc * ldb, 0);
+          cs += v;
+        }
+      }
+    } else if (col - L.mask_cols < L.dz_cols) {
+      const uint32_t voff = (uint32_t)((4 * fh) * ldzb + (col - L.mask_cols) * 4);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][ni][r]), rdz, voff, (32 * m + crow(r)) * ldzb, 0);
+    }
+    if (L.colsum != nullptr) {   // rows >= N contribute exact zeros (their dP rows were loaded as zeros)
+      cs += __shfl_xor(cs, 32, 64);
+      if (fh == 0 && col < L.mask_cols) L.colsum[(size_t)blockIdx.x * L.ldcs + col] = cs;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void fused_backward_kernel(const FusedBwdArgs p) {
+  __shared__ __attribute__((aligned(16))) float S[FROWS * FLD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int row0 = blockIdx.x * FROWS;
+
+  fused_load_x0(S, p.dp_in, p.ld_in, p.w_in, row0, p.N, 0);
+  fused_zero_pad(S, p.w_in);
+  __syncthreads();
+
+  for (int i = 0; i < p.n_layers; ++i) {
+    const FusedBwdLayer& L = p.ly[i];
+    const int nu = (L.K + 15) >> 4;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][ni][r] = 0.f;
+    const float* bp[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) bp[ni] = L.wtf + (size_t)(w + 4 * ni) * L.U * 512 + lane * 4;
+    const float* ap = S + fr * FLD + 8 * fh;
+    uint4 mq = make_uint4(0u, 0u, 0u, 0u);
+    if (L.maskbits != nullptr) mq = *reinterpret_cast<const uint4*>(L.maskbits + ((size_t)blockIdx.x * 256 + tid) * 4);
+    {
+      const int ntl = (L.ncols + 31) >> 5;
+      const int nact = ntl > w ? min(4, (ntl - w + 3) >> 2) : 0;
+      fused_kloop_dispatch(acc, ap, bp, nu, nact);
+    }
+    __syncthreads();
+    fused_bwd_epilogue(acc, S, L, w, fr, fh, row0, p.N, mq);
+    fused_zero_pad(S, L.mask_cols);
+    __syncthreads();
   }
 }
 
