@@ -10,6 +10,7 @@
 
 #include <stdlib.h>
 
+#include "dwstream.hpp"
 #include "fused.hpp"
 #include "gemm.hpp"
 #include "kernels.hpp"
@@ -154,6 +155,58 @@ void param_layout(const DsdfNet* n, DsdfParamLayout* L) {
   L->total = o;
 }
 
+// ---- dW work schedule (dwstream.hpp): (layer, K-split, 128x128 tile) items, ~one per wave of the chip ------------
+struct DwSched {
+  int tiles[DSDF_MAX_LAYERS], tiles_n[DSDF_MAX_LAYERS], nsplit[DSDF_MAX_LAYERS], kchunk[DSDF_MAX_LAYERS], item0[DSDF_MAX_LAYERS];
+  long long slab[DSDF_MAX_LAYERS];
+  int n_items;
+};
+int chip_waves() {
+  static int waves = 0;
+  if (waves == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+      waves = 4 * cus;
+    else
+      waves = 4 * 256;   // MI355X
+  }
+  return waves;
+}
+DwSched dw_schedule(const DsdfNet* n, int64_t N, const int* ld_in) {
+  DwSched S;
+  memset(&S, 0, sizeof(S));
+  const int nh = n->n_layers - 1;
+  int T = 0;
+  for (int l = 0; l < nh; ++l) {
+    S.tiles_n[l] = (n->in_dim[l] + 127) / 128;
+    S.tiles[l] = ((n->out_dim[l] + 127) / 128) * S.tiles_n[l];
+    S.slab[l] = rup((int64_t)n->out_dim[l] * ld_in[l], 64);
+    T += S.tiles[l];
+  }
+  const int W = chip_waves();
+  const int base = W / T > 0 ? W / T : 1;
+  int rem = W - base * T;
+  int maxsplit = (int)(N / 64);
+  if (maxsplit < 1) maxsplit = 1;
+  for (int l = 0; l < nh; ++l) S.nsplit[l] = base;
+  for (int pass = 0; pass < 2 && rem > 0; ++pass)          // hand the left-over waves to the layers with most tiles first
+    for (int l = 0; l < nh; ++l) {
+      const bool big = S.tiles[l] * nh >= T;   // at least the average tile count
+      if ((pass == 0) == big && rem >= S.tiles[l]) { S.nsplit[l]++; rem -= S.tiles[l]; }
+    }
+  int items = 0;
+  for (int l = 0; l < nh; ++l) {
+    if (S.nsplit[l] > maxsplit) S.nsplit[l] = maxsplit;
+    S.kchunk[l] = (int)rup((N + S.nsplit[l] - 1) / S.nsplit[l], 2);
+    S.nsplit[l] = (int)((N + S.kchunk[l] - 1) / S.kchunk[l]);
+    S.item0[l] = items;
+    items += S.nsplit[l] * S.tiles[l];
+  }
+  S.n_items = items;
+  return S;
+}
+
 // ---- workspace plan -----------------------------------------------------------------------------
 struct Plan {
   int nl, W0, N, R;
@@ -164,8 +217,9 @@ struct Plan {
   size_t u_off, y_off, dp_off[2], dzA_off, dzB_off, slab_off, colsum_off, part_off, part2_off, partdb_off,
       partloss_off, segpart_off, segnorm_off, regloss_off, gnorm_off, total;
   // fused backward: per hidden layer l a global dP_l buffer, the forward's mask bits and per-workgroup column sums
-  size_t dpl_off[DSDF_MAX_LAYERS], mask_off[DSDF_MAX_LAYERS], cs_off[DSDF_MAX_LAYERS];
+  size_t dpl_off[DSDF_MAX_LAYERS], mask_off[DSDF_MAX_LAYERS], cs_off[DSDF_MAX_LAYERS], dwslab_off[DSDF_MAX_LAYERS];
   int nwg;
+  DwSched dw;
 };
 
 Plan make_plan(const DsdfNet* n, int64_t N, int64_t R, bool inference) {
@@ -188,7 +242,7 @@ Plan make_plan(const DsdfNet* n, int64_t N, int64_t R, bool inference) {
     P.total = o;
     return P;
   }
-  for (int l = 0; l < P.nl; ++l) P.in_off[l] = take((size_t)N * P.ld_in[l] * 4);
+  for (int l = 0; l < P.nl; ++l) P.in_off[l] = take((size_t)N * P.ld_in[l] * 4 + 4096);   // + slack: edge tiles of dw_stream over-read
   P.u_off = take((size_t)N * 4);
   P.y_off = take((size_t)N * 4);
   P.ld_dp = maxw;
@@ -233,6 +287,8 @@ Plan make_plan(const DsdfNet* n, int64_t N, int64_t R, bool inference) {
     P.mask_off[l] = take((size_t)P.nwg * 256 * 16);
     P.cs_off[l] = take((size_t)P.nwg * P.ldcs * 4);
   }
+  P.dw = dw_schedule(n, N, P.ld_in);
+  for (int l = 0; l < P.nl - 1; ++l) P.dwslab_off[l] = take((size_t)P.dw.nsplit[l] * P.dw.slab[l] * 4);
   P.total = o;
   return P;
 }
@@ -580,16 +636,31 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     hipLaunchKernelGGL(fused_backward_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, a);
     LAUNCH_OK("fused_backward_kernel");
   }
+  {   // all dW_l = dP_l^T a_l in one launch
+    DwArgs d;
+    memset(&d, 0, sizeof(d));
+    d.n_layers = last; d.n_items = P.dw.n_items; d.N = (int)n;
+    double fl = 0;
+    for (int l = 0; l < last; ++l) {
+      DwLayer& y = d.ly[l];
+      y.dp = at<float>(ws, P.dpl_off[l]); y.ld_dp = P.ld_dp;
+      y.act = at<float>(ws, P.in_off[l]); y.ld_act = P.ld_in[l];
+      y.slabs = at<float>(ws, P.dwslab_off[l]); y.slab = P.dw.slab[l];
+      y.M = net->out_dim[l]; y.Nc = net->in_dim[l]; y.ldc = P.ld_in[l];
+      y.tiles_n = P.dw.tiles_n[l]; y.tiles = P.dw.tiles[l]; y.nsplit = P.dw.nsplit[l]; y.kchunk = P.dw.kchunk[l];
+      y.item0 = P.dw.item0[l];
+      fl += 2.0 * (double)n * y.M * y.Nc;
+    }
+    int grid = (d.n_items + 3) / 4;
+    if (grid > chip_waves() / 4) grid = chip_waves() / 4;
+    ProfScope ps(DSDF_PROF_GEMM_TN, fl, st);
+    hipLaunchKernelGGL(dw_stream_kernel, dim3(grid), dim3(256), 0, st, d);
+    LAUNCH_OK("dw_stream_kernel");
+  }
   for (int l = last - 1; l >= 0; --l) {
-    TnArgs t;
-    memset(&t, 0, sizeof(t));
-    t.A = at<float>(ws, P.dpl_off[l]); t.lda = P.ld_dp; t.B = at<float>(ws, P.in_off[l]); t.ldb = P.ld_in[l];
-    t.C = at<float>(ws, P.slab_off); t.ldc = P.ld_in[l]; t.M = net->out_dim[l]; t.N = net->in_dim[l]; t.K = (int)n;
-    t.kchunk = P.kchunk; t.slab = P.slab;
-    TRY(launch_tn(t, P.nsplit, st));
     FinArgs f;
     memset(&f, 0, sizeof(f));
-    f.slabs = t.C; f.nsplit = P.nsplit; f.slab = P.slab; f.ldc = t.ldc;
+    f.slabs = at<float>(ws, P.dwslab_off[l]); f.nsplit = P.dw.nsplit[l]; f.slab = P.dw.slab[l]; f.ldc = P.ld_in[l];
     if (l == last - 1) { f.colsum = at<float>(ws, P.part2_off) + P.ld_in[last]; f.npart = LAST_GROUPS; f.ldcs = P.ld_part; }
     else { f.colsum = at<float>(ws, P.cs_off[l]); f.npart = P.nwg; f.ldcs = P.ldcs; }
     f.g = L.g_off[l] >= 0 ? params + L.g_off[l] : nullptr;
