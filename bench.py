@@ -113,7 +113,7 @@ def main():
         b = batches[i % len(batches)]
         eng.train_forward_backward(lat, dlat, b["seg_scene"], b["seg_offset"], b["xyz"], b["gt"], n_norm=n_global,
                                    clamp_dist=0.1, reg_coef=1e-4 * min(1, 1 / 100), code_bound=1.0, training=True,
-                                   seed=rank, row_offset=0)
+                                   seed=rank, row_offset=0, seg_len=SAMPLES)
         dist.allreduce_sum_(eng.grads)
         eng.adam_step(lat, dlat, lat_m, lat_v, 5e-4, 1e-3)
 

@@ -6,7 +6,7 @@ import os
 from .build import LIB
 
 MAX_LAYERS = 16
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class DsdfNet(C.Structure):
@@ -24,7 +24,7 @@ class DsdfParamLayout(C.Structure):
 class DsdfBatch(C.Structure):
     _fields_ = [("seg_scene", C.c_void_p), ("seg_offset", C.c_void_p), ("n_segments", C.c_int64),
                 ("xyz", C.c_void_p), ("sdf_gt", C.c_void_p), ("n_points", C.c_int64), ("n_norm", C.c_int64),
-                ("row_offset", C.c_int64)]
+                ("row_offset", C.c_int64), ("seg_len", C.c_int64)]
 
 
 class DsdfLossCfg(C.Structure):

@@ -591,18 +591,6 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((w + 63) / 64, LAST_GROUPS), dim3(256), 0, st,
                        at<float>(ws, P.part_off), P.last_blocks, P.ld_part, w, at<float>(ws, P.part2_off), LAST_GROUPS);
     LAUNCH_OK("reduce_rows_kernel");
-    FinArgs f;
-    memset(&f, 0, sizeof(f));
-    f.slabs = at<float>(ws, P.part2_off); f.nsplit = LAST_GROUPS; f.slab = P.ld_part; f.ldc = P.ld_part;
-    f.colsum = at<float>(ws, P.partdb_off); f.npart = P.last_blocks; f.ldcs = 1;
-    f.g = L.g_off[last] >= 0 ? params + L.g_off[last] : nullptr;
-    f.v = params + L.v_off[last];
-    f.dg = L.g_off[last] >= 0 ? grads + L.g_off[last] : nullptr;
-    f.dv = grads + L.v_off[last];
-    f.db = grads + L.bias_off[last];
-    f.out = 1; f.in = net->in_dim[last]; f.accumulate = accumulate;
-    hipLaunchKernelGGL(finalize_layer_kernel, dim3(1), dim3(256), 0, st, f);
-    LAUNCH_OK("finalize_layer_kernel(last)");
   }
   *used_dzB = false;
   FusedBwdArgs a;
@@ -657,20 +645,33 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     hipLaunchKernelGGL(dw_stream_kernel, dim3(grid), dim3(256), 0, st, d);
     LAUNCH_OK("dw_stream_kernel");
   }
-  for (int l = last - 1; l >= 0; --l) {
-    FinArgs f;
-    memset(&f, 0, sizeof(f));
-    f.slabs = at<float>(ws, P.dwslab_off[l]); f.nsplit = P.dw.nsplit[l]; f.slab = P.dw.slab[l]; f.ldc = P.ld_in[l];
-    if (l == last - 1) { f.colsum = at<float>(ws, P.part2_off) + P.ld_in[last]; f.npart = LAST_GROUPS; f.ldcs = P.ld_part; }
-    else { f.colsum = at<float>(ws, P.cs_off[l]); f.npart = P.nwg; f.ldcs = P.ldcs; }
-    f.g = L.g_off[l] >= 0 ? params + L.g_off[l] : nullptr;
-    f.v = params + L.v_off[l];
-    f.dg = L.g_off[l] >= 0 ? grads + L.g_off[l] : nullptr;
-    f.dv = grads + L.v_off[l];
-    f.db = grads + L.bias_off[l];
-    f.out = net->out_dim[l]; f.in = net->in_dim[l]; f.accumulate = accumulate;
-    hipLaunchKernelGGL(finalize_layer_kernel, dim3(f.out), dim3(256), 0, st, f);
-    LAUNCH_OK("finalize_layer_kernel");
+  {   // split-K sums, weight-norm backward and bias gradients of ALL layers (last layer included) in one launch
+    FinAll fa;
+    memset(&fa, 0, sizeof(fa));
+    int rows = 0;
+    for (int l = last; l >= 0; --l) {
+      FinArgs& f = fa.f[fa.n];
+      if (l == last) {
+        f.slabs = at<float>(ws, P.part2_off); f.nsplit = LAST_GROUPS; f.slab = P.ld_part; f.ldc = P.ld_part;
+        f.colsum = at<float>(ws, P.partdb_off); f.npart = P.last_blocks; f.ldcs = 1;
+      } else {
+        f.slabs = at<float>(ws, P.dwslab_off[l]); f.nsplit = P.dw.nsplit[l]; f.slab = P.dw.slab[l]; f.ldc = P.ld_in[l];
+        if (l == last - 1) { f.colsum = at<float>(ws, P.part2_off) + P.ld_in[last]; f.npart = LAST_GROUPS; f.ldcs = P.ld_part; }
+        else { f.colsum = at<float>(ws, P.cs_off[l]); f.npart = P.nwg; f.ldcs = P.ldcs; }
+      }
+      f.g = L.g_off[l] >= 0 ? params + L.g_off[l] : nullptr;
+      f.v = params + L.v_off[l];
+      f.dg = L.g_off[l] >= 0 ? grads + L.g_off[l] : nullptr;
+      f.dv = grads + L.v_off[l];
+      f.db = grads + L.bias_off[l];
+      f.out = net->out_dim[l]; f.in = net->in_dim[l]; f.accumulate = accumulate;
+      fa.row0[fa.n] = rows;
+      rows += f.out;
+      ++fa.n;
+    }
+    fa.row0[fa.n] = rows;
+    hipLaunchKernelGGL(finalize_all_kernel, dim3(rows), dim3(256), 0, st, fa);
+    LAUNCH_OK("finalize_all_kernel");
   }
   return 0;
 }
@@ -862,7 +863,13 @@ int dsdf_train_forward_backward(const DsdfNet* net, const float* packed, const f
   TRY(launch_last<LAST_TRAIN>(a, P.last_blocks, st));
 
   bool used_dzB = false;
-  if (fusedb) TRY(run_backward_fused(net, P, ws, packed, params, n, cfg->training, grads, accumulate, Lc, &used_dzB, st));
+  // segment-sum latent gradient: every segment is a whole number of 64-row workgroups
+  int skip_l = -1;
+  for (int l = 1; l < net->n_layers - 1; ++l)
+    if ((net->skip_mask >> l) & 1) skip_l = l;
+  const bool segsum = fusedb && b->seg_len > 0 && b->seg_len % FROWS == 0 && b->seg_len * R == n && net->n_layers > 2 &&
+                      skip_l != net->n_layers - 2;   // the deepest hidden layer's dP column sums live in K3's partials
+  if (fusedb) TRY(run_backward_fused(net, P, ws, packed, params, n, cfg->training, grads, accumulate, segsum ? 0 : Lc, &used_dzB, st));
   else TRY(run_backward(net, P, ws, packed, params, n, cfg->training, grads, accumulate, Lc, &used_dzB, st));
 
   SegArgs s;
@@ -870,8 +877,25 @@ int dsdf_train_forward_backward(const DsdfNet* net, const float* packed, const f
   s.dzA = at<float>(ws, P.dzA_off); s.dzB = used_dzB ? at<float>(ws, P.dzB_off) : nullptr; s.ldz = P.ldz;
   s.seg_scene = b->seg_scene; s.seg_offset = b->seg_offset; s.R = (int)R; s.L = Lc; s.table = latent_table;
   s.segpart = at<float>(ws, P.segpart_off); s.segnorm = at<float>(ws, P.segnorm_off);
-  hipLaunchKernelGGL(seg_reduce_kernel, dim3((unsigned)R, (Lc + 63) / 64), dim3(256), 0, st, s);
-  LAUNCH_OK("seg_reduce_kernel");
+  if (segsum) {
+    const Packed pk2 = packed_layout(net);
+    const int ks = skip_l;
+    SegLatArgs q;
+    memset(&q, 0, sizeof(q));
+    q.cs0 = at<float>(ws, P.cs_off[0]); q.ldcs = P.ldcs; q.out0 = net->out_dim[0];
+    q.W0 = packed + pk2.w_off[0]; q.ldw0 = pk2.ldw[0];
+    if (ks > 0) {
+      q.csk = at<float>(ws, P.cs_off[ks]); q.outk = net->out_dim[ks];
+      q.Wk = packed + pk2.w_off[ks]; q.ldwk = pk2.ldw[ks]; q.koff = net->out_dim[ks - 1];
+    }
+    q.wg_per_seg = (int)(b->seg_len / FROWS); q.R = (int)R; q.L = Lc;
+    q.seg_scene = b->seg_scene; q.table = latent_table; q.segpart = s.segpart; q.segnorm = s.segnorm;
+    hipLaunchKernelGGL(seg_latgrad_kernel, dim3((unsigned)R, (Lc + 63) / 64), dim3(256), 0, st, q);
+    LAUNCH_OK("seg_latgrad_kernel");
+  } else {
+    hipLaunchKernelGGL(seg_reduce_kernel, dim3((unsigned)R, (Lc + 63) / 64), dim3(256), 0, st, s);
+    LAUNCH_OK("seg_reduce_kernel");
+  }
   if (!accumulate) HIP_OK(hipMemsetAsync(dlat, 0, (size_t)n_scenes * Lc * sizeof(float), st));
   ScatterArgs sc;
   memset(&sc, 0, sizeof(sc));

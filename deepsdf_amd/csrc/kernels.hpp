@@ -6,6 +6,8 @@
 
 namespace dsdf {
 
+constexpr int FSEG_MAXW = 512;   // widest layer of the segment-sum latent-gradient path
+
 // ---------------------------------------------------------------------------------------------------
 // K0a: max-norm renorm of every looked-up latent row, in place (torch embedding_renorm_,
 // train_deep_sdf.py:385,509).  One wave per segment; a segment whose scene already appears in an earlier
@@ -259,9 +261,8 @@ struct FinArgs {
   float* dg; float* dv; float* db;  // gradient arena slices
   int out, in; int accumulate;
 };
-__global__ __launch_bounds__(256) void finalize_layer_kernel(const FinArgs p) {
-  __shared__ float red[4];
-  const int i = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void finalize_row(const FinArgs& p, const int i, float* red) {
+  const int tid = threadIdx.x;
   float dot = 0.f, ss = 0.f;
   constexpr int MAXC = 8;  // in <= 2048
   float dwr[MAXC];
@@ -315,6 +316,20 @@ __global__ __launch_bounds__(256) void finalize_layer_kernel(const FinArgs p) {
   if (tid == 0) p.db[i] = p.accumulate ? p.db[i] + s : s;
 }
 
+__global__ __launch_bounds__(256) void finalize_layer_kernel(const FinArgs p) {
+  __shared__ float red[4];
+  finalize_row(p, blockIdx.x, red);
+}
+
+// every layer in ONE launch: block -> (layer, output row)
+struct FinAll { int n; int row0[DSDF_MAX_LAYERS + 1]; FinArgs f[DSDF_MAX_LAYERS]; };
+__global__ __launch_bounds__(256) void finalize_all_kernel(const FinAll p) {
+  __shared__ float red[4];
+  int l = 0;
+  while (l + 1 < p.n && (int)blockIdx.x >= p.row0[l + 1]) ++l;
+  finalize_row(p.f[l], blockIdx.x - p.row0[l], red);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K5a: per segment r and 64-column chunk: segpart[r][c] = sum over the segment's rows of (dzA + dzB),
 // and (chunk 0) the norm of the segment's latent row for the regulariser.
@@ -348,6 +363,53 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(const SegArgs p) {
     for (int c = tid; c < p.L; c += 64) { const float v = row[c]; ss += v * v; }
     ss = wave_sum(ss);
     if (tid == 0) p.segnorm[r] = sqrtf(ss);
+  }
+}
+
+// K5a': segment-sum path.  Because d/dx0 is linear in dP, the per-scene latent gradient is
+//   sum_{n in segment} (dP_0[n] W_0 + dP_k[n] W_k[:, skip])[:L]  =  (sum_n dP_0[n]) W_0[:, :L] + (sum_n dP_k[n]) W_k[:, off:off+L]
+// and the per-workgroup (64-row) column sums of dP_0 / dP_k already exist (bias-gradient partials of the fused
+// backward).  Valid when every segment is a whole number of 64-row workgroups.  Replaces the per-point d/dx0 GEMM
+// columns and seg_reduce_kernel.  grid (R, ceil(L/64)), block = 64 columns x 4 k-slices.
+struct SegLatArgs {
+  const float* cs0; int ldcs; int out0; const float* W0; int ldw0;        // column sums of dP_0, W_0 [out0][ldw0]
+  const float* csk; int outk; const float* Wk; int ldwk; int koff;        // skip layer (csk may be null)
+  int wg_per_seg; int R; int L;
+  const int64_t* seg_scene; const float* table;
+  float* segpart; float* segnorm;
+};
+__global__ __launch_bounds__(256) void seg_latgrad_kernel(const SegLatArgs p) {
+  __shared__ float ss[2][FSEG_MAXW];
+  __shared__ float red[4][64];
+  const int r = blockIdx.x, c0 = blockIdx.y * 64, tid = threadIdx.x, cx = tid & 63, ks = tid >> 6;
+  for (int j = tid; j < p.out0; j += 256) {
+    float s = 0.f;
+    for (int g = 0; g < p.wg_per_seg; ++g) s += p.cs0[(size_t)(r * p.wg_per_seg + g) * p.ldcs + j];
+    ss[0][j] = s;
+  }
+  if (p.csk != nullptr)
+    for (int j = tid; j < p.outk; j += 256) {
+      float s = 0.f;
+      for (int g = 0; g < p.wg_per_seg; ++g) s += p.csk[(size_t)(r * p.wg_per_seg + g) * p.ldcs + j];
+      ss[1][j] = s;
+    }
+  __syncthreads();
+  const int col = c0 + cx;
+  float acc = 0.f;
+  if (col < p.L) {
+    for (int j = ks; j < p.out0; j += 4) acc += ss[0][j] * p.W0[(size_t)j * p.ldw0 + col];
+    if (p.csk != nullptr)
+      for (int j = ks; j < p.outk; j += 4) acc += ss[1][j] * p.Wk[(size_t)j * p.ldwk + p.koff + col];
+  }
+  red[ks][cx] = acc;
+  __syncthreads();
+  if (ks == 0 && col < p.L) p.segpart[(size_t)r * p.L + col] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+  if (blockIdx.y == 0 && tid < 64) {
+    const float* row = p.table + (size_t)p.seg_scene[r] * p.L;
+    float q = 0.f;
+    for (int c = tid; c < p.L; c += 64) { const float v = row[c]; q += v * v; }
+    q = wave_sum(q);
+    if (tid == 0) p.segnorm[r] = sqrtf(q);
   }
 }
 

@@ -159,13 +159,13 @@ class Engine:
     # ---- training --------------------------------------------------------------------------------------------
     def train_forward_backward(self, latents, dlat, seg_scene, seg_offset, xyz, sdf_gt, *, n_norm, clamp_dist,
                                reg_coef, code_bound, training=True, seed=0, row_offset=0, accumulate=False,
-                               sdf_out=None, step=None):
+                               sdf_out=None, step=None, seg_len=0):
         """One chunk of train_deep_sdf.py:509-533.  Gradients land in self.grads / dlat, loss in self.loss."""
         self._fresh_weights()
         n, R = xyz.shape[0], seg_scene.shape[0]
         ws = self.train_workspace(n, R)
         b = _lib.DsdfBatch(seg_scene.data_ptr(), seg_offset.data_ptr(), R, xyz.data_ptr(), sdf_gt.data_ptr(), n,
-                           int(n_norm), int(row_offset))
+                           int(n_norm), int(row_offset), int(seg_len))
         cfg = _lib.DsdfLossCfg()
         cfg.clamp_dist, cfg.reg_coef = float(clamp_dist), float(reg_coef)
         cfg.code_bound = float(code_bound) if code_bound is not None else -1.0

@@ -214,11 +214,13 @@ class FusedTrainStep:
         """scene_rows [B] (rows of self.lat), xyz [B*S, G], sdf_gt [B*S]; returns nothing (loss in eng.loss)."""
         N = xyz.shape[0]
         n_norm = N if n_norm is None else n_norm
+        uniform = 0
         reg = self.lam * min(1, epoch / 100) if self.code_reg else 0.0
         if batch_split == 1:
             seg_scene = scene_rows
             seg_off = torch.arange(0, N + 1, samples_per_scene, dtype=torch.int64, device=xyz.device)
             chunks = [(seg_scene, seg_off, xyz, sdf_gt)]
+            uniform = samples_per_scene
         else:
             idx = scene_rows.repeat_interleave(samples_per_scene)
             chunks = []
@@ -230,7 +232,7 @@ class FusedTrainStep:
         for ci, (sc, so, xc, gc) in enumerate(chunks):
             self.eng.train_forward_backward(self.lat, self.dlat, sc, so, xc, gc, n_norm=n_norm, clamp_dist=self.clamp_dist,
                                             reg_coef=reg, code_bound=self.code_bound, training=True, seed=self.seed,
-                                            row_offset=row0, accumulate=ci > 0)
+                                            row_offset=row0, accumulate=ci > 0, seg_len=uniform)
             row0 += xc.shape[0]
         dist.allreduce_sum_(self.eng.grads)
         if self.grad_clip is not None:

@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define DSDF_MAX_LAYERS 16
-#define DSDF_ABI_VERSION 1
+#define DSDF_ABI_VERSION 2
 
 enum {
   DSDF_OK = 0,
@@ -73,6 +73,8 @@ typedef struct DsdfBatch {
   int64_t n_points;           /* N of this chunk */
   int64_t n_norm;             /* loss normaliser: the FULL step's point count, also across ranks (:519) */
   int64_t row_offset;         /* index of this chunk's first point inside the step (dropout hash) */
+  int64_t seg_len;            /* > 0: EVERY segment has exactly this many points (the reference's B x S layout without
+                                 --batch_split); 0: irregular.  Enables the segment-sum latent-gradient path. */
 } DsdfBatch;
 
 typedef struct DsdfLossCfg {

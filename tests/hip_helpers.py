@@ -31,10 +31,12 @@ class HipTrainer:
         for ci, (ic, xc, gc) in enumerate(zip(torch.chunk(idx, batch_split), torch.chunk(xyz, batch_split),
                                               torch.chunk(gt, batch_split))):
             sc, so = make_segments(ic)
+            lens = (so[1:] - so[:-1]).cpu()
+            seg_len = int(lens[0]) if bool((lens == lens[0]).all()) else 0
             y = torch.empty(xc.shape[0], device=self.dev) if want_y else None
             self.eng.train_forward_backward(self.lat, self.dlat, sc, so, xc.contiguous(), gc.contiguous(), n_norm=N,
                                             clamp_dist=delta, reg_coef=reg, code_bound=code_bound, training=training,
-                                            seed=seed, row_offset=row0, accumulate=ci > 0, sdf_out=y)
+                                            seed=seed, row_offset=row0, accumulate=ci > 0, sdf_out=y, seg_len=seg_len)
             row0 += xc.shape[0]
             if want_y:
                 ys.append(y)
