@@ -157,9 +157,10 @@ void param_layout(const DsdfNet* n, DsdfParamLayout* L) {
 
 // ---- dW work schedule (dwstream.hpp): (layer, K-split, 128x128 tile) items, ~one per wave of the chip ------------
 struct DwSched {
-  int tiles[DSDF_MAX_LAYERS], tiles_n[DSDF_MAX_LAYERS], nsplit[DSDF_MAX_LAYERS], kchunk[DSDF_MAX_LAYERS], item0[DSDF_MAX_LAYERS];
+  int tiles_m[DSDF_MAX_LAYERS], tiles_n[DSDF_MAX_LAYERS], last_nj[DSDF_MAX_LAYERS], nfull_n[DSDF_MAX_LAYERS],
+      nsplit[DSDF_MAX_LAYERS], kchunk[DSDF_MAX_LAYERS], full0[DSDF_MAX_LAYERS], narrow0[DSDF_MAX_LAYERS];
   long long slab[DSDF_MAX_LAYERS];
-  int n_items;
+  int n_full, n_narrow;
 };
 int chip_waves() {
   static int waves = 0;
@@ -177,33 +178,28 @@ DwSched dw_schedule(const DsdfNet* n, int64_t N, const int* ld_in) {
   DwSched S;
   memset(&S, 0, sizeof(S));
   const int nh = n->n_layers - 1;
-  int T = 0;
+  int Tfull = 0;
   for (int l = 0; l < nh; ++l) {
+    S.tiles_m[l] = (n->out_dim[l] + 127) / 128;
     S.tiles_n[l] = (n->in_dim[l] + 127) / 128;
-    S.tiles[l] = ((n->out_dim[l] + 127) / 128) * S.tiles_n[l];
+    S.last_nj[l] = ((n->in_dim[l] - (S.tiles_n[l] - 1) * 128) + 31) / 32;
+    S.nfull_n[l] = S.last_nj[l] == 4 ? S.tiles_n[l] : S.tiles_n[l] - 1;
     S.slab[l] = rup((int64_t)n->out_dim[l] * ld_in[l], 64);
-    T += S.tiles[l];
+    Tfull += S.tiles_m[l] * S.nfull_n[l];
   }
-  const int W = chip_waves();
-  const int base = W / T > 0 ? W / T : 1;
-  int rem = W - base * T;
-  int maxsplit = (int)(N / 64);
-  if (maxsplit < 1) maxsplit = 1;
-  for (int l = 0; l < nh; ++l) S.nsplit[l] = base;
-  for (int pass = 0; pass < 2 && rem > 0; ++pass)          // hand the left-over waves to the layers with most tiles first
-    for (int l = 0; l < nh; ++l) {
-      const bool big = S.tiles[l] * nh >= T;   // at least the average tile count
-      if ((pass == 0) == big && rem >= S.tiles[l]) { S.nsplit[l]++; rem -= S.tiles[l]; }
-    }
-  int items = 0;
+  // one K-split count for every layer: the largest that still gives every wave of the chip at most one full item
+  int ns = Tfull > 0 && chip_waves() / Tfull > 0 ? chip_waves() / Tfull : 1;
+  const int maxsplit = N / 64 > 0 ? (int)(N / 64) : 1;
+  if (ns > maxsplit) ns = maxsplit;
+  int kchunk = (int)rup((N + ns - 1) / ns, 2);
+  ns = (int)((N + kchunk - 1) / kchunk);
+  int nf = 0, nn = 0;
   for (int l = 0; l < nh; ++l) {
-    if (S.nsplit[l] > maxsplit) S.nsplit[l] = maxsplit;
-    S.kchunk[l] = (int)rup((N + S.nsplit[l] - 1) / S.nsplit[l], 2);
-    S.nsplit[l] = (int)((N + S.kchunk[l] - 1) / S.kchunk[l]);
-    S.item0[l] = items;
-    items += S.nsplit[l] * S.tiles[l];
+    S.nsplit[l] = ns; S.kchunk[l] = kchunk;
+    S.full0[l] = nf;   nf += ns * S.tiles_m[l] * S.nfull_n[l];
+    S.narrow0[l] = nn; nn += S.last_nj[l] == 4 ? 0 : ns * S.tiles_m[l];
   }
-  S.n_items = items;
+  S.n_full = nf; S.n_narrow = nn;
   return S;
 }
 
@@ -627,7 +623,7 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
   {   // all dW_l = dP_l^T a_l in one launch
     DwArgs d;
     memset(&d, 0, sizeof(d));
-    d.n_layers = last; d.n_items = P.dw.n_items; d.N = (int)n;
+    d.n_layers = last; d.n_full = P.dw.n_full; d.n_narrow = P.dw.n_narrow; d.N = (int)n;
     double fl = 0;
     for (int l = 0; l < last; ++l) {
       DwLayer& y = d.ly[l];
@@ -635,11 +631,11 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
       y.act = at<float>(ws, P.in_off[l]); y.ld_act = P.ld_in[l];
       y.slabs = at<float>(ws, P.dwslab_off[l]); y.slab = P.dw.slab[l];
       y.M = net->out_dim[l]; y.Nc = net->in_dim[l]; y.ldc = P.ld_in[l];
-      y.tiles_n = P.dw.tiles_n[l]; y.tiles = P.dw.tiles[l]; y.nsplit = P.dw.nsplit[l]; y.kchunk = P.dw.kchunk[l];
-      y.item0 = P.dw.item0[l];
+      y.tiles_m = P.dw.tiles_m[l]; y.tiles_n = P.dw.tiles_n[l]; y.last_nj = P.dw.last_nj[l]; y.nfull_n = P.dw.nfull_n[l];
+      y.nsplit = P.dw.nsplit[l]; y.kchunk = P.dw.kchunk[l]; y.full0 = P.dw.full0[l]; y.narrow0 = P.dw.narrow0[l];
       fl += 2.0 * (double)n * y.M * y.Nc;
     }
-    int grid = (d.n_items + 3) / 4;
+    int grid = (d.n_full + d.n_narrow + 3) / 4;
     if (grid > chip_waves() / 4) grid = chip_waves() / 4;
     ProfScope ps(DSDF_PROF_GEMM_TN, fl, st);
     hipLaunchKernelGGL(dw_stream_kernel, dim3(grid), dim3(256), 0, st, d);

@@ -19,98 +19,153 @@ struct DwLayer {
   const float* act; int ld_act;   // a_l   [N][ld_act], Nc = in_l columns used
   float* slabs; long long slab;   // [nsplit][M][ldc]
   int M, Nc, ldc;
-  int tiles_n, tiles;             // column tiles of 128, total tiles
+  int tiles_m, tiles_n;           // row / column tiles of 128
+  int last_nj;                    // 32-column sub-tiles in the LAST column tile (1..4); < 4 = a narrow (short) edge tile
+  int nfull_n;                    // column tiles that are full width (tiles_n or tiles_n - 1)
   int nsplit, kchunk;             // K-splits and points per split (even)
-  int item0;                      // first work item of this layer
+  int full0, narrow0;             // first full-width / narrow work item of this layer
 };
-struct DwArgs { int n_layers, n_items, N; DwLayer ly[DSDF_MAX_LAYERS]; };
+// Items: all full-width (128x128) items of all layers first, then the narrow edge items.  Full items go one per wave
+// (round-robin beyond that); the narrow ones are dealt to the waves that got no full item in the last round.
+struct DwArgs { int n_layers, n_full, n_narrow, N; DwLayer ly[DSDF_MAX_LAYERS]; };
 
 constexpr int DW_RING = 8;
+
+template <int NJ> struct DwVec;
+template <> struct DwVec<1> { typedef float type; };
+template <> struct DwVec<2> { typedef float2 type; };
+template <> struct DwVec<3> { typedef float3 type; };
+template <> struct DwVec<4> { typedef float4 type; };
+
+// one work item: a 128 x (32 NJ) tile over points [kbeg, kend)
+template <int NJ>
+__device__ __forceinline__ void dw_item(const DwLayer& L, int split, int m0, int n0, int kbeg, int kend, int fr, int fh) {
+  typedef typename DwVec<NJ>::type bvec;
+  const int nsteps = (kend - kbeg) >> 1;                    // full k-steps of 2 points
+  const float* ap = L.dp + (size_t)(kbeg + fh) * L.ld_dp + m0 + 4 * fr;
+  const float* bq = L.act + (size_t)(kbeg + fh) * L.ld_act + n0 + NJ * fr;
+  const size_t astep = (size_t)2 * L.ld_dp, bstep = (size_t)2 * L.ld_act;
+
+  f32x16 acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[DW_RING];
+  bvec rb[DW_RING];
+  auto ldb = [&](const float* q) -> bvec {
+    if constexpr (NJ == 3) { bvec v; v.x = q[0]; v.y = q[1]; v.z = q[2]; return v; }   // rows are only 4-byte aligned for NJ*fr
+    else return *reinterpret_cast<const bvec*>(q);
+  };
+  auto mma = [&](const float4& a, const bvec& b) {
+    const float av[4] = {a.x, a.y, a.z, a.w};
+    float bv[NJ];
+    if constexpr (NJ == 1) bv[0] = b;
+    else { bv[0] = b.x; bv[1] = b.y; if constexpr (NJ > 2) bv[2] = b.z; if constexpr (NJ > 3) bv[3] = b.w; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+  };
+  // prologue: fill the ring (steps beyond nsteps are simply not loaded)
+#pragma unroll
+  for (int q = 0; q < DW_RING - 1; ++q) {
+    if (q < nsteps) {
+      ra[q] = *reinterpret_cast<const float4*>(ap + q * astep);
+      rb[q] = ldb(bq + q * bstep);
+    }
+  }
+  int s = 0;
+  for (; s + DW_RING <= nsteps; s += DW_RING) {   // steady state: static ring slots, one new step in flight per MMA group
+#pragma unroll
+    for (int q = 0; q < DW_RING; ++q) {
+      const int nxt = s + q + DW_RING - 1;
+      if (nxt < nsteps) {
+        ra[(q + DW_RING - 1) % DW_RING] = *reinterpret_cast<const float4*>(ap + (size_t)nxt * astep);
+        rb[(q + DW_RING - 1) % DW_RING] = ldb(bq + (size_t)nxt * bstep);
+      }
+      mma(ra[q], rb[q]);
+    }
+  }
+  // tail: the remaining (< DW_RING) full steps are already in ring slots 0..rem-1
+#pragma unroll
+  for (int q = 0; q < DW_RING - 1; ++q)
+    if (s + q < nsteps) mma(ra[q], rb[q]);
+  if ((kend - kbeg) & 1) {                                   // odd last point: lanes of the second half contribute zero
+    const int k = kend - 1;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    bvec b;
+    if constexpr (NJ == 1) b = 0.f; else { b.x = 0.f; b.y = 0.f; if constexpr (NJ > 2) b.z = 0.f; if constexpr (NJ > 3) b.w = 0.f; }
+    if (fh == 0) {
+      a = *reinterpret_cast<const float4*>(L.dp + (size_t)k * L.ld_dp + m0 + 4 * fr);
+      b = ldb(L.act + (size_t)k * L.ld_act + n0 + NJ * fr);
+    }
+    mma(a, b);
+  }
+
+  // epilogue: acc[i][j][reg] = dW[m0 + 4 (crow(reg) + 4 fh) + i][n0 + NJ fr + j]  ->  one NJ-float store per (i, reg)
+  float* slab = L.slabs + (size_t)split * L.slab;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)slab, 0, L.M * L.ldc * 4, 0x00020000);
+  const int n = n0 + NJ * fr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + 4 * (crow(r) + 4 * fh) + i;       // rows >= M fall outside the descriptor and are dropped
+      if constexpr (NJ == 4) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const uint32_t voff = n < L.ldc ? (uint32_t)((m * L.ldc + n) * 4) : 0x7FFFFFFFu;   // ldc % 4 == 0
+        u32x4 v = {__float_as_uint(acc[i][0][r]), __float_as_uint(acc[i][1][r]), __float_as_uint(acc[i][2][r]),
+                   __float_as_uint(acc[i][3][r])};
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, 0, 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const uint32_t voff = n + j < L.ldc ? (uint32_t)((m * L.ldc + n + j) * 4) : 0x7FFFFFFFu;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r]), rs, voff, 0, 0);
+        }
+      }
+    }
+}
 
 __global__ __launch_bounds__(256, 1) void dw_stream_kernel(const DwArgs p) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int nwaves = gridDim.x * 4;
-  for (int item = xcd_remap(blockIdx.x, gridDim.x) * 4 + w; item < p.n_items; item += nwaves) {
+  const int wave = xcd_remap(blockIdx.x, gridDim.x) * 4 + w;
+  for (int item = wave; item < p.n_full; item += nwaves) {
     int l = 0;
-    while (l + 1 < p.n_layers && item >= p.ly[l + 1].item0) ++l;
+    while (l + 1 < p.n_layers && item >= p.ly[l + 1].full0) ++l;
     const DwLayer& L = p.ly[l];
-    const int local = item - L.item0;
-    const int split = local / L.tiles, tile = local - split * L.tiles;
-    const int m0 = (tile / L.tiles_n) * 128, n0 = (tile % L.tiles_n) * 128;
+    const int tf = L.tiles_m * L.nfull_n;
+    const int local = item - L.full0;
+    const int split = local / tf, tile = local - split * tf;
     const int kbeg = split * L.kchunk;
-    const int kend = min(p.N, kbeg + L.kchunk);
-    const int nsteps = (kend - kbeg) >> 1;                    // full k-steps of 2 points
-    const float* ap = L.dp + (size_t)(kbeg + fh) * L.ld_dp + m0 + 4 * fr;
-    const float* bq = L.act + (size_t)(kbeg + fh) * L.ld_act + n0 + 4 * fr;
-    const size_t astep = (size_t)2 * L.ld_dp, bstep = (size_t)2 * L.ld_act;
-
-    f32x16 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    float4 ra[DW_RING], rb[DW_RING];
-    auto mma = [&](const float4& a, const float4& b) {
-      const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-    };
-    // prologue: fill the ring (steps beyond nsteps are simply not loaded)
-#pragma unroll
-    for (int q = 0; q < DW_RING - 1; ++q) {
-      if (q < nsteps) {
-        ra[q] = *reinterpret_cast<const float4*>(ap + q * astep);
-        rb[q] = *reinterpret_cast<const float4*>(bq + q * bstep);
-      }
-    }
-    int s = 0;
-    for (; s + DW_RING <= nsteps; s += DW_RING) {   // steady state: static ring slots, one new step in flight per MMA group
-#pragma unroll
-      for (int q = 0; q < DW_RING; ++q) {
-        const int nxt = s + q + DW_RING - 1;
-        if (nxt < nsteps) {
-          ra[(q + DW_RING - 1) % DW_RING] = *reinterpret_cast<const float4*>(ap + (size_t)nxt * astep);
-          rb[(q + DW_RING - 1) % DW_RING] = *reinterpret_cast<const float4*>(bq + (size_t)nxt * bstep);
+    dw_item<4>(L, split, (tile / L.nfull_n) * 128, (tile % L.nfull_n) * 128, kbeg, min(p.N, kbeg + L.kchunk), fr, fh);
+  }
+  if (p.n_narrow > 0) {
+    const int used = p.n_full % nwaves;                 // waves busy in the last round of full items
+    const int spare = used == 0 ? nwaves : nwaves - used;
+    const int first = used == 0 ? 0 : used;
+    if (wave >= first) {
+      for (int item = wave - first; item < p.n_narrow; item += spare) {
+        int l = 0;
+        while (l + 1 < p.n_layers && item >= p.ly[l + 1].narrow0) ++l;
+        const DwLayer& L = p.ly[l];
+        const int local = item - L.narrow0;
+        const int split = local / L.tiles_m, tm = local - split * L.tiles_m;
+        const int kbeg = split * L.kchunk, kend = min(p.N, kbeg + L.kchunk);
+        const int m0 = tm * 128, n0 = (L.tiles_n - 1) * 128;
+        switch (L.last_nj) {
+          case 1: dw_item<1>(L, split, m0, n0, kbeg, kend, fr, fh); break;
+          case 2: dw_item<2>(L, split, m0, n0, kbeg, kend, fr, fh); break;
+          default: dw_item<3>(L, split, m0, n0, kbeg, kend, fr, fh); break;
         }
-        mma(ra[q], rb[q]);
       }
     }
-    // tail: the remaining (< DW_RING) full steps are already in ring slots 0..rem-1
-#pragma unroll
-    for (int q = 0; q < DW_RING - 1; ++q)
-      if (s + q < nsteps) mma(ra[q], rb[q]);
-    if ((kend - kbeg) & 1) {                                   // odd last point: lanes of the second half contribute zero
-      const int k = kend - 1;
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-      if (fh == 0) {
-        a = *reinterpret_cast<const float4*>(L.dp + (size_t)k * L.ld_dp + m0 + 4 * fr);
-        b = *reinterpret_cast<const float4*>(L.act + (size_t)k * L.ld_act + n0 + 4 * fr);
-      }
-      mma(a, b);
-    }
-
-    // epilogue: acc[i][j][reg] = dW[m0 + 4 (crow(reg) + 4 fh) + i][n0 + 4 fr + j]  ->  one 16-byte store per (i, reg)
-    float* slab = L.slabs + (size_t)split * L.slab;
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)slab, 0, L.M * L.ldc * 4, 0x00020000);
-    const int n = n0 + 4 * fr;
-    const bool nok = n < L.ldc;                                // ldc % 4 == 0: the whole float4 is inside the row or not
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + 4 * (crow(r) + 4 * fh) + i;
-        const uint32_t voff = nok ? (uint32_t)((m * L.ldc + n) * 4) : 0x7FFFFFFFu;   // rows >= M fall outside the descriptor
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 v = {__float_as_uint(acc[i][0][r]), __float_as_uint(acc[i][1][r]), __float_as_uint(acc[i][2][r]),
-                   __float_as_uint(acc[i][3][r])};
-        __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, 0, 0);
-      }
   }
 }
 

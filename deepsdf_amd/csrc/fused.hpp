@@ -25,6 +25,9 @@ namespace dsdf {
 constexpr int FROWS = 64;        // points per workgroup
 constexpr int FLD = 516;         // slab row stride in floats
 constexpr int FMAXW = 512;       // widest layer the fused kernels handle
+#ifndef FUSED_STORE_AUX
+#define FUSED_STORE_AUX 2          // cache policy of the activation / dP copies (lab: 2 = nt, 16 = sc1 write-through)
+#endif
 
 struct FusedLayer {
   const float* wf;       // fragment-ordered B operand
@@ -130,8 +133,8 @@ __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[2][4], co
           }
           sp[rc * FLD] = v0;
           sp[(rc + 1) * FLD] = v1;
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rsrc, voff, rc * ldb, 0);
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rsrc, voff, (rc + 1) * ldb, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rsrc, voff, rc * ldb, FUSED_STORE_AUX);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rsrc, voff, (rc + 1) * ldb, FUSED_STORE_AUX);
           mb[m] |= (v0 > 0.f ? 1u : 0u) << (2 * rp);
           mb[m] |= (v1 > 0.f ? 1u : 0u) << (2 * rp + 1);
         }
@@ -173,15 +176,22 @@ __device__ __forceinline__ void fused_kloop(f32x16 (&acc)[2][4], const float* ap
       }
     }
   };
+  // three named register sets: the weights of unit u+2 are requested while unit u is being multiplied (two units =
+  // ~8000 cycles of cover: the activation stores of the epilogues push part of the weight stream out of L2)
+  float4 b2[NACT][2];
   loadB(b0, 0);
+  if (nu > 1) loadB(b1, 1);
   int u = 0;
-  for (; u + 1 < nu; u += 2) {
-    loadB(b1, u + 1);
+  for (; u + 2 < nu; u += 3) {
+    loadB(b2, u + 2);
     compute(b0, u);
-    if (u + 2 < nu) loadB(b0, u + 2);
+    if (u + 3 < nu) loadB(b0, u + 3);
     compute(b1, u + 1);
+    if (u + 4 < nu) loadB(b1, u + 4);
+    compute(b2, u + 2);
   }
   if (u < nu) compute(b0, u);
+  if (u + 1 < nu) compute(b1, u + 1);
 }
 
 __device__ __forceinline__ void fused_kloop_dispatch(f32x16 (&acc)[2][4], const float* ap, const float* const (&bp)[4],
@@ -338,7 +348,7 @@ __device__ __forceinline__ void fused_bwd_epilogue(const f32x16 (&acc)[2][4], fl
           const int rc = 32 * m + crow(r);
           const float v = ((bits >> r) & 1u) ? acc[m][ni][r] * L.mask_scale : 0.f;
           sp[rc * FLD] = v;
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rdp, voff, rc * ldb, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rdp, voff, rc * ldb, FUSED_STORE_AUX);
           cs += v;
         }
       }
