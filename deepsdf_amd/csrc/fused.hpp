@@ -150,7 +150,11 @@ __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[2][4], co
 // The shared k-loop: acc[m][ni] += S[64 rows][K] * Bf[n-tiles of this wave][K]; NACT = existing n-tiles of this wave.
 template <int NACT>
 __device__ __forceinline__ void fused_kloop(f32x16 (&acc)[2][4], const float* ap, const float* const (&bp)[4], int nu) {
-  float4 b0[NACT][2], b1[NACT][2];
+  // Three named register sets rotate over the k-units: the WEIGHTS of unit u+2 (global, fragment order) and the
+  // ACTIVATIONS of unit u+1 (LDS slab) are requested before the 16 NACT MFMAs of unit u issue, so neither the L2
+  // latency nor the LDS latency is exposed (the wave is alone on its SIMD: nothing else would hide them).
+  float4 b0[NACT][2], b1[NACT][2], b2[NACT][2];
+  float4 a0[4], a1[4], a2[4];   // [m-tile + 2 * half]: 4 consecutive k of rows fr and 32 + fr
   auto loadB = [&](float4 (&b)[NACT][2], int u) {
 #pragma unroll
     for (int ni = 0; ni < NACT; ++ni) {
@@ -158,12 +162,17 @@ __device__ __forceinline__ void fused_kloop(f32x16 (&acc)[2][4], const float* ap
       b[ni][1] = *reinterpret_cast<const float4*>(bp[ni] + (size_t)u * 512 + 256);
     }
   };
-  auto compute = [&](const float4 (&b)[NACT][2], int u) {
+  auto readA = [&](float4 (&a)[4], int u) {
+    a[0] = *reinterpret_cast<const float4*>(ap + 16 * u);
+    a[1] = *reinterpret_cast<const float4*>(ap + 32 * FLD + 16 * u);
+    a[2] = *reinterpret_cast<const float4*>(ap + 16 * u + 4);
+    a[3] = *reinterpret_cast<const float4*>(ap + 32 * FLD + 16 * u + 4);
+  };
+  auto mma = [&](const float4 (&a)[4], const float4 (&b)[NACT][2]) {
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
-      const float4 a0 = *reinterpret_cast<const float4*>(ap + 16 * u + 4 * hf);
-      const float4 a1 = *reinterpret_cast<const float4*>(ap + 32 * FLD + 16 * u + 4 * hf);
-      const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+      const float av0[4] = {a[2 * hf].x, a[2 * hf].y, a[2 * hf].z, a[2 * hf].w};
+      const float av1[4] = {a[2 * hf + 1].x, a[2 * hf + 1].y, a[2 * hf + 1].z, a[2 * hf + 1].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
 #pragma unroll
@@ -176,22 +185,26 @@ __device__ __forceinline__ void fused_kloop(f32x16 (&acc)[2][4], const float* ap
       }
     }
   };
-  // three named register sets: the weights of unit u+2 are requested while unit u is being multiplied (two units =
-  // ~8000 cycles of cover: the activation stores of the epilogues push part of the weight stream out of L2)
-  float4 b2[NACT][2];
   loadB(b0, 0);
   if (nu > 1) loadB(b1, 1);
+  readA(a0, 0);
   int u = 0;
   for (; u + 2 < nu; u += 3) {
     loadB(b2, u + 2);
-    compute(b0, u);
+    readA(a1, u + 1);
+    mma(a0, b0);
     if (u + 3 < nu) loadB(b0, u + 3);
-    compute(b1, u + 1);
+    readA(a2, u + 2);
+    mma(a1, b1);
     if (u + 4 < nu) loadB(b1, u + 4);
-    compute(b2, u + 2);
+    if (u + 3 < nu) readA(a0, u + 3);
+    mma(a2, b2);
   }
-  if (u < nu) compute(b0, u);
-  if (u + 1 < nu) compute(b1, u + 1);
+  if (u < nu) {
+    if (u + 1 < nu) readA(a1, u + 1);
+    mma(a0, b0);
+  }
+  if (u + 1 < nu) mma(a1, b1);
 }
 
 __device__ __forceinline__ void fused_kloop_dispatch(f32x16 (&acc)[2][4], const float* ap, const float* const (&bp)[4],
