@@ -6,7 +6,7 @@ import os
 from .build import LIB
 
 MAX_LAYERS = 16
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class DsdfNet(C.Structure):
@@ -29,7 +29,7 @@ class DsdfBatch(C.Structure):
 
 class DsdfLossCfg(C.Structure):
     _fields_ = [("clamp_dist", C.c_float), ("reg_coef", C.c_float), ("code_bound", C.c_float),
-                ("training", C.c_int32), ("dropout_key", C.c_uint32 * MAX_LAYERS)]
+                ("training", C.c_int32), ("frozen_decoder", C.c_int32), ("dropout_key", C.c_uint32 * MAX_LAYERS)]
 
 
 class DsdfAdamCfg(C.Structure):

@@ -501,14 +501,14 @@ float mask_scale_of(const DsdfNet* net, int layer, int training) {
 // shared backward over hidden layers, given dp of layer nl-2 in dp[0] and the last layer's partials.
 // ncols_dz: how many leading x0 columns of d/dx0 are needed (L for training, W0 for the module path).
 int run_backward(const DsdfNet* net, const Plan& P, void* ws, const float* packed, const float* params, int64_t n,
-                 int training, float* grads, int accumulate, int ncols_dz, bool* used_dzB, hipStream_t st) {
+                 int training, float* grads, int accumulate, int ncols_dz, bool* used_dzB, hipStream_t st, bool want_dw = true) {
   DsdfParamLayout L;
   param_layout(net, &L);
   const Packed pk = packed_layout(net);
   const int nl = net->n_layers;
   const int last = nl - 1;
   // second stage of the last layer's partials
-  {
+  if (want_dw) {
     const int w = P.ld_part;
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((w + 63) / 64, LAST_GROUPS), dim3(256), 0, st,
                        at<float>(ws, P.part_off), P.last_blocks, P.ld_part, w, at<float>(ws, P.part2_off), LAST_GROUPS);
@@ -531,6 +531,7 @@ int run_backward(const DsdfNet* net, const Plan& P, void* ws, const float* packe
   for (int l = last - 1; l >= 0; --l) {
     float* dp = at<float>(ws, P.dp_off[cur]);
     // dW_l = dp^T in_l  (split-K slabs)
+    if (want_dw) {
     TnArgs t;
     memset(&t, 0, sizeof(t));
     t.A = dp; t.lda = P.ld_dp; t.B = at<float>(ws, P.in_off[l]); t.ldb = P.ld_in[l];
@@ -550,6 +551,7 @@ int run_backward(const DsdfNet* net, const Plan& P, void* ws, const float* packe
     f.out = net->out_dim[l]; f.in = net->in_dim[l]; f.accumulate = accumulate;
     hipLaunchKernelGGL(finalize_layer_kernel, dim3(f.out), dim3(256), 0, st, f);
     LAUNCH_OK("finalize_layer_kernel");
+    }
     // dX
     NtArgs a;
     memset(&a, 0, sizeof(a));
@@ -577,12 +579,13 @@ int run_backward(const DsdfNet* net, const Plan& P, void* ws, const float* packe
 // Backward with the fused dX chain (fused.hpp): K3's second stage + last layer finalize, ONE launch for the whole
 // dX chain (writes every dP_l, column sums, latent-gradient inputs), then dW (split-K) + finalize per layer.
 int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float* packed, const float* params, int64_t n,
-                       int training, float* grads, int accumulate, int ncols_dz, bool* used_dzB, hipStream_t st) {
+                       int training, float* grads, int accumulate, int ncols_dz, bool* used_dzB, hipStream_t st,
+                       bool want_dw = true) {
   DsdfParamLayout L;
   param_layout(net, &L);
   const Packed pk = packed_layout(net);
   const int nl = net->n_layers, last = nl - 1;
-  {
+  if (want_dw) {
     const int w = P.ld_part;
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((w + 63) / 64, LAST_GROUPS), dim3(256), 0, st,
                        at<float>(ws, P.part_off), P.last_blocks, P.ld_part, w, at<float>(ws, P.part2_off), LAST_GROUPS);
@@ -620,7 +623,7 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     hipLaunchKernelGGL(fused_backward_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, a);
     LAUNCH_OK("fused_backward_kernel");
   }
-  {   // all dW_l = dP_l^T a_l in one launch
+  if (want_dw) {   // all dW_l = dP_l^T a_l in one launch
     DwArgs d;
     memset(&d, 0, sizeof(d));
     d.n_layers = last; d.n_full = P.dw.n_full; d.n_narrow = P.dw.n_narrow; d.N = (int)n;
@@ -641,7 +644,7 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     hipLaunchKernelGGL(dw_stream_kernel, dim3(grid), dim3(256), 0, st, d);
     LAUNCH_OK("dw_stream_kernel");
   }
-  {   // split-K sums, weight-norm backward and bias gradients of ALL layers (last layer included) in one launch
+  if (want_dw) {   // split-K sums, weight-norm backward and bias gradients of ALL layers (last layer included) in one launch
     FinAll fa;
     memset(&fa, 0, sizeof(fa));
     int rows = 0;
@@ -865,8 +868,9 @@ int dsdf_train_forward_backward(const DsdfNet* net, const float* packed, const f
     if ((net->skip_mask >> l) & 1) skip_l = l;
   const bool segsum = fusedb && b->seg_len > 0 && b->seg_len % FROWS == 0 && b->seg_len * R == n && net->n_layers > 2 &&
                       skip_l != net->n_layers - 2;   // the deepest hidden layer's dP column sums live in K3's partials
-  if (fusedb) TRY(run_backward_fused(net, P, ws, packed, params, n, cfg->training, grads, accumulate, segsum ? 0 : Lc, &used_dzB, st));
-  else TRY(run_backward(net, P, ws, packed, params, n, cfg->training, grads, accumulate, Lc, &used_dzB, st));
+  const bool want_dw = cfg->frozen_decoder == 0;
+  if (fusedb) TRY(run_backward_fused(net, P, ws, packed, params, n, cfg->training, grads, accumulate, segsum ? 0 : Lc, &used_dzB, st, want_dw));
+  else TRY(run_backward(net, P, ws, packed, params, n, cfg->training, grads, accumulate, Lc, &used_dzB, st, want_dw));
 
   SegArgs s;
   memset(&s, 0, sizeof(s));

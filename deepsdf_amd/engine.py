@@ -159,7 +159,7 @@ class Engine:
     # ---- training --------------------------------------------------------------------------------------------
     def train_forward_backward(self, latents, dlat, seg_scene, seg_offset, xyz, sdf_gt, *, n_norm, clamp_dist,
                                reg_coef, code_bound, training=True, seed=0, row_offset=0, accumulate=False,
-                               sdf_out=None, step=None, seg_len=0):
+                               sdf_out=None, step=None, seg_len=0, frozen_decoder=False):
         """One chunk of train_deep_sdf.py:509-533.  Gradients land in self.grads / dlat, loss in self.loss."""
         self._fresh_weights()
         n, R = xyz.shape[0], seg_scene.shape[0]
@@ -170,6 +170,7 @@ class Engine:
         cfg.clamp_dist, cfg.reg_coef = float(clamp_dist), float(reg_coef)
         cfg.code_bound = float(code_bound) if code_bound is not None else -1.0
         cfg.training = int(training)
+        cfg.frozen_decoder = int(frozen_decoder)
         st = self.step if step is None else step
         for l in range(_lib.MAX_LAYERS):
             cfg.dropout_key[l] = dropout_layer_key(seed, st, l)

@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define DSDF_MAX_LAYERS 16
-#define DSDF_ABI_VERSION 2
+#define DSDF_ABI_VERSION 3
 
 enum {
   DSDF_OK = 0,
@@ -82,6 +82,7 @@ typedef struct DsdfLossCfg {
   float reg_coef;             /* CodeRegularizationLambda * min(1, epoch/100), 0 disables (:523-527) */
   float code_bound;           /* CodeBound (Embedding max_norm, :343,385); <= 0 disables the renorm */
   int32_t training;           /* 1: dropout active (decoder.train(), :477) */
+  int32_t frozen_decoder;     /* 1: skip the decoder's weight gradients (latent-only optimisation, config 4); grads untouched */
   uint32_t dropout_key[DSDF_MAX_LAYERS]; /* [host-computed] per-layer hash keys (oracle: dropout_layer_key) */
 } DsdfLossCfg;
 

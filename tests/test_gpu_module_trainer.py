@@ -145,3 +145,44 @@ def test_trainer_end_to_end_and_resume(tmp_path):
         bad["epoch"] = 3
         torch.save(bad, os.path.join(exp, "LatentCodes", "latest.pth"))
         train.main_function(exp, "latest", 1)
+
+
+def test_latent_only_reconstruction_vs_golden():
+    """Config 4: frozen decoder, Adam on the code only -- golden g7 = reference Decoder.eval() + torch Adam."""
+    from deepsdf_amd.engine import Engine
+    from deepsdf_amd.net import NetSpec
+    from deepsdf_amd.reconstruct import reconstruct
+    g = Golden("g7_latent_only")
+    m = g.meta
+    eng = Engine(NetSpec(m["L"], **m["net_specs"]))
+    eng.load_params(g.group("params0"))
+    grads_before = eng.grads.clone()
+    its = [g.group(f"it{i}") for i in range(m["iters"])]
+
+    def feed(it):
+        return its[it]["xyz"].cuda().unsqueeze(0), its[it]["gt"].cuda().reshape(1, -1)
+
+    z, _ = reconstruct(eng, its[0]["xyz"].cuda().unsqueeze(0), its[0]["gt"].cuda().reshape(1, -1), num_iterations=m["iters"],
+                       clamp_dist=m["delta"], lr=m["lr"], l2reg=m["l2reg"], z0=g.get("z0/z"), lr_drop_every=0, callback=feed)
+    assert rel_err(z.cpu(), its[-1]["z_after"]) <= PARAM_TOL
+    assert torch.equal(eng.grads, grads_before)          # the frozen decoder's gradient arena is never touched
+
+
+def test_batched_reconstruction_matches_single():
+    """Many shapes at once (one code each, S a multiple of 64 -> segment-sum path) == each shape alone."""
+    from deepsdf_amd.engine import Engine
+    from deepsdf_amd.net import NetSpec
+    from deepsdf_amd.reconstruct import reconstruct
+    kw = dict(dims=[128] * 4, dropout=[0, 1, 2, 3], dropout_prob=0.2, norm_layers=[0, 1, 2, 3], latent_in=[2],
+              weight_norm=True, geom_dimension=3)
+    eng = Engine(NetSpec(16, **kw))
+    eng.init_like_reference(torch.Generator().manual_seed(3))
+    gen = torch.Generator().manual_seed(4)
+    B, S = 3, 128
+    xyz = (torch.rand(B, S, 3, generator=gen) * 2 - 1).cuda()
+    sdf = (xyz.norm(dim=2) - torch.tensor([0.4, 0.5, 0.6], device="cuda")[:, None])
+    z0 = torch.randn(B, 16, generator=gen) * 0.01
+    zb, _ = reconstruct(eng, xyz, sdf, num_iterations=20, z0=z0)
+    for b in range(B):
+        z1, _ = reconstruct(eng, xyz[b:b + 1], sdf[b:b + 1], num_iterations=20, z0=z0[b:b + 1])
+        assert rel_err(zb[b:b + 1].cpu(), z1.cpu()) <= 1e-5
