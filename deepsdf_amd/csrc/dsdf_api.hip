@@ -580,22 +580,16 @@ int run_backward(const DsdfNet* net, const Plan& P, void* ws, const float* packe
 // dX chain (writes every dP_l, column sums, latent-gradient inputs), then dW (split-K) + finalize per layer.
 int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float* packed, const float* params, int64_t n,
                        int training, float* grads, int accumulate, int ncols_dz, bool* used_dzB, hipStream_t st,
-                       bool want_dw = true) {
+                       bool want_dw, const FusedBwdHead& head) {
   DsdfParamLayout L;
   param_layout(net, &L);
   const Packed pk = packed_layout(net);
   const int nl = net->n_layers, last = nl - 1;
-  if (want_dw) {
-    const int w = P.ld_part;
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((w + 63) / 64, LAST_GROUPS), dim3(256), 0, st,
-                       at<float>(ws, P.part_off), P.last_blocks, P.ld_part, w, at<float>(ws, P.part2_off), LAST_GROUPS);
-    LAUNCH_OK("reduce_rows_kernel");
-  }
   *used_dzB = false;
   FusedBwdArgs a;
   memset(&a, 0, sizeof(a));
   a.N = (int)n;
-  a.dp_in = at<float>(ws, P.dpl_off[last - 1]); a.ld_in = P.ld_dp; a.w_in = net->out_dim[last - 1];
+  a.head = head;
   int cnt = 0;
   double wmac = 0;
   for (int l = last - 1; l >= 0; --l) {
@@ -618,10 +612,16 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     wmac += (double)y.K * y.ncols;
   }
   a.n_layers = cnt;
-  if (cnt > 0) {
+  {
     ProfScope ps(DSDF_PROF_FUSED_BWD, 2.0 * (double)n * wmac, st);
     hipLaunchKernelGGL(fused_backward_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, a);
     LAUNCH_OK("fused_backward_kernel");
+  }
+  if (want_dw) {   // second stage of the head's per-workgroup partials
+    const int w = P.ld_part;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((w + 63) / 64, LAST_GROUPS), dim3(256), 0, st,
+                       at<float>(ws, P.part_off), P.nwg, P.ld_part, w, at<float>(ws, P.part2_off), LAST_GROUPS);
+    LAUNCH_OK("reduce_rows_kernel");
   }
   if (want_dw) {   // all dW_l = dP_l^T a_l in one launch
     DwArgs d;
@@ -652,7 +652,7 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
       FinArgs& f = fa.f[fa.n];
       if (l == last) {
         f.slabs = at<float>(ws, P.part2_off); f.nsplit = LAST_GROUPS; f.slab = P.ld_part; f.ldc = P.ld_part;
-        f.colsum = at<float>(ws, P.partdb_off); f.npart = P.last_blocks; f.ldcs = 1;
+        f.colsum = at<float>(ws, P.partdb_off); f.npart = P.nwg; f.ldcs = 1;
       } else {
         f.slabs = at<float>(ws, P.dwslab_off[l]); f.nsplit = P.dw.nsplit[l]; f.slab = P.dw.slab[l]; f.ldc = P.ld_in[l];
         if (l == last - 1) { f.colsum = at<float>(ws, P.part2_off) + P.ld_in[last]; f.npart = LAST_GROUPS; f.ldcs = P.ld_part; }
@@ -673,6 +673,24 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     LAUNCH_OK("finalize_all_kernel");
   }
   return 0;
+}
+
+FusedBwdHead make_head(const DsdfNet* net, const Plan& P, void* ws, const float* packed, const float* params, int mode,
+                       int training) {
+  DsdfParamLayout L;
+  param_layout(net, &L);
+  const Packed pk = packed_layout(net);
+  const int last = net->n_layers - 1;
+  FusedBwdHead h;
+  memset(&h, 0, sizeof(h));
+  h.mode = mode;
+  h.a_last = at<float>(ws, P.in_off[last]); h.ld_a = P.ld_in[last]; h.in_last = net->in_dim[last];
+  h.w_last = packed + pk.w_off[last]; h.b_last = params + L.bias_off[last]; h.use_tanh = net->use_tanh;
+  h.mask_scale = mask_scale_of(net, last - 1, training);
+  h.dp_out = at<float>(ws, P.dpl_off[last - 1]); h.ld_dp = P.ld_dp;
+  h.part = at<float>(ws, P.part_off); h.ld_part = P.ld_part;
+  h.part_db = at<float>(ws, P.partdb_off); h.part_loss = at<float>(ws, P.partloss_off);
+  return h;
 }
 
 int check_common(const DsdfNet* net, const void* packed, const void* params, const void* ws) {
@@ -798,15 +816,20 @@ int dsdf_module_backward(const DsdfNet* net, const float* packed, const float* p
   a.w = packed + pk.w_off[last]; a.b = params + L.bias_off[last]; a.n = (int)n; a.use_tanh = net->use_tanh;
   a.d_sdf = d_sdf; a.u_in = at<float>(ws, P.u_off);
   const bool fusedb = fused_enabled() && fused_eligible(net);
-  a.dp_prev = fusedb ? at<float>(ws, P.dpl_off[last - 1]) : at<float>(ws, P.dp_off[0]);
+  a.dp_prev = at<float>(ws, P.dp_off[0]);
   a.lddp = P.ld_dp; a.mask_scale = mask_scale_of(net, last - 1, training);
   a.part_dw = at<float>(ws, P.part_off); a.ld_part = P.ld_part;
   a.part_colsum = at<float>(ws, P.part_off) + P.ld_in[last];
   a.part_db = at<float>(ws, P.partdb_off); a.part_loss = at<float>(ws, P.partloss_off);
-  TRY(launch_last<LAST_BWD_EXT>(a, P.last_blocks, st));
   bool used_dzB = false;
-  if (fusedb) TRY(run_backward_fused(net, P, ws, packed, params, n, training, grads, accumulate, d_input ? P.W0 : 0, &used_dzB, st));
-  else TRY(run_backward(net, P, ws, packed, params, n, training, grads, accumulate, d_input ? P.W0 : 0, &used_dzB, st));
+  if (fusedb) {
+    FusedBwdHead h = make_head(net, P, ws, packed, params, HEAD_EXT, training);
+    h.d_sdf = d_sdf; h.u_in = at<float>(ws, P.u_off);
+    TRY(run_backward_fused(net, P, ws, packed, params, n, training, grads, accumulate, d_input ? P.W0 : 0, &used_dzB, st, true, h));
+  } else {
+    TRY(launch_last<LAST_BWD_EXT>(a, P.last_blocks, st));
+    TRY(run_backward(net, P, ws, packed, params, n, training, grads, accumulate, d_input ? P.W0 : 0, &used_dzB, st));
+  }
   if (d_input) {
     const long long tot = (long long)n * P.W0;
     hipLaunchKernelGGL(add2_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, at<float>(ws, P.dzA_off), P.ldz,
@@ -854,12 +877,12 @@ int dsdf_train_forward_backward(const DsdfNet* net, const float* packed, const f
   a.w = packed + pk.w_off[last]; a.b = params + L.bias_off[last]; a.n = (int)n; a.use_tanh = net->use_tanh;
   a.y_out = sdf_out; a.gt = b->sdf_gt; a.delta = cfg->clamp_dist; a.inv_n = 1.0f / (float)b->n_norm;
   const bool fusedb = fused_enabled() && fused_eligible(net);
-  a.dp_prev = fusedb ? at<float>(ws, P.dpl_off[last - 1]) : at<float>(ws, P.dp_off[0]);
+  a.dp_prev = at<float>(ws, P.dp_off[0]);
   a.lddp = P.ld_dp; a.mask_scale = mask_scale_of(net, last - 1, cfg->training);
   a.part_dw = at<float>(ws, P.part_off); a.ld_part = P.ld_part;
   a.part_colsum = at<float>(ws, P.part_off) + P.ld_in[last];
   a.part_db = at<float>(ws, P.partdb_off); a.part_loss = at<float>(ws, P.partloss_off);
-  TRY(launch_last<LAST_TRAIN>(a, P.last_blocks, st));
+  if (!fusedb) TRY(launch_last<LAST_TRAIN>(a, P.last_blocks, st));
 
   bool used_dzB = false;
   // segment-sum latent gradient: every segment is a whole number of 64-row workgroups
@@ -869,8 +892,13 @@ int dsdf_train_forward_backward(const DsdfNet* net, const float* packed, const f
   const bool segsum = fusedb && b->seg_len > 0 && b->seg_len % FROWS == 0 && b->seg_len * R == n && net->n_layers > 2 &&
                       skip_l != net->n_layers - 2;   // the deepest hidden layer's dP column sums live in K3's partials
   const bool want_dw = cfg->frozen_decoder == 0;
-  if (fusedb) TRY(run_backward_fused(net, P, ws, packed, params, n, cfg->training, grads, accumulate, segsum ? 0 : Lc, &used_dzB, st, want_dw));
-  else TRY(run_backward(net, P, ws, packed, params, n, cfg->training, grads, accumulate, Lc, &used_dzB, st, want_dw));
+  if (fusedb) {
+    FusedBwdHead h = make_head(net, P, ws, packed, params, HEAD_TRAIN, cfg->training);
+    h.gt = b->sdf_gt; h.delta = cfg->clamp_dist; h.inv_n = 1.0f / (float)b->n_norm; h.y_out = sdf_out;
+    TRY(run_backward_fused(net, P, ws, packed, params, n, cfg->training, grads, accumulate, segsum ? 0 : Lc, &used_dzB, st, want_dw, h));
+  } else {
+    TRY(run_backward(net, P, ws, packed, params, n, cfg->training, grads, accumulate, Lc, &used_dzB, st, want_dw));
+  }
 
   SegArgs s;
   memset(&s, 0, sizeof(s));
@@ -904,7 +932,7 @@ int dsdf_train_forward_backward(const DsdfNet* net, const float* packed, const f
   sc.creg = cfg->reg_coef / (float)b->n_norm; sc.reg_loss = at<float>(ws, P.regloss_off);
   hipLaunchKernelGGL(seg_scatter_kernel, dim3((unsigned)R), dim3(256), 0, st, sc);
   LAUNCH_OK("seg_scatter_kernel");
-  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, at<float>(ws, P.partloss_off), P.last_blocks,
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, at<float>(ws, P.partloss_off), fusedb ? P.nwg : P.last_blocks,
                      1.0f / (float)b->n_norm, at<float>(ws, P.regloss_off), loss_out, accumulate);
   LAUNCH_OK("loss_finish_kernel");
   return 0;

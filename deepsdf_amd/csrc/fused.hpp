@@ -286,6 +286,7 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(const FusedFwdArg
   }
 
   // last layer: 16 rows per wave, a row's `in_last` (<= 512) floats spread over the 64 lanes as two float4 chunks
+  if (p.y_out == nullptr && p.u_out == nullptr) return;   // training: the backward kernel's head recomputes it from the slab
   float4 qv[2];
 #pragma unroll
   for (int cc = 0; cc < 2; ++cc) {
@@ -329,9 +330,26 @@ struct FusedBwdLayer {
   float* colsum; int ldcs;         // [n_wg][ldcs] per-workgroup column sums of dP_{l-1}
   float* dz_out; int ldz; int dz_cols;
 };
+// Head of the chain = the LAST layer (out_dim 1) done in the prologue from the activation slab a_last:
+//   u = <a, w> + b ; y = tanh(tanh?(u)) ; TRAIN: clamped-L1 loss + dy (train_deep_sdf.py:493,517-521) | EXT: dy = d_sdf
+//   du = dy (1-y^2)(1-t1^2) ; dP_{last-1} = du w [a > 0] scale -> slab + global ; per-workgroup partials of
+//   dW_last = sum du a, db_last = sum du, column sums of dP_{last-1}, loss.
+enum { HEAD_DP_GIVEN = 0, HEAD_TRAIN = 1, HEAD_EXT = 2 };
+struct FusedBwdHead {
+  int mode;
+  const float* a_last; int ld_a; int in_last; const float* w_last; const float* b_last; int use_tanh;
+  const float* gt; float delta; float inv_n;          // HEAD_TRAIN
+  const float* d_sdf; const float* u_in;              // HEAD_EXT
+  float* y_out;                                       // optional [N]
+  float mask_scale;
+  float* dp_out; int ld_dp;                           // global dP_{last-1}
+  float* part; int ld_part;                           // [n_wg][ld_part]: [dW_last (in_last) | colsum of dP_{last-1} at offset ld_a]
+  float* part_db; float* part_loss;                   // [n_wg]
+};
 struct FusedBwdArgs {
   int n_layers, N;                 // entries of ly[], processed in order (deepest layer first)
-  const float* dp_in; int ld_in; int w_in;   // dP of the deepest hidden layer [N][ld_in], w_in columns
+  const float* dp_in; int ld_in; int w_in;   // HEAD_DP_GIVEN: dP of the deepest hidden layer [N][ld_in], w_in columns
+  FusedBwdHead head;
   FusedBwdLayer ly[DSDF_MAX_LAYERS];
 };
 
@@ -386,8 +404,91 @@ __global__ __launch_bounds__(256, 2) void fused_backward_kernel(const FusedBwdAr
   const int fr = lane & 31, fh = lane >> 5;
   const int row0 = blockIdx.x * FROWS;
 
-  fused_load_x0(S, p.dp_in, p.ld_in, p.w_in, row0, p.N, 0);
-  fused_zero_pad(S, p.w_in);
+  if (p.head.mode == HEAD_DP_GIVEN) {
+    fused_load_x0(S, p.dp_in, p.ld_in, p.w_in, row0, p.N, 0);
+    fused_zero_pad(S, p.w_in);
+  } else {
+    __shared__ float hred[4][2 * FMAXW];
+    __shared__ float hsc[4][2];
+    const FusedBwdHead& H = p.head;
+    fused_load_x0(S, H.a_last, H.ld_a, H.in_last, row0, p.N, 0);
+    float4 qv[2], dwa[2], csa[2];
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      const int c = 4 * lane + 256 * cc;
+      qv[cc] = c < H.in_last ? *reinterpret_cast<const float4*>(H.w_last + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      dwa[cc] = make_float4(0.f, 0.f, 0.f, 0.f); csa[cc] = dwa[cc];
+    }
+    const float blast = H.b_last[0];
+    float lossacc = 0.f, dbacc = 0.f;
+    __syncthreads();
+    for (int rr = 0; rr < FROWS / 4; ++rr) {
+      const int row = (FROWS / 4) * w + rr, grow = row0 + row;
+      float4 av[2];
+      float dot = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        const int c = 4 * lane + 256 * cc;
+        av[cc] = c < H.in_last ? *reinterpret_cast<const float4*>(S + row * FLD + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dot += av[cc].x * qv[cc].x + av[cc].y * qv[cc].y + av[cc].z * qv[cc].z + av[cc].w * qv[cc].w;
+      }
+      const bool live = grow < p.N;
+      float u = wave_sum(dot) + blast;
+      if (H.mode == HEAD_EXT && live) u = H.u_in[grow];
+      const float t1 = H.use_tanh ? tanhf(u) : u;
+      const float y = tanhf(t1);
+      float dy = 0.f;
+      if (live) {
+        if (H.mode == HEAD_TRAIN) {
+          const float yh = fminf(fmaxf(y, -H.delta), H.delta);
+          const float th = fminf(fmaxf(H.gt[grow], -H.delta), H.delta);
+          const float diff = yh - th;
+          lossacc += fabsf(diff);
+          const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+          dy = (y >= -H.delta && y <= H.delta) ? sg * H.inv_n : 0.f;
+        } else {
+          dy = H.d_sdf[grow];
+        }
+        if (lane == 0 && H.y_out != nullptr) H.y_out[grow] = y;
+      }
+      float du = dy * (1.f - y * y);
+      if (H.use_tanh) du *= (1.f - t1 * t1);
+      dbacc += du;
+      const float ds = du * H.mask_scale;
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        const int c = 4 * lane + 256 * cc;
+        if (c < H.in_last) {
+          float4 d;
+          d.x = av[cc].x > 0.f ? ds * qv[cc].x : 0.f;
+          d.y = av[cc].y > 0.f ? ds * qv[cc].y : 0.f;
+          d.z = av[cc].z > 0.f ? ds * qv[cc].z : 0.f;
+          d.w = av[cc].w > 0.f ? ds * qv[cc].w : 0.f;
+          *reinterpret_cast<float4*>(S + row * FLD + c) = d;
+          if (live) *reinterpret_cast<float4*>(H.dp_out + (size_t)grow * H.ld_dp + c) = d;
+          dwa[cc].x += du * av[cc].x; dwa[cc].y += du * av[cc].y; dwa[cc].z += du * av[cc].z; dwa[cc].w += du * av[cc].w;
+          csa[cc].x += d.x; csa[cc].y += d.y; csa[cc].z += d.z; csa[cc].w += d.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      *reinterpret_cast<float4*>(&hred[w][4 * lane + 256 * cc]) = dwa[cc];
+      *reinterpret_cast<float4*>(&hred[w][FMAXW + 4 * lane + 256 * cc]) = csa[cc];
+    }
+    if (lane == 0) { hsc[w][0] = lossacc; hsc[w][1] = dbacc; }
+    __syncthreads();
+    for (int c = tid; c < H.in_last; c += 256) {
+      H.part[(size_t)blockIdx.x * H.ld_part + c] = (hred[0][c] + hred[1][c]) + (hred[2][c] + hred[3][c]);
+      H.part[(size_t)blockIdx.x * H.ld_part + H.ld_a + c] =
+          (hred[0][FMAXW + c] + hred[1][FMAXW + c]) + (hred[2][FMAXW + c] + hred[3][FMAXW + c]);
+    }
+    if (tid == 0) {
+      H.part_loss[blockIdx.x] = (hsc[0][0] + hsc[1][0]) + (hsc[2][0] + hsc[3][0]);
+      H.part_db[blockIdx.x] = (hsc[0][1] + hsc[1][1]) + (hsc[2][1] + hsc[3][1]);
+    }
+    fused_zero_pad(S, H.in_last);
+  }
   __syncthreads();
 
   for (int i = 0; i < p.n_layers; ++i) {
