@@ -397,9 +397,21 @@ __global__ __launch_bounds__(256) void seg_latgrad_kernel(const SegLatArgs p) {
   const int col = c0 + cx;
   float acc = 0.f;
   if (col < p.L) {
-    for (int j = ks; j < p.out0; j += 4) acc += ss[0][j] * p.W0[(size_t)j * p.ldw0 + col];
-    if (p.csk != nullptr)
-      for (int j = ks; j < p.outk; j += 4) acc += ss[1][j] * p.Wk[(size_t)j * p.ldwk + p.koff + col];
+    auto dotcol = [&](const float* sv, const float* W, int ldw, int n) {   // 16 independent loads in flight per batch
+      float a = 0.f;
+      int j = ks;
+      for (; j + 60 < n; j += 64) {
+        float t[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t[q] = W[(size_t)(j + 4 * q) * ldw];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a += sv[j + 4 * q] * t[q];
+      }
+      for (; j < n; j += 4) a += sv[j] * W[(size_t)j * ldw];
+      return a;
+    };
+    acc = dotcol(ss[0], p.W0 + col, p.ldw0, p.out0);
+    if (p.csk != nullptr) acc += dotcol(ss[1], p.Wk + p.koff + col, p.ldwk, p.outk);
   }
   red[ks][cx] = acc;
   __syncthreads();
