@@ -37,9 +37,9 @@ class DsdfAdamCfg(C.Structure):
                 ("beta2", C.c_float), ("eps", C.c_float), ("grad_scale", C.c_void_p)]
 
 
-PROF_CLASSES = 6
+PROF_CLASSES = 7
 PROF_NAMES = ("gemm_nt_kernel", "gemm_tn_kernel", "last_layer_kernel", "fused_forward_kernel", "fused_backward_kernel",
-              "other")
+              "dw_stream_kernel", "other")
 
 
 class DsdfProfile(C.Structure):

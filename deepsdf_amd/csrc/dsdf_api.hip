@@ -640,7 +640,7 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     }
     int grid = (d.n_full + d.n_narrow + 3) / 4;
     if (grid > chip_waves() / 4) grid = chip_waves() / 4;
-    ProfScope ps(DSDF_PROF_GEMM_TN, fl, st);
+    ProfScope ps(DSDF_PROF_DW_STREAM, fl, st);
     hipLaunchKernelGGL(dw_stream_kernel, dim3(grid), dim3(256), 0, st, d);
     LAUNCH_OK("dw_stream_kernel");
   }

@@ -152,9 +152,9 @@ int dsdf_adam_latent_only(float* latent, const float* dlat, float* exp_avg, floa
 
 /* ---- diagnostics: per-kernel-class device time from HIP events recorded on the caller's stream around every
  * launch of that class (bench.py's roofline object).  Off by default; thread-local; read synchronises. */
-#define DSDF_PROF_CLASSES 6
+#define DSDF_PROF_CLASSES 7
 enum { DSDF_PROF_GEMM_NT = 0, DSDF_PROF_GEMM_TN = 1, DSDF_PROF_LAST = 2, DSDF_PROF_FUSED_FWD = 3, DSDF_PROF_FUSED_BWD = 4,
-       DSDF_PROF_OTHER = 5 };
+       DSDF_PROF_DW_STREAM = 5, DSDF_PROF_OTHER = 6 };
 typedef struct DsdfProfile {
   double ms[DSDF_PROF_CLASSES];     /* summed event-to-event time per class */
   double flops[DSDF_PROF_CLASSES];  /* summed 2*M*N*K (executed, incl. tile padding excluded) per class */
