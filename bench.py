@@ -91,7 +91,11 @@ def main():
     from deepsdf_amd.engine import Engine
     from deepsdf_amd.net import NetSpec
 
-    rank, local, world = dist.init()
+    # rehearsal knobs (1-GPU box): DSDF_DIST_BACKEND=gloo + DSDF_SINGLE_DEVICE=1 run several ranks on ONE card to exercise
+    # the multi-process logic; the driver's real multi-GPU runs use neither (backend nccl = RCCL, one rank per GPU)
+    rank, local, world = dist.init(backend=os.environ.get("DSDF_DIST_BACKEND"))
+    if os.environ.get("DSDF_SINGLE_DEVICE") == "1":
+        local = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     dev = torch.device("cuda", local)

@@ -148,12 +148,35 @@ __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[2][4], co
 }
 
 // The shared k-loop: acc[m][ni] += S[64 rows][K] * Bf[n-tiles of this wave][K]; NACT = existing n-tiles of this wave.
+struct FusedBSets { float4 b0[4][2], b1[4][2]; };   // weights of k-units 0 and 1 of the NEXT layer, requested before the epilogue
+
+__device__ __forceinline__ void fused_prefetch_b(FusedBSets& B, const float* wf, int U, int w, int lane, int nact, int nu) {
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    if (ni < nact) {
+      const float* q = wf + (size_t)(w + 4 * ni) * U * 512 + lane * 4;
+      B.b0[ni][0] = *reinterpret_cast<const float4*>(q);
+      B.b0[ni][1] = *reinterpret_cast<const float4*>(q + 256);
+      if (nu > 1) {
+        B.b1[ni][0] = *reinterpret_cast<const float4*>(q + 512);
+        B.b1[ni][1] = *reinterpret_cast<const float4*>(q + 768);
+      }
+    }
+  }
+}
+
 template <int NACT>
-__device__ __forceinline__ void fused_kloop(f32x16 (&acc)[2][4], const float* ap, const float* const (&bp)[4], int nu) {
+__device__ __forceinline__ void fused_kloop(f32x16 (&acc)[2][4], const float* ap, const float* const (&bp)[4], int nu,
+                                            FusedBSets& PB) {
   // Three named register sets rotate over the k-units: the WEIGHTS of unit u+2 (global, fragment order) and the
   // ACTIVATIONS of unit u+1 (LDS slab) are requested before the 16 NACT MFMAs of unit u issue, so neither the L2
   // latency nor the LDS latency is exposed (the wave is alone on its SIMD: nothing else would hide them).
   float4 b0[NACT][2], b1[NACT][2], b2[NACT][2];
+#pragma unroll
+  for (int ni = 0; ni < NACT; ++ni) {   // units 0 and 1 were requested by fused_prefetch_b (before the previous epilogue)
+    b0[ni][0] = PB.b0[ni][0]; b0[ni][1] = PB.b0[ni][1];
+    b1[ni][0] = PB.b1[ni][0]; b1[ni][1] = PB.b1[ni][1];
+  }
   float4 a0[4], a1[4], a2[4];   // [m-tile + 2 * half]: 4 consecutive k of rows fr and 32 + fr
   auto loadB = [&](float4 (&b)[NACT][2], int u) {
 #pragma unroll
@@ -185,8 +208,6 @@ __device__ __forceinline__ void fused_kloop(f32x16 (&acc)[2][4], const float* ap
       }
     }
   };
-  loadB(b0, 0);
-  if (nu > 1) loadB(b1, 1);
   readA(a0, 0);
   int u = 0;
   for (; u + 2 < nu; u += 3) {
@@ -208,14 +229,19 @@ __device__ __forceinline__ void fused_kloop(f32x16 (&acc)[2][4], const float* ap
 }
 
 __device__ __forceinline__ void fused_kloop_dispatch(f32x16 (&acc)[2][4], const float* ap, const float* const (&bp)[4],
-                                                     int nu, int nact) {
+                                                     int nu, int nact, FusedBSets& PB) {
   switch (nact) {
-    case 4: fused_kloop<4>(acc, ap, bp, nu); break;
-    case 3: fused_kloop<3>(acc, ap, bp, nu); break;
-    case 2: fused_kloop<2>(acc, ap, bp, nu); break;
-    case 1: fused_kloop<1>(acc, ap, bp, nu); break;
+    case 4: fused_kloop<4>(acc, ap, bp, nu, PB); break;
+    case 3: fused_kloop<3>(acc, ap, bp, nu, PB); break;
+    case 2: fused_kloop<2>(acc, ap, bp, nu, PB); break;
+    case 1: fused_kloop<1>(acc, ap, bp, nu, PB); break;
     default: break;
   }
+}
+
+__device__ __forceinline__ int fused_nact(int ncols, int w) {   // how many of this wave's n-tiles {w, w+4, w+8, w+12} exist
+  const int ntl = (ncols + 31) >> 5;
+  return ntl > w ? min(4, (ntl - w + 3) >> 2) : 0;
 }
 
 __device__ __forceinline__ void fused_zero_pad(float* S, int nin) {   // columns [nin, roundup16(nin)) of every slab row
@@ -229,6 +255,8 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(const FusedFwdArg
   const int fr = lane & 31, fh = lane >> 5;
   const int row0 = blockIdx.x * FROWS;
 
+  FusedBSets PB;
+  fused_prefetch_b(PB, p.ly[0].wf, p.ly[0].U, w, lane, fused_nact(p.ly[0].out_dim, w), (p.ly[0].in + 15) >> 4);
   fused_load_x0(S, p.x0, p.ldx0, p.W0, row0, p.N, 0);
   fused_zero_pad(S, p.W0);
   __syncthreads();
@@ -258,10 +286,10 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(const FusedFwdArg
       const int col = 32 * (w + 4 * ni) + fr;
       biasv[ni] = col < L.out_dim ? L.bias[col] : 0.f;
     }
-    {
-      const int ntl = (L.out_dim + 31) >> 5;
-      const int nact = ntl > w ? min(4, (ntl - w + 3) >> 2) : 0;
-      fused_kloop_dispatch(acc, ap, bp, nu, nact);
+    fused_kloop_dispatch(acc, ap, bp, nu, fused_nact(L.out_dim, w), PB);
+    if (l + 1 < p.n_hidden) {   // next layer's first weights travel while this layer's epilogue runs
+      const FusedLayer& Ln = p.ly[l + 1];
+      fused_prefetch_b(PB, Ln.wf, Ln.U, w, lane, fused_nact(Ln.out_dim, w), (Ln.in + 15) >> 4);
     }
 #ifdef DSDF_LAB
     if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 1 + 3 * l] = __builtin_amdgcn_s_memtime();
@@ -489,6 +517,8 @@ __global__ __launch_bounds__(256, 2) void fused_backward_kernel(const FusedBwdAr
     }
     fused_zero_pad(S, H.in_last);
   }
+  FusedBSets PB;
+  if (p.n_layers > 0) fused_prefetch_b(PB, p.ly[0].wtf, p.ly[0].U, w, lane, fused_nact(p.ly[0].ncols, w), (p.ly[0].K + 15) >> 4);
   __syncthreads();
 
   for (int i = 0; i < p.n_layers; ++i) {
@@ -507,10 +537,10 @@ __global__ __launch_bounds__(256, 2) void fused_backward_kernel(const FusedBwdAr
     const float* ap = S + fr * FLD + 8 * fh;
     uint4 mq = make_uint4(0u, 0u, 0u, 0u);
     if (L.maskbits != nullptr) mq = *reinterpret_cast<const uint4*>(L.maskbits + ((size_t)blockIdx.x * 256 + tid) * 4);
-    {
-      const int ntl = (L.ncols + 31) >> 5;
-      const int nact = ntl > w ? min(4, (ntl - w + 3) >> 2) : 0;
-      fused_kloop_dispatch(acc, ap, bp, nu, nact);
+    fused_kloop_dispatch(acc, ap, bp, nu, fused_nact(L.ncols, w), PB);
+    if (i + 1 < p.n_layers) {
+      const FusedBwdLayer& Ln = p.ly[i + 1];
+      fused_prefetch_b(PB, Ln.wtf, Ln.U, w, lane, fused_nact(Ln.ncols, w), (Ln.K + 15) >> 4);
     }
     __syncthreads();
     fused_bwd_epilogue(acc, S, L, w, fr, fh, row0, p.N, mq);

@@ -27,6 +27,7 @@ def init(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             torch.cuda.set_device(local)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver only supports dmabuf IPC
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
 

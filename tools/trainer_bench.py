@@ -1,0 +1,36 @@
+"""End-to-end epoch time of the drop-in trainer on a config-2-shaped synthetic experiment (256 scenes x 20k samples on disk,
+ScenesPerBatch 64 x SamplesPerScene 256 = 16384 pts/step, 4 steps per epoch).  Usage: python tools/trainer_bench.py [epochs]"""
+import json, os, sys, tempfile, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from oracle import deepsdf_oracle as orc
+from deepsdf_amd import train
+epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+root = tempfile.mkdtemp()
+d = os.path.join(root, "data", "SdfSamples", "synth", "spheres"); os.makedirs(d)
+names = []
+NSC = 256
+for k in range(NSC):
+    pos, neg = orc.sphere_scene(k, 20000)
+    np.savez(os.path.join(d, f"s{k}.npz"), pos=pos, neg=neg); names.append(f"s{k}")
+json.dump({"synth": {"spheres": names}}, open(os.path.join(root, "split.json"), "w"))
+exp = os.path.join(root, "exp"); os.makedirs(exp)
+specs = {"Description": "config 2 shape", "DataSource": os.path.join(root, "data"), "NetworkArch": "deep_sdf_decoder",
+         "TrainSplit": os.path.join(root, "split.json"), "TestSplit": "", "ReconstructionSplit": "",
+         "NetworkSpecs": {"dims": [512] * 8, "dropout": list(range(8)), "dropout_prob": 0.2, "norm_layers": list(range(8)),
+                          "latent_in": [4], "xyz_in_all": False, "use_tanh": False, "latent_dropout": False, "weight_norm": True,
+                          "geom_dimension": 3},
+         "CodeLength": 256, "NumEpochs": epochs, "SnapshotFrequency": 10 ** 6, "AdditionalSnapshots": [],
+         "LearningRateSchedule": [{"Type": "Step", "Initial": 0.0005, "Interval": 500, "Factor": 0.5},
+                                  {"Type": "Step", "Initial": 0.001, "Interval": 500, "Factor": 0.5}],
+         "SamplesPerScene": 256, "ScenesPerBatch": 64, "ClampingDistance": 0.1, "CodeRegularization": True,
+         "CodeRegularizationLambda": 1e-4, "CodeBound": 1.0, "LogFrequency": 10 ** 6}
+json.dump(specs, open(os.path.join(exp, "specs.json"), "w"))
+import logging; logging.disable(logging.INFO)
+t0 = time.time(); train.main_function(exp, None, 1); torch.cuda.synchronize(); t = time.time() - t0
+print(f"trainer: {epochs} epochs ({NSC//64} steps of 16384 pts each) in {t:.2f} s incl. setup")
+specs["NumEpochs"] = 3 * epochs; json.dump(specs, open(os.path.join(exp, "specs.json"), "w"))
+t0 = time.time(); train.main_function(exp, None, 1); torch.cuda.synchronize(); t3 = time.time() - t0
+per = (t3 - t) / (2 * epochs)
+spe = NSC // 64
+print(f"marginal: {per*1e3:.3f} ms/epoch = {per/spe*1e3:.3f} ms/step = {16384*spe/per/1e6:.2f} M pts/s end-to-end (sampling + step + per-epoch logging)")
