@@ -29,7 +29,7 @@ struct DwLayer {
 // (round-robin beyond that); the narrow ones are dealt to the waves that got no full item in the last round.
 struct DwArgs { int n_layers, n_full, n_narrow, N; DwLayer ly[DSDF_MAX_LAYERS]; };
 
-constexpr int DW_RING = 8;
+constexpr int DW_RING = 16;
 
 template <int NJ> struct DwVec;
 template <> struct DwVec<1> { typedef float type; };
