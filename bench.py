@@ -115,6 +115,11 @@ def main():
 
     def step(i):
         b = batches[i % len(batches)]
+        if world == 1:     # the trainer's single-GPU path: one library call (FusedTrainStep in deepsdf_amd/train.py)
+            eng.train_step(lat, dlat, lat_m, lat_v, b["seg_scene"], b["seg_offset"], b["xyz"], b["gt"], n_norm=n_global,
+                           clamp_dist=0.1, reg_coef=1e-4 * min(1, 1 / 100), code_bound=1.0, lr_decoder=5e-4, lr_latent=1e-3,
+                           training=True, seed=rank, seg_len=SAMPLES)
+            return
         eng.train_forward_backward(lat, dlat, b["seg_scene"], b["seg_offset"], b["xyz"], b["gt"], n_norm=n_global,
                                    clamp_dist=0.1, reg_coef=1e-4 * min(1, 1 / 100), code_bound=1.0, training=True,
                                    seed=rank, row_offset=0, seg_len=SAMPLES)

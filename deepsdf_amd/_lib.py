@@ -6,7 +6,7 @@ import os
 from .build import LIB
 
 MAX_LAYERS = 16
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class DsdfNet(C.Structure):
@@ -69,6 +69,8 @@ PROTOTYPES = {
                                     _P, _I32, _P, _SZ, _P],
     "dsdf_grad_norm": [_P, _I64, _F, _P, _P, _P, _SZ, _P],
     "dsdf_adam_step": [_NET, _P, _P, _P, _P, _P, _P, _P, _P, _I64, C.POINTER(DsdfAdamCfg), _P, _P],
+    "dsdf_train_step": [_NET, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, C.POINTER(DsdfBatch), C.POINTER(DsdfLossCfg),
+                        C.POINTER(DsdfAdamCfg), _P, _P, _P, _SZ, _P],
     "dsdf_adam_latent_only": [_P, _P, _P, _P, _I64, C.POINTER(DsdfAdamCfg), _P],
     "dsdf_profile_enable": [_I32],
     "dsdf_profile_read": [C.POINTER(DsdfProfile)],

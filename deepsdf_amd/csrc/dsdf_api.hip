@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* part, int
   }
 }
 
-int materialize(const DsdfNet* net, const float* params, float* packed, hipStream_t st) {
+int materialize(const DsdfNet* net, const float* params, float* packed, hipStream_t st, bool scales_ready = false) {
   DsdfParamLayout L;
   param_layout(net, &L);
   const Packed pk = packed_layout(net);
@@ -374,8 +374,10 @@ int materialize(const DsdfNet* net, const float* params, float* packed, hipStrea
     tiles += ((y.out + 31) / 32) * y.tcols;
   }
   a.total_rows = rows; a.total_tiles = tiles;
-  hipLaunchKernelGGL(wn_scale_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a);
-  LAUNCH_OK("wn_scale_kernel");
+  if (!scales_ready) {   // dsdf_train_step's fused finalize+Adam already wrote the new row scales
+    hipLaunchKernelGGL(wn_scale_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a);
+    LAUNCH_OK("wn_scale_kernel");
+  }
   hipLaunchKernelGGL(wn_tiles_kernel, dim3(tiles), dim3(256), 0, st, a);
   LAUNCH_OK("wn_tiles_kernel");
   return 0;
@@ -576,11 +578,13 @@ int run_backward(const DsdfNet* net, const Plan& P, void* ws, const float* packe
   return 0;
 }
 
+struct FuseAdam { const DsdfAdamCfg* cfg; float* params; float* exp_avg; float* exp_avg_sq; float* packed; };
+
 // Backward with the fused dX chain (fused.hpp): K3's second stage + last layer finalize, ONE launch for the whole
 // dX chain (writes every dP_l, column sums, latent-gradient inputs), then dW (split-K) + finalize per layer.
 int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float* packed, const float* params, int64_t n,
                        int training, float* grads, int accumulate, int ncols_dz, bool* used_dzB, hipStream_t st,
-                       bool want_dw, const FusedBwdHead& head) {
+                       bool want_dw, const FusedBwdHead& head, const FuseAdam* fz = nullptr) {
   DsdfParamLayout L;
   param_layout(net, &L);
   const Packed pk = packed_layout(net);
@@ -664,6 +668,19 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
       f.dv = grads + L.v_off[l];
       f.db = grads + L.bias_off[l];
       f.out = net->out_dim[l]; f.in = net->in_dim[l]; f.accumulate = accumulate;
+      if (fz != nullptr) {
+        const DsdfAdamCfg* c = fz->cfg;
+        const double bc1 = 1.0 - pow((double)c->beta1, (double)c->step), bc2 = 1.0 - pow((double)c->beta2, (double)c->step);
+        f.adam = 1;
+        f.pb = fz->params + L.bias_off[l]; f.mb = fz->exp_avg + L.bias_off[l]; f.sb = fz->exp_avg_sq + L.bias_off[l];
+        f.pv = fz->params + L.v_off[l];    f.mv = fz->exp_avg + L.v_off[l];    f.sv = fz->exp_avg_sq + L.v_off[l];
+        if (L.g_off[l] >= 0) { f.pg = fz->params + L.g_off[l]; f.mg = fz->exp_avg + L.g_off[l]; f.sg = fz->exp_avg_sq + L.g_off[l]; }
+        int r0 = 0;
+        for (int q = 0; q < l; ++q) r0 += net->out_dim[q];
+        f.scale_out = fz->packed + pk.scale_off + r0;
+        f.omb1 = 1.0f - c->beta1; f.b2 = c->beta2; f.omb2 = 1.0f - c->beta2;
+        f.step_size = (float)((double)c->lr_decoder / bc1); f.bc2_sqrt = (float)sqrt(bc2); f.eps = c->eps;
+      }
       fa.row0[fa.n] = rows;
       rows += f.out;
       ++fa.n;
@@ -839,10 +856,14 @@ int dsdf_module_backward(const DsdfNet* net, const float* packed, const float* p
   return 0;
 }
 
-int dsdf_train_forward_backward(const DsdfNet* net, const float* packed, const float* params, float* latent_table,
-                                int64_t n_scenes, const DsdfBatch* b, const DsdfLossCfg* cfg, float* grads, float* dlat,
-                                float* loss_out, float* sdf_out, int32_t accumulate, void* ws, size_t ws_bytes,
-                                void* stream) {
+}  // extern "C"
+
+namespace {
+// returns 1 in *adam_fused when the decoder's Adam update (and the new weight-norm scales) was folded into the finalize pass
+int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, float* latent_table, int64_t n_scenes,
+                  const DsdfBatch* b, const DsdfLossCfg* cfg, float* grads, float* dlat, float* loss_out, float* sdf_out,
+                  int32_t accumulate, void* ws, size_t ws_bytes, void* stream, const FuseAdam* fz, int* adam_fused) {
+  if (adam_fused) *adam_fused = 0;
   TRY(check_common(net, packed, params, ws));
   if (!b || !cfg || !latent_table || !grads || !dlat || !loss_out) return fail(DSDF_E_INVALID, "NULL argument");
   const int64_t n = b->n_points, R = b->n_segments;
@@ -895,7 +916,9 @@ int dsdf_train_forward_backward(const DsdfNet* net, const float* packed, const f
   if (fusedb) {
     FusedBwdHead h = make_head(net, P, ws, packed, params, HEAD_TRAIN, cfg->training);
     h.gt = b->sdf_gt; h.delta = cfg->clamp_dist; h.inv_n = 1.0f / (float)b->n_norm; h.y_out = sdf_out;
-    TRY(run_backward_fused(net, P, ws, packed, params, n, cfg->training, grads, accumulate, segsum ? 0 : Lc, &used_dzB, st, want_dw, h));
+    const FuseAdam* use = (fz != nullptr && want_dw && !accumulate) ? fz : nullptr;
+    TRY(run_backward_fused(net, P, ws, packed, params, n, cfg->training, grads, accumulate, segsum ? 0 : Lc, &used_dzB, st, want_dw, h, use));
+    if (use != nullptr && adam_fused) *adam_fused = 1;
   } else {
     TRY(run_backward(net, P, ws, packed, params, n, cfg->training, grads, accumulate, Lc, &used_dzB, st, want_dw));
   }
@@ -936,6 +959,17 @@ int dsdf_train_forward_backward(const DsdfNet* net, const float* packed, const f
                      1.0f / (float)b->n_norm, at<float>(ws, P.regloss_off), loss_out, accumulate);
   LAUNCH_OK("loss_finish_kernel");
   return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int dsdf_train_forward_backward(const DsdfNet* net, const float* packed, const float* params, float* latent_table,
+                                int64_t n_scenes, const DsdfBatch* b, const DsdfLossCfg* cfg, float* grads, float* dlat,
+                                float* loss_out, float* sdf_out, int32_t accumulate, void* ws, size_t ws_bytes,
+                                void* stream) {
+  return train_fb_impl(net, packed, params, latent_table, n_scenes, b, cfg, grads, dlat, loss_out, sdf_out, accumulate, ws,
+                       ws_bytes, stream, nullptr, nullptr);
 }
 
 int dsdf_grad_norm(const float* grads, int64_t n, float max_norm, float* norm_out, float* coef_out, void* ws,
@@ -982,6 +1016,26 @@ int dsdf_adam_step(const DsdfNet* net, float* params, const float* grads, float*
     TRY(adam_launch(latent_table, dlat, lat_exp_avg, lat_exp_avg_sq, n_latent_floats, cfg->lr_latent, cfg, nullptr, st));
   }
   return materialize(net, params, packed, st);
+}
+
+int dsdf_train_step(const DsdfNet* net, float* packed, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                    float* latent_table, int64_t n_scenes, float* dlat, float* lat_exp_avg, float* lat_exp_avg_sq,
+                    const DsdfBatch* b, const DsdfLossCfg* cfg, const DsdfAdamCfg* adam, float* loss_out, float* sdf_out,
+                    void* ws, size_t ws_bytes, void* stream) {
+  if (!adam || !exp_avg || !exp_avg_sq || !lat_exp_avg || !lat_exp_avg_sq) return fail(DSDF_E_INVALID, "NULL argument");
+  if (adam->step < 1) return fail(DSDF_E_INVALID, "Adam step must be >= 1");
+  FuseAdam fz{adam, params, exp_avg, exp_avg_sq, packed};
+  int fused = 0;
+  const bool can_fuse = adam->grad_scale == nullptr && cfg && !cfg->frozen_decoder;
+  TRY(train_fb_impl(net, packed, params, latent_table, n_scenes, b, cfg, grads, dlat, loss_out, sdf_out, 0, ws, ws_bytes, stream,
+                    can_fuse ? &fz : nullptr, &fused));
+  const int64_t nlat = n_scenes * net->latent_size;
+  if (!fused)
+    return dsdf_adam_step(net, params, grads, exp_avg, exp_avg_sq, latent_table, dlat, lat_exp_avg, lat_exp_avg_sq, nlat, adam,
+                          packed, stream);
+  hipStream_t st = (hipStream_t)stream;
+  TRY(adam_launch(latent_table, dlat, lat_exp_avg, lat_exp_avg_sq, nlat, adam->lr_latent, adam, nullptr, st));
+  return materialize(net, params, packed, st, true);
 }
 
 int dsdf_adam_latent_only(float* latent, const float* dlat, float* exp_avg, float* exp_avg_sq, int64_t n,

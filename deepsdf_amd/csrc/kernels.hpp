@@ -260,7 +260,24 @@ struct FinArgs {
   const float* g; const float* v;   // parameters (g null for plain layers)
   float* dg; float* dv; float* db;  // gradient arena slices
   int out, in; int accumulate;
+  // fused optimiser (single-GPU fast path, dsdf_train_step): when adam != 0 the gradients are consumed on the spot --
+  // Adam on this row's bias, g and v (torch math, same expressions as adam_kernel), then the new weight-norm scale
+  // g/||v|| of the row -- and are NOT written to the gradient arena.
+  int adam;
+  float* pb; float* pg; float* pv;          // parameters (mutable aliases of bias / g / v-or-weight)
+  float* mb; float* mg; float* mv;          // exp_avg
+  float* sb; float* sg; float* sv;          // exp_avg_sq
+  float* scale_out;                         // [out] weight-norm scale of the updated row (1 for plain layers)
+  float omb1, b2, omb2, step_size, bc2_sqrt, eps;
 };
+
+__device__ __forceinline__ float adam_elem(float& p, float g, float& m, float& v, const FinArgs& a) {
+  const float mi = fmaf(a.omb1, g - m, m);
+  const float vi = a.b2 * v + a.omb2 * g * g;
+  m = mi; v = vi;
+  p = p - a.step_size * (mi / (sqrtf(vi) / a.bc2_sqrt + a.eps));
+  return p;
+}
 __device__ __forceinline__ void finalize_row(const FinArgs& p, const int i, float* red) {
   const int tid = threadIdx.x;
   float dot = 0.f, ss = 0.f;
@@ -292,28 +309,44 @@ __device__ __forceinline__ void finalize_row(const FinArgs& p, const int i, floa
     const float gi = p.g[i];
     const float dgi = dot / nrm;
     const float a = gi / nrm, b = gi * dgi / (nrm * nrm);
+    float ssn = 0.f;
 #pragma unroll
     for (int k = 0; k < MAXC; ++k) {
       const int c = tid + 256 * k;
       if (c < p.in) {
         const size_t o = (size_t)i * p.in + c;
         const float d = a * dwr[k] - b * p.v[o];
-        p.dv[o] = p.accumulate ? p.dv[o] + d : d;
+        if (p.adam) { const float vn = adam_elem(p.pv[o], d, p.mv[o], p.sv[o], p); ssn += vn * vn; }
+        else p.dv[o] = p.accumulate ? p.dv[o] + d : d;
       }
     }
-    if (tid == 0) p.dg[i] = p.accumulate ? p.dg[i] + dgi : dgi;
+    if (p.adam) {
+      ssn = block_sum_256(ssn, red);
+      if (tid == 0) {
+        const float gn = adam_elem(p.pg[i], dgi, p.mg[i], p.sg[i], p);
+        p.scale_out[i] = gn / sqrtf(ssn);
+      }
+    } else if (tid == 0) p.dg[i] = p.accumulate ? p.dg[i] + dgi : dgi;
   } else {
 #pragma unroll
     for (int k = 0; k < MAXC; ++k) {
       const int c = tid + 256 * k;
-      if (c < p.in) { const size_t o = (size_t)i * p.in + c; p.dv[o] = p.accumulate ? p.dv[o] + dwr[k] : dwr[k]; }
+      if (c < p.in) {
+        const size_t o = (size_t)i * p.in + c;
+        if (p.adam) adam_elem(p.pv[o], dwr[k], p.mv[o], p.sv[o], p);
+        else p.dv[o] = p.accumulate ? p.dv[o] + dwr[k] : dwr[k];
+      }
     }
+    if (p.adam && tid == 0) p.scale_out[i] = 1.f;
   }
   // bias gradient: fixed-order sum of the column partials
   float s = 0.f;
   for (int q = tid; q < p.npart; q += 256) s += p.colsum[(size_t)q * p.ldcs + i];
   s = block_sum_256(s, red);
-  if (tid == 0) p.db[i] = p.accumulate ? p.db[i] + s : s;
+  if (tid == 0) {
+    if (p.adam) adam_elem(p.pb[i], s, p.mb[i], p.sb[i], p);
+    else p.db[i] = p.accumulate ? p.db[i] + s : s;
+  }
 }
 
 __global__ __launch_bounds__(256) void finalize_layer_kernel(const FinArgs p) {

@@ -46,6 +46,10 @@ def allreduce_sum_(flat):
     return flat
 
 
+def is_multi():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

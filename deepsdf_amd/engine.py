@@ -179,6 +179,29 @@ class Engine:
             C.byref(cfg), _ptr(self.grads), _ptr(dlat), _ptr(self.loss), _ptr(sdf_out), int(accumulate), _ptr(ws),
             ws.numel(), _stream()))
 
+    def train_step(self, latents, dlat, lat_m, lat_v, seg_scene, seg_offset, xyz, sdf_gt, *, n_norm, clamp_dist, reg_coef,
+                   code_bound, lr_decoder, lr_latent, training=True, seed=0, seg_len=0, betas=(0.9, 0.999), eps=1e-8):
+        """Whole optimiser step in ONE library call (single process, no --batch_split, no clipping): forward + backward +
+        Adam on both groups + weight re-materialisation, with the decoder's Adam folded into the finalize pass."""
+        self._fresh_weights()
+        n, R = xyz.shape[0], seg_scene.shape[0]
+        ws = self.train_workspace(n, R)
+        b = _lib.DsdfBatch(seg_scene.data_ptr(), seg_offset.data_ptr(), R, xyz.data_ptr(), sdf_gt.data_ptr(), n,
+                           int(n_norm), 0, int(seg_len))
+        cfg = _lib.DsdfLossCfg()
+        cfg.clamp_dist, cfg.reg_coef = float(clamp_dist), float(reg_coef)
+        cfg.code_bound = float(code_bound) if code_bound is not None else -1.0
+        cfg.training, cfg.frozen_decoder = int(training), 0
+        for l in range(_lib.MAX_LAYERS):
+            cfg.dropout_key[l] = dropout_layer_key(seed, self.step, l)
+        self.step += 1
+        ad = _lib.DsdfAdamCfg(self.step, float(lr_decoder), float(lr_latent), betas[0], betas[1], eps, None)
+        _lib.check(self.lib.dsdf_train_step(
+            C.byref(self.cnet), _ptr(self.packed), _ptr(self.params), _ptr(self.grads), _ptr(self.exp_avg),
+            _ptr(self.exp_avg_sq), _ptr(latents), latents.shape[0], _ptr(dlat), _ptr(lat_m), _ptr(lat_v), C.byref(b),
+            C.byref(cfg), C.byref(ad), _ptr(self.loss), None, _ptr(ws), ws.numel(), _stream()))
+        self.weights_dirty = False
+
     def grad_norm(self, max_norm):
         """clip_grad_norm_ coefficient into self.clip[1] (device); returns the device tensor [norm, coef]."""
         ws = self._workspace(1 << 16)

@@ -228,6 +228,13 @@ class FusedTrainStep:
                                   torch.chunk(sdf_gt, batch_split)):
                 sc, so = make_segments(ic)
                 chunks.append((sc, so, xc.contiguous(), gc.contiguous()))
+        if batch_split == 1 and self.grad_clip is None and not dist.is_multi():
+            # single-GPU fast path: one library call, decoder Adam folded into the finalize pass
+            sc, so, xc, gc = chunks[0]
+            self.eng.train_step(self.lat, self.dlat, self.lat_m, self.lat_v, sc, so, xc, gc, n_norm=n_norm,
+                                clamp_dist=self.clamp_dist, reg_coef=reg, code_bound=self.code_bound, lr_decoder=lr_decoder,
+                                lr_latent=lr_latent, training=True, seed=self.seed, seg_len=uniform)
+            return
         row0 = 0
         for ci, (sc, so, xc, gc) in enumerate(chunks):
             self.eng.train_forward_backward(self.lat, self.dlat, sc, so, xc, gc, n_norm=n_norm, clamp_dist=self.clamp_dist,

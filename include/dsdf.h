@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define DSDF_MAX_LAYERS 16
-#define DSDF_ABI_VERSION 3
+#define DSDF_ABI_VERSION 4
 
 enum {
   DSDF_OK = 0,
@@ -145,6 +145,15 @@ int dsdf_grad_norm(const float* grads, int64_t n, float max_norm, float* norm_ou
 int dsdf_adam_step(const DsdfNet* net, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                    float* latent_table, const float* dlat, float* lat_exp_avg, float* lat_exp_avg_sq,
                    int64_t n_latent_floats, const DsdfAdamCfg* cfg, float* packed, void* stream);
+
+/* Single-GPU fast path = dsdf_train_forward_backward (accumulate 0) + dsdf_adam_step in one call.  When nothing has to
+ * happen between the gradients and the update (no all-reduce, no --batch_split accumulation, no clipping:
+ * adam->grad_scale == NULL) the decoder's Adam and the new weight-norm scales are folded into the split-K finalize pass
+ * (the gradient arena is then NOT written); otherwise it is exactly the two calls in sequence. */
+int dsdf_train_step(const DsdfNet* net, float* packed, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                    float* latent_table, int64_t n_scenes, float* dlat, float* lat_exp_avg, float* lat_exp_avg_sq,
+                    const DsdfBatch* batch, const DsdfLossCfg* cfg, const DsdfAdamCfg* adam, float* loss_out, float* sdf_out,
+                    void* ws, size_t ws_bytes, void* stream);
 
 /* latent-only Adam (frozen decoder; config 4): updates only the given latent arena. */
 int dsdf_adam_latent_only(float* latent, const float* dlat, float* exp_avg, float* exp_avg_sq, int64_t n,

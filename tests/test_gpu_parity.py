@@ -168,3 +168,29 @@ def test_full_size_properties():
         assert rel_err(outs[2]["grads"][k], outs[0]["grads"][k]) <= 1e-5, k        # accumulation == one pass
     assert torch.equal(outs[0]["dlat"], outs[1]["dlat"])
     assert abs(outs[2]["loss"] - outs[0]["loss"]) <= 1e-6 * abs(outs[0]["loss"])
+
+
+def test_train_step_fast_path_equals_two_call_path():
+    """dsdf_train_step (finalize + Adam + weight-norm scales fused, gradient arena not written) == forward_backward +
+    adam_step: identical Adam arithmetic per element; only the row-norm summation order of the new scales differs."""
+    from deepsdf_amd.engine import make_segments
+    L, B, S = 256, 8, 256
+    net = orc.make_net(L, **BIG)
+    spec = spec_from_meta(dict(L=L, net_specs=BIG))
+    params = orc.init_params(net, 21)
+    lat0 = torch.randn(B, L, generator=torch.Generator().manual_seed(2)) / math.sqrt(L)
+    a, b = HipTrainer(spec, params, lat0), HipTrainer(spec, params, lat0)
+    for step in range(3):
+        idx, xyz, gt = _big_batch(B, S, 300 + step)
+        a.step(idx, xyz, gt, delta=0.1, code_bound=1.0, code_reg=True, lam=1e-4, epoch=150, lr=(5e-4, 1e-3), seed=5)
+        sc, so = make_segments(idx.cuda())
+        b.eng.train_step(b.lat, b.dlat, b.lat_m, b.lat_v, sc, so, xyz.cuda().contiguous(), gt.reshape(-1).cuda().contiguous(),
+                         n_norm=B * S, clamp_dist=0.1, reg_coef=1e-4, code_bound=1.0, lr_decoder=5e-4, lr_latent=1e-3, seed=5,
+                         seg_len=S)
+        assert abs(float(a.eng.loss) - float(b.eng.loss)) <= 1e-6 * abs(float(a.eng.loss))
+        pa, pb = a.params(), b.params()
+        for k in pa:
+            assert rel_err(pb[k], pa[k]) <= 2e-6, (step, k)
+        assert rel_err(b.lat.cpu(), a.lat.cpu()) <= 2e-6
+        assert rel_err(b.eng.exp_avg.cpu(), a.eng.exp_avg.cpu()) <= 1e-5
+        assert rel_err(b.eng.packed.cpu(), a.eng.packed.cpu()) <= 2e-6       # W, W^T, fragment copies and scales
