@@ -941,7 +941,7 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
     }
     q.wg_per_seg = (int)(b->seg_len / FROWS); q.R = (int)R; q.L = Lc;
     q.seg_scene = b->seg_scene; q.table = latent_table; q.segpart = s.segpart; q.segnorm = s.segnorm;
-    hipLaunchKernelGGL(seg_latgrad_kernel, dim3((unsigned)R, (Lc + 63) / 64), dim3(256), 0, st, q);
+    hipLaunchKernelGGL(seg_latgrad_kernel, dim3((unsigned)R, (Lc + 15) / 16), dim3(256), 0, st, q);
     LAUNCH_OK("seg_latgrad_kernel");
   } else {
     hipLaunchKernelGGL(seg_reduce_kernel, dim3((unsigned)R, (Lc + 63) / 64), dim3(256), 0, st, s);

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(const SegArgs p) {
 //   sum_{n in segment} (dP_0[n] W_0 + dP_k[n] W_k[:, skip])[:L]  =  (sum_n dP_0[n]) W_0[:, :L] + (sum_n dP_k[n]) W_k[:, off:off+L]
 // and the per-workgroup (64-row) column sums of dP_0 / dP_k already exist (bias-gradient partials of the fused
 // backward).  Valid when every segment is a whole number of 64-row workgroups.  Replaces the per-point d/dx0 GEMM
-// columns and seg_reduce_kernel.  grid (R, ceil(L/64)), block = 64 columns x 4 k-slices.
+// columns and seg_reduce_kernel.
 struct SegLatArgs {
   const float* cs0; int ldcs; int out0; const float* W0; int ldw0;        // column sums of dP_0, W_0 [out0][ldw0]
   const float* csk; int outk; const float* Wk; int ldwk; int koff;        // skip layer (csk may be null)
@@ -412,9 +412,10 @@ struct SegLatArgs {
   float* segpart; float* segnorm;
 };
 __global__ __launch_bounds__(256) void seg_latgrad_kernel(const SegLatArgs p) {
+  // grid (R, ceil(L/16)); block = 16 columns x 16 k-slices: 1024+ blocks of short dot products instead of 256 long ones
   __shared__ float ss[2][FSEG_MAXW];
-  __shared__ float red[4][64];
-  const int r = blockIdx.x, c0 = blockIdx.y * 64, tid = threadIdx.x, cx = tid & 63, ks = tid >> 6;
+  __shared__ float red[16][17];
+  const int r = blockIdx.x, c0 = blockIdx.y * 16, tid = threadIdx.x, cx = tid & 15, ks = tid >> 4;
   for (int j = tid; j < p.out0; j += 256) {
     float s = 0.f;
     for (int g = 0; g < p.wg_per_seg; ++g) s += p.cs0[(size_t)(r * p.wg_per_seg + g) * p.ldcs + j];
@@ -433,14 +434,14 @@ __global__ __launch_bounds__(256) void seg_latgrad_kernel(const SegLatArgs p) {
     auto dotcol = [&](const float* sv, const float* W, int ldw, int n) {   // 16 independent loads in flight per batch
       float a = 0.f;
       int j = ks;
-      for (; j + 60 < n; j += 64) {
+      for (; j + 240 < n; j += 256) {
         float t[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) t[q] = W[(size_t)(j + 4 * q) * ldw];
+        for (int q = 0; q < 16; ++q) t[q] = W[(size_t)(j + 16 * q) * ldw];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) a += sv[j + 4 * q] * t[q];
+        for (int q = 0; q < 16; ++q) a += sv[j + 16 * q] * t[q];
       }
-      for (; j < n; j += 4) a += sv[j] * W[(size_t)j * ldw];
+      for (; j < n; j += 16) a += sv[j] * W[(size_t)j * ldw];
       return a;
     };
     acc = dotcol(ss[0], p.W0 + col, p.ldw0, p.out0);
@@ -448,7 +449,12 @@ __global__ __launch_bounds__(256) void seg_latgrad_kernel(const SegLatArgs p) {
   }
   red[ks][cx] = acc;
   __syncthreads();
-  if (ks == 0 && col < p.L) p.segpart[(size_t)r * p.L + col] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+  if (ks == 0 && col < p.L) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += red[q][cx];
+    p.segpart[(size_t)r * p.L + col] = s;
+  }
   if (blockIdx.y == 0 && tid < 64) {
     const float* row = p.table + (size_t)p.seg_scene[r] * p.L;
     float q = 0.f;
