@@ -192,7 +192,9 @@ DwSched dw_schedule(const DsdfNet* n, int64_t N, const int* ld_in) {
   const int maxsplit = N / 64 > 0 ? (int)(N / 64) : 1;
   if (ns > maxsplit) ns = maxsplit;
   int kchunk = (int)rup((N + ns - 1) / ns, 2);
+  if (kchunk < 2) kchunk = 2;   // N == 0 (size queries for an empty batch)
   ns = (int)((N + kchunk - 1) / kchunk);
+  if (ns < 1) ns = 1;
   int nf = 0, nn = 0;
   for (int l = 0; l < nh; ++l) {
     S.nsplit[l] = ns; S.kchunk[l] = kchunk;
@@ -252,7 +254,9 @@ Plan make_plan(const DsdfNet* n, int64_t N, int64_t R, bool inference) {
   if (ns > NSPLIT_MAX) ns = NSPLIT_MAX;
   if (ns < 1) ns = 1;
   P.kchunk = (int)rup((N + ns - 1) / ns, BK);
+  if (P.kchunk < BK) P.kchunk = BK;   // N == 0 (size query for an empty batch)
   P.nsplit = (int)((N + P.kchunk - 1) / P.kchunk);
+  if (P.nsplit < 1) P.nsplit = 1;
   int64_t maxslab = 0;
   int maxout = 1;
   for (int l = 0; l < P.nl - 1; ++l) {

@@ -70,3 +70,13 @@ def test_param_names_match_oracle():
     from deepsdf_amd.net import dropout_layer_key
     assert dropout_layer_key(1234, 5, 3) == orc.dropout_layer_key(1234, 5, 3)
     assert dropout_layer_key((1 << 40) + 7, (1 << 33) + 1, 0) == orc.dropout_layer_key((1 << 40) + 7, (1 << 33) + 1, 0)
+
+
+def test_size_queries_survive_degenerate_batches(lib):
+    from deepsdf_amd.net import NetSpec
+    net = NetSpec(4, [32, 32], 3, norm_layers=[0, 1], weight_norm=True).c_struct()
+    b = C.c_size_t()
+    for n in (0, 1, 63, 64, 65):
+        assert lib.dsdf_workspace_bytes(C.byref(net), n, 1 if n else 0, C.byref(b)) == 0 and b.value > 0
+        assert lib.dsdf_decode_workspace_bytes(C.byref(net), n, C.byref(b)) == 0
+    assert lib.dsdf_workspace_bytes(C.byref(net), -1, 0, C.byref(b)) == -1

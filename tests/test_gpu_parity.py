@@ -194,3 +194,66 @@ def test_train_step_fast_path_equals_two_call_path():
         assert rel_err(b.lat.cpu(), a.lat.cpu()) <= 2e-6
         assert rel_err(b.eng.exp_avg.cpu(), a.eng.exp_avg.cpu()) <= 1e-5
         assert rel_err(b.eng.packed.cpu(), a.eng.packed.cpu()) <= 2e-6       # W, W^T, fragment copies and scales
+
+
+def test_fused_and_layered_paths_agree_on_ragged_batches(monkeypatch):
+    """The two product paths (fused persistent kernels vs layer-by-layer GEMM launches, DSDF_NO_FUSED=1) on a batch the
+    fast paths do not special-case: N not a multiple of 64, ragged segments, a repeated scene, odd dropout row offset
+    through --batch_split 3."""
+    L = 256
+    net = orc.make_net(L, **BIG)
+    spec = spec_from_meta(dict(L=L, net_specs=BIG))
+    params = orc.init_params(net, 33)
+    lat0 = torch.randn(6, L, generator=torch.Generator().manual_seed(8)) / math.sqrt(L)
+    gen = torch.Generator().manual_seed(9)
+    lens = [700, 129, 1, 333, 64, 2100]
+    scenes = [3, 0, 5, 3, 1, 4]                       # scene 3 appears in two segments
+    idx = torch.cat([torch.full((n,), s, dtype=torch.int64) for n, s in zip(lens, scenes)])
+    N = idx.numel()
+    xyz = torch.rand(N, 3, generator=gen) * 2 - 1
+    gt = xyz.norm(dim=1, keepdim=True) - 0.5
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DSDF_NO_FUSED", mode)
+        tr = HipTrainer(spec, params, lat0)
+        outs[mode] = tr.step(idx, xyz, gt, delta=0.1, code_bound=1.0, code_reg=True, lam=1e-4, epoch=300, lr=(5e-4, 1e-3),
+                             batch_split=3, seed=77, want_y=True)
+        outs[mode]["params"] = tr.params()
+        outs[mode]["lat"] = tr.lat.cpu()
+    a, b = outs["0"], outs["1"]
+    assert rel_err(a["y"], b["y"]) <= 1e-6
+    assert abs(a["loss"] - b["loss"]) <= 1e-6 * abs(b["loss"])
+    # the two paths sum in different orders, so a few of the 13.6 M pre-activations flip their ReLU (not margin-safe)
+    for k in a["grads"]:
+        assert rel_err(a["grads"][k], b["grads"][k]) <= 3e-4, k
+    assert rel_err(a["dlat"], b["dlat"]) <= 3e-4
+    for k in a["params"]:   # Adam's first step is ~lr*sign(g): an element whose tiny gradient differs moves differently
+        assert rel_err(a["params"][k], b["params"][k]) <= 1e-4, k
+    # and against the oracle (fp32) for the same batch
+    st = orc.TrainState.create({k: v.clone() for k, v in params.items()}, lat0.clone())
+    ro = orc.train_step(net, st, idx, xyz, gt, delta=0.1, code_bound=1.0, epoch=300, batch_split=3, seed=77)
+    assert abs(a["loss"] - ro["loss"]) <= 1e-5 * abs(ro["loss"])
+    assert rel_err(a["dlat"], ro["dlat"]) <= 2e-4
+    for k in ro["grads"]:
+        assert rel_err(a["grads"][k], ro["grads"][k]) <= 3e-4, k     # not margin-safe: a few ReLU flips are expected
+
+
+def test_empty_and_invalid_batches_are_rejected():
+    import ctypes as C
+    from deepsdf_amd import _lib
+    from deepsdf_amd.engine import Engine, make_segments
+    spec = spec_from_meta(dict(L=4, net_specs=dict(dims=[32] * 2, dropout=None, dropout_prob=0.0, norm_layers=[0, 1],
+                                                   latent_in=(), weight_norm=True, geom_dimension=3)))
+    eng = Engine(spec)
+    eng.init_like_reference(torch.Generator().manual_seed(0))
+    lat = torch.zeros(2, 4, device="cuda")
+    dl = torch.zeros_like(lat)
+    sc, so = make_segments(torch.zeros(8, dtype=torch.int64, device="cuda"))
+    xyz, gt = torch.zeros(8, 3, device="cuda"), torch.zeros(8, device="cuda")
+    with pytest.raises(_lib.DsdfError, match="n_norm must be positive"):
+        eng.train_forward_backward(lat, dl, sc, so, xyz, gt, n_norm=0, clamp_dist=0.1, reg_coef=0.0, code_bound=None)
+    with pytest.raises(_lib.DsdfError, match="empty batch"):
+        eng.train_forward_backward(lat, dl, sc[:0], so[:1], xyz[:0], gt[:0], n_norm=8, clamp_dist=0.1, reg_coef=0.0, code_bound=None)
+    with pytest.raises(ValueError, match="expected input"):
+        eng.decode(torch.zeros(4, 3, device="cuda"))
+    assert eng.decode(torch.zeros(0, 7, device="cuda")).shape == (0, 1)      # empty inference batch is a no-op
