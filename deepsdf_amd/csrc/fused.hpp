@@ -208,18 +208,40 @@ __device__ __forceinline__ void fused_kloop(f32x16 (&acc)[2][4], const float* ap
       }
     }
   };
+  // One step = {request B of unit +2, read A of unit +1, 16 NACT MFMAs of the current unit}.  The memory instructions
+  // must be SPREAD over the MFMA stream: the wave is alone on its SIMD, and a cluster of 12 loads at the top of a step
+  // keeps the (in-order) wave from issuing the next MFMA for ~400 cycles.  sched_group_barrier pins the interleave:
+  // one memory op, then MPG MFMAs, ... (prefetch indices are clamped instead of branched so a step is one region).
+  constexpr int NMEM = 2 * NACT + 4, MPG = (16 * NACT) / NMEM, MREST = 16 * NACT - NMEM * MPG;
+  auto interleave = [&]() {
+#pragma unroll
+    for (int q = 0; q < 2 * NACT; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+      __builtin_amdgcn_sched_group_barrier(0x008, MPG, 0); // MFMA
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+      __builtin_amdgcn_sched_group_barrier(0x008, MPG, 0);
+    }
+    if constexpr (MREST > 0) __builtin_amdgcn_sched_group_barrier(0x008, MREST, 0);
+  };
+  const int ulast = nu - 1;
   readA(a0, 0);
   int u = 0;
   for (; u + 2 < nu; u += 3) {
     loadB(b2, u + 2);
     readA(a1, u + 1);
     mma(a0, b0);
-    if (u + 3 < nu) loadB(b0, u + 3);
+    interleave();
+    loadB(b0, min(u + 3, ulast));
     readA(a2, u + 2);
     mma(a1, b1);
-    if (u + 4 < nu) loadB(b1, u + 4);
-    if (u + 3 < nu) readA(a0, u + 3);
+    interleave();
+    loadB(b1, min(u + 4, ulast));
+    readA(a0, min(u + 3, ulast));
     mma(a2, b2);
+    interleave();
   }
   if (u < nu) {
     if (u + 1 < nu) readA(a1, u + 1);
