@@ -83,10 +83,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--scenes-per-batch", type=int, default=64,
+                    help="NOT the headline config: scale the batch (x 256 samples) to see large-batch behaviour")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event instrumented pass")
     args = ap.parse_args()
 
+    global SCENES_PER_BATCH
+    SCENES_PER_BATCH = args.scenes_per_batch
     from deepsdf_amd import _lib, dist
     from deepsdf_amd.engine import Engine
     from deepsdf_amd.net import NetSpec
@@ -104,7 +108,7 @@ def main():
     spec = NetSpec(L, **NET)
     eng = Engine(spec, dev)
     eng.init_like_reference(torch.Generator().manual_seed(0))      # identical on every rank (replicated decoder)
-    total_scenes = SCENES_PER_BATCH if world == 1 else 512          # configs[1] / configs[2]
+    total_scenes = SCENES_PER_BATCH if world == 1 else max(512, SCENES_PER_BATCH * world)   # configs[1] / configs[2]
     lo, hi = dist.owned_scenes(total_scenes, rank, world)
     gen = torch.Generator().manual_seed(100 + rank)
     lat = (torch.randn(hi - lo, L, generator=gen) / math.sqrt(L)).to(dev)
@@ -194,7 +198,7 @@ def main():
                                     "weight-norm, dropout 0.2, 16384 pts/step, fp32" if world == 1 else
                                     f"configs[2]: 512 scenes sharded over {world} ranks, 16384 pts/step/rank, RCCL all-reduce of "
                                     "decoder grads"),
-                       "points_per_step_per_gpu": n_local, "parallelism": f"dp{world}", "final_loss": loss},
+                       "points_per_step_per_gpu": n_local, "headline_config": SCENES_PER_BATCH == 64, "parallelism": f"dp{world}", "final_loss": loss},
             "roofline": roofline, "cpu_baseline": cpu}))
 
 
