@@ -87,6 +87,9 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64; it must be in the process BEFORE our library is dlopen'ed so that both use
+    # ONE HIP runtime (loaded the other way round, ours binds /opt/rocm's copy and sees "no ROCm-capable device")
+    import torch  # noqa: F401
     if not os.path.exists(LIB):
         raise DsdfError(f"{LIB} is missing: build it with `python -m deepsdf_amd.build` "
                         "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
