@@ -186,3 +186,21 @@ def test_batched_reconstruction_matches_single():
     for b in range(B):
         z1, _ = reconstruct(eng, xyz[b:b + 1], sdf[b:b + 1], num_iterations=20, z0=z0[b:b + 1])
         assert rel_err(zb[b:b + 1].cpu(), z1.cpu()) <= 1e-5
+
+
+def test_reconstruct_cli_writes_codes(tmp_path):
+    """reconstruct.py on an experiment trained by the drop-in trainer: codes land where deep_sdf/workspace.py:137-149 says."""
+    import subprocess, sys
+    from deepsdf_amd import train
+    exp = _make_experiment(str(tmp_path), 4)
+    torch.manual_seed(1)
+    train.main_function(exp, None, 1)
+    root = os.path.dirname(exp)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "reconstruct.py"),
+                        "-e", exp, "-c", "latest", "-d", os.path.join(root, "data"), "-s", os.path.join(root, "split.json"),
+                        "--iters", "30", "--samples", "1024"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = os.path.join(exp, "Reconstructions", "6", "Codes", "synth", "spheres")
+    assert sorted(os.listdir(d)) == ["s0.pth", "s1.pth", "s2.pth", "s3.pth"]
+    code = torch.load(os.path.join(d, "s0.pth"), weights_only=True)
+    assert code.shape == (1, 1, 4) and bool(torch.isfinite(code).all())
