@@ -9,6 +9,7 @@ b = np.stack([d[:, 2 + 3*l] - d[:, 1 + 3*l] for l in range(nl)], 1)             
 e = np.stack([d[:, 3 + 3*l] - d[:, 2 + 3*l] for l in range(nl)], 1)                               # epilogue
 tot = d[:, 3*nl] - d[:, 0]
 np.set_printoptions(linewidth=200)
+print("prologue: start->rows %s  rows->slab ready %s" % (np.median(d[:, 61] - d[:, 62]), np.median(d[:, 0] - d[:, 61])))
 print("k-loop median per layer :", np.median(k, 0))
 print("k-loop max per layer    :", k.max(0))
 print("barrier median per layer:", np.median(b, 0))

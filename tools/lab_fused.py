@@ -13,7 +13,9 @@ spec = NetSpec(256, **NET)
 eng = Engine(spec, "cuda")
 eng.init_like_reference(torch.Generator().manual_seed(0))
 x = torch.randn(N, 259, device="cuda") * 0.1
+dirty = torch.empty(int(os.environ.get("LAB_DIRTY_MB", "0")) * 262144, device="cuda")
 def run():
+    if dirty.numel(): dirty.fill_(1.0)     # leave dirty lines in L2 / MALL in front of the forward
     if mode == "decode":
         eng.decode(x)
     else:
