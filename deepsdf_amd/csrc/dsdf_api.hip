@@ -174,17 +174,31 @@ int chip_waves() {
   }
   return waves;
 }
-DwSched dw_schedule(const DsdfNet* n, int64_t N, const int* ld_in) {
+int skip_layer(const DsdfNet* n) {
+  for (int l = 1; l < n->n_layers - 1; ++l)
+    if ((n->skip_mask >> l) & 1) return l;
+  return -1;
+}
+// columns of layer l's input that the dW GEMM contracts over the points: all of them, or -- segment mode -- only the
+// previous layer's activations (the x0 columns of layer 0 / the skip layer are hoisted: finalize_row, kernels.hpp)
+int dw_cols(const DsdfNet* n, int l, bool segmode) {
+  if (!segmode) return n->in_dim[l];
+  if (l == 0) return 0;
+  return l == skip_layer(n) ? n->out_dim[l - 1] : n->in_dim[l];
+}
+DwSched dw_schedule(const DsdfNet* n, int64_t N, const int* ld_in, bool segmode) {
   DwSched S;
   memset(&S, 0, sizeof(S));
   const int nh = n->n_layers - 1;
   int Tfull = 0;
   for (int l = 0; l < nh; ++l) {
-    S.tiles_m[l] = (n->out_dim[l] + 127) / 128;
-    S.tiles_n[l] = (n->in_dim[l] + 127) / 128;
-    S.last_nj[l] = ((n->in_dim[l] - (S.tiles_n[l] - 1) * 128) + 31) / 32;
-    S.nfull_n[l] = S.last_nj[l] == 4 ? S.tiles_n[l] : S.tiles_n[l] - 1;
+    const int nc = dw_cols(n, l, segmode);
     S.slab[l] = rup((int64_t)n->out_dim[l] * ld_in[l], 64);
+    if (nc == 0) { S.last_nj[l] = 4; continue; }   // no items
+    S.tiles_m[l] = (n->out_dim[l] + 127) / 128;
+    S.tiles_n[l] = (nc + 127) / 128;
+    S.last_nj[l] = ((nc - (S.tiles_n[l] - 1) * 128) + 31) / 32;
+    S.nfull_n[l] = S.last_nj[l] == 4 ? S.tiles_n[l] : S.tiles_n[l] - 1;
     Tfull += S.tiles_m[l] * S.nfull_n[l];
   }
   // one K-split count for every layer: the largest that still gives every wave of the chip at most one full item
@@ -197,7 +211,7 @@ DwSched dw_schedule(const DsdfNet* n, int64_t N, const int* ld_in) {
   if (ns < 1) ns = 1;
   int nf = 0, nn = 0;
   for (int l = 0; l < nh; ++l) {
-    S.nsplit[l] = ns; S.kchunk[l] = kchunk;
+    S.nsplit[l] = S.tiles_m[l] > 0 ? ns : 0; S.kchunk[l] = kchunk;
     S.full0[l] = nf;   nf += ns * S.tiles_m[l] * S.nfull_n[l];
     S.narrow0[l] = nn; nn += S.last_nj[l] == 4 ? 0 : ns * S.tiles_m[l];
   }
@@ -218,9 +232,13 @@ struct Plan {
   size_t dpl_off[DSDF_MAX_LAYERS], mask_off[DSDF_MAX_LAYERS], cs_off[DSDF_MAX_LAYERS], dwslab_off[DSDF_MAX_LAYERS];
   int nwg;
   DwSched dw;
+  // segment mode: U[R][2][ldu] of the hoisted layers, per-workgroup xyz sums [nwg][4][ldcs] for each of them
+  int segmode, ldu, ldh;
+  long long hstride;
+  size_t hoistU_off, xsum_off[2], hs_off;   // hs: [2][maxout][ldh] x0 columns of the hoisted layers' weight gradients
 };
 
-Plan make_plan(const DsdfNet* n, int64_t N, int64_t R, bool inference) {
+Plan make_plan(const DsdfNet* n, int64_t N, int64_t R, bool inference, bool segmode = false) {
   Plan P;
   memset(&P, 0, sizeof(P));
   P.nl = n->n_layers; P.W0 = n->latent_size + n->geom_dim; P.N = (int)N; P.R = (int)R;
@@ -287,8 +305,17 @@ Plan make_plan(const DsdfNet* n, int64_t N, int64_t R, bool inference) {
     P.mask_off[l] = take((size_t)P.nwg * 256 * 16);
     P.cs_off[l] = take((size_t)P.nwg * P.ldcs * 4);
   }
-  P.dw = dw_schedule(n, N, P.ld_in);
+  P.dw = dw_schedule(n, N, P.ld_in, segmode);
   for (int l = 0; l < P.nl - 1; ++l) P.dwslab_off[l] = take((size_t)P.dw.nsplit[l] * P.dw.slab[l] * 4);
+  P.segmode = segmode ? 1 : 0;
+  if (segmode) {
+    P.ldu = P.ldcs;
+    P.hoistU_off = take((size_t)(R > 0 ? R : 1) * 2 * P.ldu * 4);
+    for (int t = 0; t < 2; ++t) P.xsum_off[t] = take((size_t)P.nwg * 4 * P.ldcs * 4);
+    P.ldh = (int)rup(n->latent_size + n->geom_dim, 4);
+    P.hstride = (long long)P.ldcs * P.ldh;
+    P.hs_off = take((size_t)2 * P.hstride * 4);
+  }
   P.total = o;
   return P;
 }
@@ -335,22 +362,6 @@ int launch_last(const LastArgs& a, int blocks, hipStream_t st) {
   else hipLaunchKernelGGL((last_layer_kernel<MODE, 8>), dim3(blocks), dim3(256), 0, st, a);
   LAUNCH_OK("last_layer_kernel");
   return 0;
-}
-
-// rows [g*P/G, (g+1)*P/G) of part[P][ld] summed into out[g][ld] (fixed order)
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* part, int P, int ld, int n, float* out, int G) {
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), ry = threadIdx.x >> 6, g = blockIdx.y;
-  const int beg = (int)((long long)g * P / G), end = (int)((long long)(g + 1) * P / G);
-  float s = 0.f;
-  if (c < n)
-    for (int r = beg + ry; r < end; r += 4) s += part[(size_t)r * ld + c];
-  red[ry][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (ry == 0 && c < n) {
-    const int x = threadIdx.x;
-    out[(size_t)g * ld + c] = (red[0][x] + red[1][x]) + (red[2][x] + red[3][x]);
-  }
 }
 
 int materialize(const DsdfNet* net, const float* params, float* packed, hipStream_t st, bool scales_ready = false) {
@@ -418,9 +429,37 @@ bool fused_eligible(const DsdfNet* net) {
 
 // all hidden layers + the last layer's forward in ONE launch (fused.hpp).  store_act: keep global copies of the
 // activations (training / module path) or not (inference).
+// Segment mode: U[s][t][:] = W_t[:, latent columns] latent_s for layer 0 (t = 0) and the skip layer (t = 1), and the
+// descriptor the fused forward needs to start its accumulators from them.
+int run_hoist(const DsdfNet* net, const Plan& P, void* ws, const float* packed, const float* table, const DsdfBatch* b,
+              FusedSeg* seg, hipStream_t st) {
+  const Packed pk = packed_layout(net);
+  const int ks = skip_layer(net);
+  HoistArgs h;
+  memset(&h, 0, sizeof(h));
+  memset(seg, 0, sizeof(*seg));
+  h.nh = ks > 0 ? 2 : 1;
+  h.W[0] = packed + pk.w_off[0]; h.ldw[0] = pk.ldw[0]; h.c0[0] = 0; h.out[0] = net->out_dim[0];
+  seg->h[0].layer = 0; seg->h[0].wx = h.W[0] + net->latent_size; seg->h[0].ldw = pk.ldw[0];
+  seg->h[1].layer = -1;
+  if (ks > 0) {
+    h.W[1] = packed + pk.w_off[ks]; h.ldw[1] = pk.ldw[ks]; h.c0[1] = net->out_dim[ks - 1]; h.out[1] = net->out_dim[ks];
+    seg->h[1].layer = ks; seg->h[1].wx = h.W[1] + h.c0[1] + net->latent_size; seg->h[1].ldw = pk.ldw[ks];
+  }
+  h.L = net->latent_size; h.seg_scene = b->seg_scene; h.table = table; h.R = (int)b->n_segments;
+  h.U = at<float>(ws, P.hoistU_off); h.ldu = P.ldu;
+  const int rows = h.out[0] + (ks > 0 ? h.out[1] : 0);
+  hipLaunchKernelGGL(seg_hoist_kernel, dim3((unsigned)((rows + 3) / 4), (unsigned)((h.R + HOIST_SC - 1) / HOIST_SC)), dim3(256), 0, st, h);
+  LAUNCH_OK("seg_hoist_kernel");
+  seg->wg_per_seg = (int)(b->seg_len / FROWS);
+  seg->xyz = b->xyz; seg->G = net->geom_dim; seg->U = h.U; seg->ldu = h.ldu;
+  return 0;
+}
+
+// seg != nullptr: segment mode (fused.hpp FusedSeg) -- x0 is not read at all, seg->h[] / seg->U come from run_hoist
 int run_fused_forward(const DsdfNet* net, const Plan& P, void* ws, const float* packed, const float* params, int64_t n,
                       int training, const uint32_t* keys, uint32_t row_offset, bool store_act, float* y_out, float* u_out,
-                      hipStream_t st) {
+                      hipStream_t st, const FusedSeg* seg = nullptr) {
   DsdfParamLayout L;
   param_layout(net, &L);
   const Packed pk = packed_layout(net);
@@ -445,7 +484,13 @@ int run_fused_forward(const DsdfNet* net, const Plan& P, void* ws, const float* 
     }
     y.x0_col = ((net->skip_mask >> (l + 1)) & 1) ? net->out_dim[l] : -1;
     y.maskbits = store_act ? at<uint32_t>(ws, P.mask_off[l]) : nullptr;
+    if (seg != nullptr) {   // hoisted x0 columns: nothing left to contract for layer 0, only the previous layer for the skip layer
+      y.x0_col = -1;
+      if (l == 0) y.in = 0;
+      else if ((net->skip_mask >> l) & 1) y.in = net->out_dim[l - 1];
+    }
   }
+  if (seg != nullptr) a.seg = *seg;
   a.w_last = packed + pk.w_off[last]; a.b_last = params + L.bias_off[last]; a.in_last = net->in_dim[last];
   a.use_tanh = net->use_tanh; a.y_out = y_out; a.u_out = u_out;
   double wmac = 0;
@@ -517,7 +562,7 @@ int run_backward(const DsdfNet* net, const Plan& P, void* ws, const float* packe
   if (want_dw) {
     const int w = P.ld_part;
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((w + 63) / 64, LAST_GROUPS), dim3(256), 0, st,
-                       at<float>(ws, P.part_off), P.last_blocks, P.ld_part, w, at<float>(ws, P.part2_off), LAST_GROUPS);
+                       ReduceRowsArgs{at<float>(ws, P.part_off), P.last_blocks, P.ld_part, w, at<float>(ws, P.part2_off), LAST_GROUPS});
     LAUNCH_OK("reduce_rows_kernel");
     FinArgs f;
     memset(&f, 0, sizeof(f));
@@ -586,9 +631,12 @@ struct FuseAdam { const DsdfAdamCfg* cfg; float* params; float* exp_avg; float* 
 
 // Backward with the fused dX chain (fused.hpp): K3's second stage + last layer finalize, ONE launch for the whole
 // dX chain (writes every dP_l, column sums, latent-gradient inputs), then dW (split-K) + finalize per layer.
+// Segment mode (sb != nullptr): what the weight gradients of the hoisted layers need from the batch
+struct SegBwd { const FusedSeg* seg; const int64_t* seg_scene; const float* table; int R; };
+
 int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float* packed, const float* params, int64_t n,
                        int training, float* grads, int accumulate, int ncols_dz, bool* used_dzB, hipStream_t st,
-                       bool want_dw, const FusedBwdHead& head, const FuseAdam* fz = nullptr) {
+                       bool want_dw, const FusedBwdHead& head, const FuseAdam* fz = nullptr, const SegBwd* sb = nullptr) {
   DsdfParamLayout L;
   param_layout(net, &L);
   const Packed pk = packed_layout(net);
@@ -598,6 +646,9 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
   memset(&a, 0, sizeof(a));
   a.N = (int)n;
   a.head = head;
+  const bool segmode = sb != nullptr;
+  const int ks = skip_layer(net);
+  if (segmode) { a.xyz = sb->seg->xyz; a.G = sb->seg->G; }
   int cnt = 0;
   double wmac = 0;
   for (int l = last - 1; l >= 0; --l) {
@@ -611,6 +662,8 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
       y.maskbits = at<uint32_t>(ws, P.mask_off[l - 1]);
       y.dp_out = at<float>(ws, P.dpl_off[l - 1]); y.ld_dp = P.ld_dp;
       y.colsum = at<float>(ws, P.cs_off[l - 1]); y.ldcs = P.ldcs;
+      if (segmode && want_dw && (l - 1 == 0 || l - 1 == ks)) y.xsum = at<float>(ws, P.xsum_off[l - 1 == 0 ? 0 : 1]);
+      if (segmode && l - 1 == 0) y.dp_out = nullptr;   // dP_0 is consumed through its column sums only
       if (skip && ncols_dz > 0) { y.dz_out = at<float>(ws, P.dzB_off); y.ldz = P.ldz; y.dz_cols = ncols_dz; *used_dzB = true; }
       y.ncols = y.mask_cols + y.dz_cols;
     } else {
@@ -625,11 +678,41 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     hipLaunchKernelGGL(fused_backward_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, a);
     LAUNCH_OK("fused_backward_kernel");
   }
-  if (want_dw) {   // second stage of the head's per-workgroup partials
-    const int w = P.ld_part;
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((w + 63) / 64, LAST_GROUPS), dim3(256), 0, st,
-                       at<float>(ws, P.part_off), P.nwg, P.ld_part, w, at<float>(ws, P.part2_off), LAST_GROUPS);
-    LAUNCH_OK("reduce_rows_kernel");
+  const ReduceRowsArgs rr{at<float>(ws, P.part_off), P.nwg, P.ld_part, P.ld_part, at<float>(ws, P.part2_off), LAST_GROUPS};
+  const int rr_bx = (P.ld_part + 63) / 64;
+  if (!segmode) {
+    if (want_dw) {   // second stage of the head's per-workgroup partials
+      hipLaunchKernelGGL(reduce_rows_kernel, dim3(rr_bx, LAST_GROUPS), dim3(256), 0, st, rr);
+      LAUNCH_OK("reduce_rows_kernel");
+    }
+  } else {   // one launch for everything that consumes only the backward's per-workgroup partials (kernels.hpp post_bwd_kernel)
+    PostBwdArgs q;
+    memset(&q, 0, sizeof(q));
+    if (want_dw) {
+      q.rr = rr; q.rr_bx = rr_bx; q.rr_n = rr_bx * LAST_GROUPS;
+      SegDwArgs& d = q.dw;
+      d.nh = ks > 0 ? 2 : 1;
+      d.cs[0] = at<float>(ws, P.cs_off[0]); d.xsum[0] = at<float>(ws, P.xsum_off[0]); d.out[0] = net->out_dim[0];
+      if (ks > 0) { d.cs[1] = at<float>(ws, P.cs_off[ks]); d.xsum[1] = at<float>(ws, P.xsum_off[1]); d.out[1] = net->out_dim[ks]; }
+      d.ldcs = P.ldcs; d.nwg = P.nwg; d.wg_per_seg = sb->seg->wg_per_seg; d.R = sb->R; d.L = net->latent_size; d.G = net->geom_dim;
+      d.seg_scene = sb->seg_scene; d.table = sb->table;
+      d.HS = at<float>(ws, P.hs_off); d.ldh = P.ldh; d.hstride = P.hstride;
+      q.dw_n = (d.out[0] + SDW_ROWS - 1) / SDW_ROWS + (ks > 0 ? (d.out[1] + SDW_ROWS - 1) / SDW_ROWS : 0);
+    }
+    SegLatArgs& g = q.lat;   // per-segment latent gradient from the column sums of dP_0 / dP_skip
+    g.cs0 = at<float>(ws, P.cs_off[0]); g.ldcs = P.ldcs; g.out0 = net->out_dim[0];
+    g.W0 = packed + pk.w_off[0]; g.ldw0 = pk.ldw[0];
+    if (ks > 0) {
+      g.csk = at<float>(ws, P.cs_off[ks]); g.outk = net->out_dim[ks];
+      g.Wk = packed + pk.w_off[ks]; g.ldwk = pk.ldw[ks]; g.koff = net->out_dim[ks - 1];
+    }
+    g.wg_per_seg = sb->seg->wg_per_seg; g.R = sb->R; g.L = net->latent_size;
+    g.seg_scene = sb->seg_scene; g.table = sb->table;
+    g.segpart = at<float>(ws, P.segpart_off); g.segnorm = at<float>(ws, P.segnorm_off);
+    q.lat_bx = sb->R;
+    const int lat_n = sb->R * ((net->latent_size + 15) / 16);
+    hipLaunchKernelGGL(post_bwd_kernel, dim3((unsigned)(q.rr_n + q.dw_n + lat_n)), dim3(256), 0, st, q);
+    LAUNCH_OK("post_bwd_kernel");
   }
   if (want_dw) {   // all dW_l = dP_l^T a_l in one launch
     DwArgs d;
@@ -641,10 +724,10 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
       y.dp = at<float>(ws, P.dpl_off[l]); y.ld_dp = P.ld_dp;
       y.act = at<float>(ws, P.in_off[l]); y.ld_act = P.ld_in[l];
       y.slabs = at<float>(ws, P.dwslab_off[l]); y.slab = P.dw.slab[l];
-      y.M = net->out_dim[l]; y.Nc = net->in_dim[l]; y.ldc = P.ld_in[l];
+      y.M = net->out_dim[l]; y.Nc = dw_cols(net, l, segmode); y.ldc = P.ld_in[l];
       y.tiles_m = P.dw.tiles_m[l]; y.tiles_n = P.dw.tiles_n[l]; y.last_nj = P.dw.last_nj[l]; y.nfull_n = P.dw.nfull_n[l];
       y.nsplit = P.dw.nsplit[l]; y.kchunk = P.dw.kchunk[l]; y.full0 = P.dw.full0[l]; y.narrow0 = P.dw.narrow0[l];
-      fl += 2.0 * (double)n * y.M * y.Nc;
+      fl += 2.0 * (double)n * y.M * net->in_dim[l];   // algorithmic (segment mode executes fewer: hoisted x0 columns)
     }
     int grid = (d.n_full + d.n_narrow + 3) / 4;
     if (grid > chip_waves() / 4) grid = chip_waves() / 4;
@@ -672,6 +755,10 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
       f.dv = grads + L.v_off[l];
       f.db = grads + L.bias_off[l];
       f.out = net->out_dim[l]; f.in = net->in_dim[l]; f.accumulate = accumulate;
+      if (segmode && (l == 0 || l == ks)) {
+        f.hoist = 1; f.lat0 = l == 0 ? 0 : net->out_dim[l - 1]; f.hW = net->latent_size + net->geom_dim; f.ldh = P.ldh;
+        f.hs = at<float>(ws, P.hs_off) + (l == 0 ? 0 : P.hstride);
+      }
       if (fz != nullptr) {
         const DsdfAdamCfg* c = fz->cfg;
         const double bc1 = 1.0 - pow((double)c->beta1, (double)c->step), bc2 = 1.0 - pow((double)c->beta2, (double)c->step);
@@ -748,7 +835,9 @@ int dsdf_workspace_bytes(const DsdfNet* net, int64_t n_points, int64_t n_segment
   TRY(validate(net));
   if (!bytes || n_points < 0 || n_segments < 0) return fail(DSDF_E_INVALID, "bad arguments");
   if (n_points > (1ll << 30)) return fail(DSDF_E_INVALID, "n_points too large");
-  *bytes = make_plan(net, n_points, n_segments, false).total;
+  const size_t a = make_plan(net, n_points, n_segments, false, false).total;
+  const size_t b = make_plan(net, n_points, n_segments, false, true).total;   // segment mode lays the workspace out differently
+  *bytes = a > b ? a : b;
   return 0;
 }
 
@@ -875,22 +964,42 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
   if (!b->seg_scene || !b->seg_offset || !b->xyz || !b->sdf_gt) return fail(DSDF_E_INVALID, "NULL batch pointer");
   if (b->n_norm <= 0) return fail(DSDF_E_INVALID, "n_norm must be positive");
   if (net->latent_size <= 0) return fail(DSDF_E_INVALID, "training needs latent_size > 0");
-  const Plan P = make_plan(net, n, R, false);
+  // Segment mode: the batch is scenes x samples with every segment a whole number of 64-row workgroups, so a workgroup
+  // sees ONE latent vector: its products with the weights are hoisted out of the per-point work (fused.hpp FusedSeg),
+  // and the latent gradient / the x0 columns of the weight gradients come from per-workgroup column sums.
+  const bool fusedb = fused_enabled() && fused_eligible(net);
+  const int skip_l = skip_layer(net);
+  const bool segsum = fusedb && b->seg_len > 0 && b->seg_len % FROWS == 0 && b->seg_len * R == n && net->n_layers > 2 &&
+                      skip_l != net->n_layers - 2 &&   // the deepest hidden layer's dP column sums live in the head's partials
+                      net->geom_dim <= FGEO && net->latent_size <= HOIST_MAXL;
+  const Plan P = make_plan(net, n, R, false, segsum);
   if (ws_bytes < P.total) return fail(DSDF_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, P.total);
   hipStream_t st = (hipStream_t)stream;
   const int Lc = net->latent_size;
 
-  if (cfg->code_bound > 0.f) {
-    hipLaunchKernelGGL(latent_renorm_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, latent_table, Lc, b->seg_scene,
-                       (int)R, cfg->code_bound);
+  if (cfg->code_bound > 0.f || !accumulate) {   // max-norm renorm of the looked-up rows + zero of the dense latent gradient
+    const long long nzero = accumulate ? 0 : (long long)n_scenes * Lc;
+    long long blocks = (R + 3) / 4, zb = (nzero + 4095) / 4096;
+    if (zb > 2048) zb = 2048;
+    if (zb > blocks) blocks = zb;
+    hipLaunchKernelGGL(latent_renorm_kernel, dim3((unsigned)blocks), dim3(256), 0, st, latent_table, Lc, b->seg_scene, (int)R,
+                       cfg->code_bound > 0.f ? cfg->code_bound : 0.f, accumulate ? nullptr : dlat, nzero);
     LAUNCH_OK("latent_renorm_kernel");
   }
-  TRY(run_gather(net, P, ws, latent_table, b, nullptr, 0, n, st));
-  if (fused_enabled() && fused_eligible(net))
+  FusedSeg seg;
+  memset(&seg, 0, sizeof(seg));
+  if (segsum) {
+    TRY(run_hoist(net, P, ws, packed, latent_table, b, &seg, st));
     TRY(run_fused_forward(net, P, ws, packed, params, n, cfg->training, cfg->dropout_key, (uint32_t)b->row_offset, true,
-                          nullptr, nullptr, st));
-  else
-    TRY(run_hidden_forward(net, P, ws, packed, params, n, cfg->training, cfg->dropout_key, (uint32_t)b->row_offset, st));
+                          nullptr, nullptr, st, &seg));
+  } else {
+    TRY(run_gather(net, P, ws, latent_table, b, nullptr, 0, n, st));
+    if (fusedb)
+      TRY(run_fused_forward(net, P, ws, packed, params, n, cfg->training, cfg->dropout_key, (uint32_t)b->row_offset, true,
+                            nullptr, nullptr, st));
+    else
+      TRY(run_hidden_forward(net, P, ws, packed, params, n, cfg->training, cfg->dropout_key, (uint32_t)b->row_offset, st));
+  }
 
   DsdfParamLayout L;
   param_layout(net, &L);
@@ -901,7 +1010,6 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
   a.a = at<float>(ws, P.in_off[last]); a.lda = P.ld_in[last]; a.in = net->in_dim[last];
   a.w = packed + pk.w_off[last]; a.b = params + L.bias_off[last]; a.n = (int)n; a.use_tanh = net->use_tanh;
   a.y_out = sdf_out; a.gt = b->sdf_gt; a.delta = cfg->clamp_dist; a.inv_n = 1.0f / (float)b->n_norm;
-  const bool fusedb = fused_enabled() && fused_eligible(net);
   a.dp_prev = at<float>(ws, P.dp_off[0]);
   a.lddp = P.ld_dp; a.mask_scale = mask_scale_of(net, last - 1, cfg->training);
   a.part_dw = at<float>(ws, P.part_off); a.ld_part = P.ld_part;
@@ -910,18 +1018,14 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
   if (!fusedb) TRY(launch_last<LAST_TRAIN>(a, P.last_blocks, st));
 
   bool used_dzB = false;
-  // segment-sum latent gradient: every segment is a whole number of 64-row workgroups
-  int skip_l = -1;
-  for (int l = 1; l < net->n_layers - 1; ++l)
-    if ((net->skip_mask >> l) & 1) skip_l = l;
-  const bool segsum = fusedb && b->seg_len > 0 && b->seg_len % FROWS == 0 && b->seg_len * R == n && net->n_layers > 2 &&
-                      skip_l != net->n_layers - 2;   // the deepest hidden layer's dP column sums live in K3's partials
   const bool want_dw = cfg->frozen_decoder == 0;
   if (fusedb) {
     FusedBwdHead h = make_head(net, P, ws, packed, params, HEAD_TRAIN, cfg->training);
     h.gt = b->sdf_gt; h.delta = cfg->clamp_dist; h.inv_n = 1.0f / (float)b->n_norm; h.y_out = sdf_out;
     const FuseAdam* use = (fz != nullptr && want_dw && !accumulate) ? fz : nullptr;
-    TRY(run_backward_fused(net, P, ws, packed, params, n, cfg->training, grads, accumulate, segsum ? 0 : Lc, &used_dzB, st, want_dw, h, use));
+    const SegBwd sb{&seg, b->seg_scene, latent_table, (int)R};
+    TRY(run_backward_fused(net, P, ws, packed, params, n, cfg->training, grads, accumulate, segsum ? 0 : Lc, &used_dzB, st, want_dw, h,
+                           use, segsum ? &sb : nullptr));
     if (use != nullptr && adam_fused) *adam_fused = 1;
   } else {
     TRY(run_backward(net, P, ws, packed, params, n, cfg->training, grads, accumulate, Lc, &used_dzB, st, want_dw));
@@ -932,36 +1036,19 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
   s.dzA = at<float>(ws, P.dzA_off); s.dzB = used_dzB ? at<float>(ws, P.dzB_off) : nullptr; s.ldz = P.ldz;
   s.seg_scene = b->seg_scene; s.seg_offset = b->seg_offset; s.R = (int)R; s.L = Lc; s.table = latent_table;
   s.segpart = at<float>(ws, P.segpart_off); s.segnorm = at<float>(ws, P.segnorm_off);
-  if (segsum) {
-    const Packed pk2 = packed_layout(net);
-    const int ks = skip_l;
-    SegLatArgs q;
-    memset(&q, 0, sizeof(q));
-    q.cs0 = at<float>(ws, P.cs_off[0]); q.ldcs = P.ldcs; q.out0 = net->out_dim[0];
-    q.W0 = packed + pk2.w_off[0]; q.ldw0 = pk2.ldw[0];
-    if (ks > 0) {
-      q.csk = at<float>(ws, P.cs_off[ks]); q.outk = net->out_dim[ks];
-      q.Wk = packed + pk2.w_off[ks]; q.ldwk = pk2.ldw[ks]; q.koff = net->out_dim[ks - 1];
-    }
-    q.wg_per_seg = (int)(b->seg_len / FROWS); q.R = (int)R; q.L = Lc;
-    q.seg_scene = b->seg_scene; q.table = latent_table; q.segpart = s.segpart; q.segnorm = s.segnorm;
-    hipLaunchKernelGGL(seg_latgrad_kernel, dim3((unsigned)R, (Lc + 15) / 16), dim3(256), 0, st, q);
-    LAUNCH_OK("seg_latgrad_kernel");
-  } else {
+  if (!segsum) {   // (segment mode: per-segment latent gradients came out of post_bwd_kernel)
     hipLaunchKernelGGL(seg_reduce_kernel, dim3((unsigned)R, (Lc + 63) / 64), dim3(256), 0, st, s);
     LAUNCH_OK("seg_reduce_kernel");
   }
-  if (!accumulate) HIP_OK(hipMemsetAsync(dlat, 0, (size_t)n_scenes * Lc * sizeof(float), st));
   ScatterArgs sc;
   memset(&sc, 0, sizeof(sc));
   sc.segpart = s.segpart; sc.segnorm = s.segnorm; sc.seg_scene = b->seg_scene; sc.seg_offset = b->seg_offset;
   sc.R = (int)R; sc.L = Lc; sc.table = latent_table; sc.dlat = dlat;
-  sc.creg = cfg->reg_coef / (float)b->n_norm; sc.reg_loss = at<float>(ws, P.regloss_off);
-  hipLaunchKernelGGL(seg_scatter_kernel, dim3((unsigned)R), dim3(256), 0, st, sc);
+  sc.creg = cfg->reg_coef / (float)b->n_norm;
+  sc.part_loss = at<float>(ws, P.partloss_off); sc.n_part = fusedb ? P.nwg : P.last_blocks;
+  sc.loss_scale = 1.0f / (float)b->n_norm; sc.loss_out = loss_out; sc.accumulate = accumulate;
+  hipLaunchKernelGGL(seg_scatter_kernel, dim3((unsigned)R), dim3(256), 0, st, sc);   // + the loss (block 0)
   LAUNCH_OK("seg_scatter_kernel");
-  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, at<float>(ws, P.partloss_off), fusedb ? P.nwg : P.last_blocks,
-                     1.0f / (float)b->n_norm, at<float>(ws, P.regloss_off), loss_out, accumulate);
-  LAUNCH_OK("loss_finish_kernel");
   return 0;
 }
 }  // namespace

@@ -39,9 +39,29 @@ struct FusedLayer {
   uint32_t* maskbits;              // [n_wg][256 threads][4]: bit (32 m + 16 (ni&1) + reg) of word 2m + (ni>>1) = output > 0; or nullptr
 };
 
+// Segment mode (training batches in the reference's scenes x samples layout, every 64-row workgroup inside ONE scene):
+// x0 = [latent_s | xyz] enters layer 0 and the skip layer only through  W[:, lat] latent_s + W[:, xyz] xyz,  and the
+// first term is the same for every point of the scene.  It is computed ONCE per scene (seg_hoist_kernel, kernels.hpp)
+// and enters as the initial value of the accumulators, together with the 3-term xyz product done on the VALU:
+// layer 0 needs no MFMA pass at all, the skip layer contracts only the previous layer's columns, and x0 is never
+// gathered, stored or re-read (the backward side mirrors this: dwstream.hpp / finalize_row in kernels.hpp).
+constexpr int FHOIST = 2;          // hoisted layers: layer 0 and (optionally) the one skip layer
+constexpr int FGEO = 4;            // xyz columns carried per point (geom_dim <= 4)
+struct FusedHoist {
+  int layer;                       // hidden-layer index, -1 = unused slot
+  const float* wx; int ldw;        // &W[0][first xyz column] of the row-major weight [out][ldw]
+};
+struct FusedSeg {
+  int wg_per_seg;                  // > 0: segment mode
+  const float* xyz; int G;         // [N][G]
+  const float* U; int ldu;         // [R][FHOIST][ldu]: W[:, lat] latent_s of each hoisted layer (no bias)
+  FusedHoist h[FHOIST];
+};
+
 struct FusedFwdArgs {
   int n_hidden, N, W0;
-  const float* x0; int ldx0;       // [N][ldx0] = in[0]
+  const float* x0; int ldx0;       // [N][ldx0] = in[0] (general mode)
+  FusedSeg seg;
   uint32_t row_offset;
   FusedLayer ly[DSDF_MAX_LAYERS];
   // last layer (out_dim 1): u = <a, w> + b, y = tanh(tanh?(u))
@@ -271,16 +291,70 @@ __device__ __forceinline__ void fused_zero_pad(float* S, int nin) {   // columns
   for (int i = threadIdx.x; i < FROWS * zc; i += 256) S[(i / zc) * FLD + nin + (i % zc)] = 0.f;
 }
 
+// accumulators of a hoisted layer start at  U_s[col] + <xyz[row], W[col, xyz]>  (all operands staged in LDS)
+__device__ __forceinline__ void fused_hoist_init(f32x16 (&acc)[2][4], const float* hu, const float4* hwx, const float4* xs,
+                                                 int out_dim, int w, int fr, int fh) {
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {   // one n-tile at a time (few live registers); the xyz rows are re-read from LDS (broadcast)
+    const int col = 32 * (w + 4 * ni) + fr;
+    const bool ok = col < out_dim;
+    const float ub = ok ? hu[col] : 0.f;
+    const float4 wq = ok ? hwx[col] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float4 x = xs[32 * m + crow(r) + 4 * fh];
+        acc[m][ni][r] = fmaf(x.w, wq.w, fmaf(x.z, wq.z, fmaf(x.y, wq.y, fmaf(x.x, wq.x, ub))));
+      }
+  }
+}
+
 __global__ __launch_bounds__(256, 2) void fused_forward_kernel(const FusedFwdArgs p) {
   __shared__ __attribute__((aligned(16))) float S[FROWS * FLD];
+  __shared__ float4 xs[FROWS];                       // segment mode: xyz of the 64 points (zero padded)
+  __shared__ float hu[FHOIST][FMAXW];                // segment mode: U_s of the hoisted layers
+  __shared__ float4 hwx[FHOIST][FMAXW];              //               and their xyz weight columns
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int row0 = blockIdx.x * FROWS;
+  const bool segm = p.seg.wg_per_seg > 0;
 
   FusedBSets PB;
-  fused_prefetch_b(PB, p.ly[0].wf, p.ly[0].U, w, lane, fused_nact(p.ly[0].out_dim, w), (p.ly[0].in + 15) >> 4);
-  fused_load_x0(S, p.x0, p.ldx0, p.W0, row0, p.N, 0);
-  fused_zero_pad(S, p.W0);
+  const int lfirst = (segm && p.n_hidden > 1) ? 1 : 0;   // first layer with an MFMA pass (segment mode: layer 0 has none)
+  fused_prefetch_b(PB, p.ly[lfirst].wf, p.ly[lfirst].U, w, lane, fused_nact(p.ly[lfirst].out_dim, w), (p.ly[lfirst].in + 15) >> 4);
+  if (segm) {
+    if (tid < FROWS) {
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + tid < p.N) {
+        const float* q = p.seg.xyz + (size_t)(row0 + tid) * p.seg.G;
+        x.x = q[0];
+        if (p.seg.G > 1) x.y = q[1];
+        if (p.seg.G > 2) x.z = q[2];
+        if (p.seg.G > 3) x.w = q[3];
+      }
+      xs[tid] = x;
+    }
+    const int sidx = blockIdx.x / p.seg.wg_per_seg;
+#pragma unroll
+    for (int t = 0; t < FHOIST; ++t) {
+      const FusedHoist& H = p.seg.h[t];
+      if (H.layer < 0) continue;
+      const int od = p.ly[H.layer].out_dim;
+      for (int c = tid; c < od; c += 256) {
+        hu[t][c] = p.seg.U[((size_t)sidx * FHOIST + t) * p.seg.ldu + c];
+        const float* q = H.wx + (size_t)c * H.ldw;
+        float4 x = make_float4(q[0], 0.f, 0.f, 0.f);
+        if (p.seg.G > 1) x.y = q[1];
+        if (p.seg.G > 2) x.z = q[2];
+        if (p.seg.G > 3) x.w = q[3];
+        hwx[t][c] = x;
+      }
+    }
+  } else {
+    fused_load_x0(S, p.x0, p.ldx0, p.W0, row0, p.N, 0);
+    fused_zero_pad(S, p.W0);
+  }
   __syncthreads();
 #ifdef DSDF_LAB
   if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 0] = __builtin_amdgcn_s_memtime();
@@ -288,14 +362,20 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(const FusedFwdArg
 
   for (int l = 0; l < p.n_hidden; ++l) {
     const FusedLayer& L = p.ly[l];
-    const int nu = (L.in + 15) >> 4;
+    const int nu = (L.in + 15) >> 4;   // segment mode: 0 for layer 0, only the previous layer's columns for the skip layer
     f32x16 acc[2][4];
+    int hidx = -1;
+    if (segm) hidx = l == p.seg.h[0].layer ? 0 : (l == p.seg.h[1].layer ? 1 : -1);
+    if (hidx >= 0) {
+      fused_hoist_init(acc, hu[hidx], hwx[hidx], xs, L.out_dim, w, fr, fh);
+    } else {
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
+        for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][ni][r] = 0.f;
+          for (int r = 0; r < 16; ++r) acc[m][ni][r] = 0.f;
+    }
     const float* bp[4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) bp[ni] = L.wf + (size_t)(w + 4 * ni) * L.U * 512 + lane * 4;
@@ -308,10 +388,12 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(const FusedFwdArg
       const int col = 32 * (w + 4 * ni) + fr;
       biasv[ni] = col < L.out_dim ? L.bias[col] : 0.f;
     }
-    fused_kloop_dispatch(acc, ap, bp, nu, fused_nact(L.out_dim, w), PB);
-    if (l + 1 < p.n_hidden) {   // next layer's first weights travel while this layer's epilogue runs
-      const FusedLayer& Ln = p.ly[l + 1];
-      fused_prefetch_b(PB, Ln.wf, Ln.U, w, lane, fused_nact(Ln.out_dim, w), (Ln.in + 15) >> 4);
+    if (nu > 0) {
+      fused_kloop_dispatch(acc, ap, bp, nu, fused_nact(L.out_dim, w), PB);
+      if (l + 1 < p.n_hidden) {   // next layer's first weights travel while this layer's epilogue runs
+        const FusedLayer& Ln = p.ly[l + 1];
+        fused_prefetch_b(PB, Ln.wf, Ln.U, w, lane, fused_nact(Ln.out_dim, w), (Ln.in + 15) >> 4);
+      }
     }
 #ifdef DSDF_LAB
     if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 1 + 3 * l] = __builtin_amdgcn_s_memtime();
@@ -379,7 +461,8 @@ struct FusedBwdLayer {
   float* dp_out; int ld_dp;        // global dP_{l-1} [N][ld_dp] (read later by the dW kernel)
   float* colsum; int ldcs;         // [n_wg][ldcs] per-workgroup column sums of dP_{l-1}
   float* dz_out; int ldz; int dz_cols;
-};
+  float* xsum;                     // segment mode, hoisted layers: [n_wg][FGEO][ldcs] per-workgroup sums of dP_{l-1}[n][c] * xyz[n][j]
+};                                 //   (= the xyz columns of that layer's weight gradient), or nullptr
 // Head of the chain = the LAST layer (out_dim 1) done in the prologue from the activation slab a_last:
 //   u = <a, w> + b ; y = tanh(tanh?(u)) ; TRAIN: clamped-L1 loss + dy (train_deep_sdf.py:493,517-521) | EXT: dy = d_sdf
 //   du = dy (1-y^2)(1-t1^2) ; dP_{last-1} = du w [a > 0] scale -> slab + global ; per-workgroup partials of
@@ -399,12 +482,14 @@ struct FusedBwdHead {
 struct FusedBwdArgs {
   int n_layers, N;                 // entries of ly[], processed in order (deepest layer first)
   const float* dp_in; int ld_in; int w_in;   // HEAD_DP_GIVEN: dP of the deepest hidden layer [N][ld_in], w_in columns
+  const float* xyz; int G;                   // segment mode ([N][G], G <= FGEO), else nullptr
   FusedBwdHead head;
   FusedBwdLayer ly[DSDF_MAX_LAYERS];
 };
 
+template <bool XS>
 __device__ __forceinline__ void fused_bwd_epilogue(const f32x16 (&acc)[2][4], float* S, const FusedBwdLayer& L, int w, int fr,
-                                                   int fh, int row0, int N, const uint4 mq) {
+                                                   int fh, int row0, int N, const uint4 mq, const float4* xs) {
   const int rows_here = min(FROWS, N - row0);
   __amdgpu_buffer_rsrc_t rdp = __builtin_amdgcn_make_buffer_rsrc(
       L.dp_out != nullptr ? (void*)(L.dp_out + (size_t)row0 * L.ld_dp) : (void*)S, 0,
@@ -418,6 +503,7 @@ __device__ __forceinline__ void fused_bwd_epilogue(const f32x16 (&acc)[2][4], fl
   for (int ni = 0; ni < 4; ++ni) {
     const int col = 32 * (w + 4 * ni) + fr;
     float cs = 0.f;
+    float4 cx = make_float4(0.f, 0.f, 0.f, 0.f);
     if (col < L.mask_cols) {
       const uint32_t voff = (uint32_t)((4 * fh) * ldb + col * 4);
       float* sp = S + (4 * fh) * FLD + col;
@@ -431,6 +517,10 @@ __device__ __forceinline__ void fused_bwd_epilogue(const f32x16 (&acc)[2][4], fl
           sp[rc * FLD] = v;
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rdp, voff, rc * ldb, FUSED_STORE_AUX);
           cs += v;
+          if constexpr (XS) {
+            const float4 x = xs[rc + 4 * fh];
+            cx.x = fmaf(v, x.x, cx.x); cx.y = fmaf(v, x.y, cx.y); cx.z = fmaf(v, x.z, cx.z); cx.w = fmaf(v, x.w, cx.w);
+          }
         }
       }
     } else if (col - L.mask_cols < L.dz_cols) {
@@ -445,14 +535,34 @@ __device__ __forceinline__ void fused_bwd_epilogue(const f32x16 (&acc)[2][4], fl
       cs += __shfl_xor(cs, 32, 64);
       if (fh == 0 && col < L.mask_cols) L.colsum[(size_t)blockIdx.x * L.ldcs + col] = cs;
     }
+    if constexpr (XS) {
+      cx.x += __shfl_xor(cx.x, 32, 64); cx.y += __shfl_xor(cx.y, 32, 64);
+      cx.z += __shfl_xor(cx.z, 32, 64); cx.w += __shfl_xor(cx.w, 32, 64);
+      if (fh == 0 && col < L.mask_cols) {
+        float* q = L.xsum + (size_t)blockIdx.x * FGEO * L.ldcs + col;
+        q[0] = cx.x; q[L.ldcs] = cx.y; q[2 * L.ldcs] = cx.z; q[3 * L.ldcs] = cx.w;
+      }
+    }
   }
 }
 
 __global__ __launch_bounds__(256, 2) void fused_backward_kernel(const FusedBwdArgs p) {
   __shared__ __attribute__((aligned(16))) float S[FROWS * FLD];
+  __shared__ float4 xs[FROWS];   // segment mode: xyz of the 64 points (zero padded)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int row0 = blockIdx.x * FROWS;
+  if (p.xyz != nullptr && tid < FROWS) {
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + tid < p.N) {
+      const float* q = p.xyz + (size_t)(row0 + tid) * p.G;
+      x.x = q[0];
+      if (p.G > 1) x.y = q[1];
+      if (p.G > 2) x.z = q[2];
+      if (p.G > 3) x.w = q[3];
+    }
+    xs[tid] = x;
+  }
 
   if (p.head.mode == HEAD_DP_GIVEN) {
     fused_load_x0(S, p.dp_in, p.ld_in, p.w_in, row0, p.N, 0);
@@ -565,7 +675,8 @@ __global__ __launch_bounds__(256, 2) void fused_backward_kernel(const FusedBwdAr
       fused_prefetch_b(PB, Ln.wtf, Ln.U, w, lane, fused_nact(Ln.ncols, w), (Ln.K + 15) >> 4);
     }
     __syncthreads();
-    fused_bwd_epilogue(acc, S, L, w, fr, fh, row0, p.N, mq);
+    if (L.xsum != nullptr) fused_bwd_epilogue<true>(acc, S, L, w, fr, fh, row0, p.N, mq, xs);
+    else fused_bwd_epilogue<false>(acc, S, L, w, fr, fh, row0, p.N, mq, xs);
     fused_zero_pad(S, L.mask_cols);
     __syncthreads();
   }

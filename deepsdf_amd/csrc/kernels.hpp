@@ -12,11 +12,17 @@ constexpr int FSEG_MAXW = 512;   // widest layer of the segment-sum latent-gradi
 // K0a: max-norm renorm of every looked-up latent row, in place (torch embedding_renorm_,
 // train_deep_sdf.py:385,509).  One wave per segment; a segment whose scene already appears in an earlier
 // segment is skipped, so every distinct scene is scaled exactly once.
+// The same launch zeroes the dense latent-gradient table (nzero floats, grid-stride; nullptr: leave it).
 __global__ void latent_renorm_kernel(float* __restrict__ table, int L, const int64_t* __restrict__ seg_scene,
-                                     int R, float max_norm) {
+                                     int R, float max_norm, float* __restrict__ dlat, long long nzero) {
+  if (dlat != nullptr)
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < nzero; i += (long long)gridDim.x * blockDim.x * 4) {
+      if (i + 3 < nzero) *reinterpret_cast<float4*>(dlat + i) = make_float4(0.f, 0.f, 0.f, 0.f);   // dlat is 16-byte aligned
+      else for (long long q = i; q < nzero; ++q) dlat[q] = 0.f;
+    }
   const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (r >= R) return;
+  if (r >= R || max_norm <= 0.f) return;
   const int64_t j = seg_scene[r];
   int dup = 0;
   for (int q = lane; q < r; q += 64) dup |= (seg_scene[q] == j);
@@ -60,6 +66,141 @@ __global__ void gather_concat_kernel(const GatherArgs p) {
   for (int c = lane; c < W; c += 64) {
     const float v = c < p.L ? src_lat[c] : src_xyz[c - p.L];
     for (int d = 0; d < p.ndst; ++d) p.dst[d].ptr[(size_t)n * p.dst[d].ld + p.dst[d].col0 + c] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K0c (segment mode): the per-scene part of the layers that see x0 = [latent | xyz] (layer 0 and the skip layer),
+//   U[s][t][n] = sum_c W_t[n][c0_t + c] * latent[scene_s][c]      (deep_sdf_decoder.py:86-92 restricted to the latent columns)
+// computed once per segment instead of once per point; the fused forward starts its accumulators from it (fused.hpp).
+// One wave per weight row (its latent columns stay in registers), looping over the segments.
+constexpr int HOIST_MAXL = 512;
+constexpr int HOIST_SC = 16;               // segments per wave: all their loads are in flight together
+struct HoistArgs {
+  int nh;                                  // hoisted layers (1 or 2)
+  const float* W[2]; int ldw[2]; int c0[2]; int out[2];
+  int L; const int64_t* seg_scene; const float* table; int R;
+  float* U; int ldu;                       // [R][2][ldu]
+};
+__global__ __launch_bounds__(256) void seg_hoist_kernel(const HoistArgs p) {   // grid (rows / 4, ceil(R / HOIST_SC))
+  const int lane = threadIdx.x & 63;
+  int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int t = 0;
+  if (n >= p.out[0]) { n -= p.out[0]; t = 1; }
+  if (t >= p.nh || n >= p.out[t]) return;
+  const int s0 = blockIdx.y * HOIST_SC;
+  const float* rows[HOIST_SC];
+#pragma unroll
+  for (int q = 0; q < HOIST_SC; ++q) rows[q] = p.table + (size_t)p.seg_scene[min(s0 + q, p.R - 1)] * p.L;
+  const float* wrow = p.W[t] + (size_t)n * p.ldw[t] + p.c0[t];
+  float a[HOIST_SC];
+#pragma unroll
+  for (int q = 0; q < HOIST_SC; ++q) a[q] = 0.f;
+  for (int c = lane; c < p.L; c += 64) {
+    const float wv = wrow[c];
+    float v[HOIST_SC];
+#pragma unroll
+    for (int q = 0; q < HOIST_SC; ++q) v[q] = rows[q][c];
+#pragma unroll
+    for (int q = 0; q < HOIST_SC; ++q) a[q] = fmaf(wv, v[q], a[q]);
+  }
+#pragma unroll
+  for (int q = 0; q < HOIST_SC; ++q) {
+    const float r = wave_sum(a[q]);
+    if (lane == 0 && s0 + q < p.R) p.U[((size_t)(s0 + q) * 2 + t) * p.ldu + n] = r;
+  }
+}
+
+// K5c (segment mode): the x0 columns of the hoisted layers' weight gradients, from per-workgroup sums of the fused
+// backward instead of a GEMM over the points (x0 = [latent_s | xyz] is constant / 3 wide):
+//   HS[t][i][c]     = sum_s (sum of segment s's workgroup column sums of dP_t[:, i]) * latent[scene_s][c]     c < L
+//   HS[t][i][L + j] = sum_wg xsum_t[wg][j][i]                                                                 j < G
+// finalize_row adds HS to the row's columns [lat0, lat0 + L + G).  Block = 8 output rows x all columns; fixed order.
+constexpr int SDW_ROWS = 8;
+struct SegDwArgs {
+  int nh; const float* cs[2]; const float* xsum[2]; int out[2];   // per-workgroup sums [nwg][ldcs] / [nwg][4][ldcs]
+  int ldcs, nwg, wg_per_seg, R, L, G;
+  const int64_t* seg_scene; const float* table;
+  float* HS; int ldh; long long hstride;                          // HS[t] = HS + t * hstride, [out_t][ldh]
+};
+__device__ __forceinline__ void seg_dw_body(const SegDwArgs& p, int bidx) {
+  __shared__ __attribute__((aligned(16))) float css[64][SDW_ROWS];
+  __shared__ long long srow[64];
+  __shared__ float xred[32][SDW_ROWS][4];
+  const int tid = threadIdx.x;
+  int blk = bidx, t = 0;
+  const int b0 = (p.out[0] + SDW_ROWS - 1) / SDW_ROWS;
+  if (blk >= b0) { blk -= b0; t = 1; }
+  const int i0 = blk * SDW_ROWS;
+  const float* cs = p.cs[t];
+  const int r_ld = tid & (SDW_ROWS - 1), s_ld = tid / SDW_ROWS;   // loader mapping: 8 consecutive rows x 32 segments / slices
+  // xyz columns first (independent loads, in flight under everything else): 32 slices of the workgroups
+  float xa[4] = {0.f, 0.f, 0.f, 0.f};
+  if (i0 + r_ld < p.out[t])
+    for (int wg = s_ld; wg < p.nwg; wg += 32)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < p.G) xa[j] += p.xsum[t][((size_t)wg * 4 + j) * p.ldcs + i0 + r_ld];
+  constexpr int NC = HOIST_MAXL / 256;       // column passes of 256
+  float acc[NC][SDW_ROWS];
+#pragma unroll
+  for (int k = 0; k < NC; ++k)
+#pragma unroll
+    for (int r = 0; r < SDW_ROWS; ++r) acc[k][r] = 0.f;
+  for (int s0 = 0; s0 < p.R; s0 += 64) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int sl = s_ld + 32 * q, sg = s0 + sl;
+      float a = 0.f;
+      if (sg < p.R && i0 + r_ld < p.out[t])
+        for (int g = 0; g < p.wg_per_seg; ++g) a += cs[(size_t)(sg * p.wg_per_seg + g) * p.ldcs + i0 + r_ld];
+      css[sl][r_ld] = a;
+    }
+    if (tid < 64) srow[tid] = s0 + tid < p.R ? (long long)p.seg_scene[s0 + tid] * p.L : 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const int c = tid + 256 * k;
+      if (c < p.L) {
+        float v[64];                          // every latent value of this column for the 64 segments: one wait
+#pragma unroll
+        for (int u = 0; u < 64; ++u) v[u] = p.table[srow[u] + c];   // segments beyond R: row 0 (valid), css == 0
+#pragma unroll
+        for (int u = 0; u < 64; ++u) {
+          const float4* cq = reinterpret_cast<const float4*>(css[u]);   // broadcast 16-byte reads
+#pragma unroll
+          for (int r4 = 0; r4 < SDW_ROWS / 4; ++r4) {
+            const float4 cv = cq[r4];
+            acc[k][4 * r4 + 0] = fmaf(cv.x, v[u], acc[k][4 * r4 + 0]);
+            acc[k][4 * r4 + 1] = fmaf(cv.y, v[u], acc[k][4 * r4 + 1]);
+            acc[k][4 * r4 + 2] = fmaf(cv.z, v[u], acc[k][4 * r4 + 2]);
+            acc[k][4 * r4 + 3] = fmaf(cv.w, v[u], acc[k][4 * r4 + 3]);
+          }
+        }
+      }
+    }
+  }
+  float* hs = p.HS + (size_t)t * p.hstride;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const int c = tid + 256 * k;
+    if (c < p.L)
+#pragma unroll
+      for (int r = 0; r < SDW_ROWS; ++r)
+        if (i0 + r < p.out[t]) hs[(size_t)(i0 + r) * p.ldh + c] = acc[k][r];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) xred[s_ld][r_ld][j] = xa[j];
+  __syncthreads();
+  if (tid < SDW_ROWS * 4) {                  // fixed-order sum of the 32 slices
+    const int r = tid >> 2, j = tid & 3;
+    if (j < p.G && i0 + r < p.out[t]) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) v += xred[q][r][j];
+      hs[(size_t)(i0 + r) * p.ldh + p.L + j] = v;
+    }
   }
 }
 
@@ -269,6 +410,9 @@ struct FinArgs {
   float* sb; float* sg; float* sv;          // exp_avg_sq
   float* scale_out;                         // [out] weight-norm scale of the updated row (1 for plain layers)
   float omb1, b2, omb2, step_size, bc2_sqrt, eps;
+  // segment mode, hoisted layers (fused.hpp): columns [lat0, lat0 + hW) of the row multiply x0 = [latent_s | xyz]; their
+  // gradient comes from seg_dw_kernel's hs[out][ldh] instead of the split-K slabs (columns < lat0 still do)
+  int hoist, lat0, hW, ldh; const float* hs;
 };
 
 __device__ __forceinline__ float adam_elem(float& p, float g, float& m, float& v, const FinArgs& a) {
@@ -287,7 +431,7 @@ __device__ __forceinline__ void finalize_row(const FinArgs& p, const int i, floa
   for (int k = 0; k < MAXC; ++k) {
     const int c = tid + 256 * k;
     float s = 0.f;
-    if (c < p.in) {
+    if (c < p.in && (!p.hoist || c < p.lat0)) {
       const float* q = p.slabs + (size_t)i * p.ldc + c;
       int sp = 0;
       for (; sp + 8 <= p.nsplit; sp += 8) {  // 8 independent loads in flight, summed in fixed order
@@ -298,9 +442,22 @@ __device__ __forceinline__ void finalize_row(const FinArgs& p, const int i, floa
         for (int u = 0; u < 8; ++u) s += t[u];
       }
       for (; sp < p.nsplit; ++sp) s += q[(size_t)sp * p.slab];
-      if (p.g) { const float vv = p.v[(size_t)i * p.in + c]; dot += s * vv; ss += vv * vv; }
     }
     dwr[k] = s;
+  }
+  if (p.hoist) {   // x0 columns of a hoisted layer: computed by seg_dw_kernel
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      const int c = tid + 256 * k - p.lat0;
+      if (c >= 0 && c < p.hW) dwr[k] += p.hs[(size_t)i * p.ldh + c];
+    }
+  }
+  if (p.g) {
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      const int c = tid + 256 * k;
+      if (c < p.in) { const float vv = p.v[(size_t)i * p.in + c]; dot += dwr[k] * vv; ss += vv * vv; }
+    }
   }
   if (p.g) {
     dot = block_sum_256(dot, red);
@@ -411,11 +568,11 @@ struct SegLatArgs {
   const int64_t* seg_scene; const float* table;
   float* segpart; float* segnorm;
 };
-__global__ __launch_bounds__(256) void seg_latgrad_kernel(const SegLatArgs p) {
-  // grid (R, ceil(L/16)); block = 16 columns x 16 k-slices: 1024+ blocks of short dot products instead of 256 long ones
+__device__ __forceinline__ void seg_latgrad_body(const SegLatArgs& p, int bx, int by) {
+  // (bx, by) in (R, ceil(L/16)); block = 16 columns x 16 k-slices: 1024+ blocks of short dot products instead of 256 long ones
   __shared__ float ss[2][FSEG_MAXW];
   __shared__ float red[16][17];
-  const int r = blockIdx.x, c0 = blockIdx.y * 16, tid = threadIdx.x, cx = tid & 15, ks = tid >> 4;
+  const int r = bx, c0 = by * 16, tid = threadIdx.x, cx = tid & 15, ks = tid >> 4;
   for (int j = tid; j < p.out0; j += 256) {
     float s = 0.f;
     for (int g = 0; g < p.wg_per_seg; ++g) s += p.cs0[(size_t)(r * p.wg_per_seg + g) * p.ldcs + j];
@@ -455,7 +612,7 @@ __global__ __launch_bounds__(256) void seg_latgrad_kernel(const SegLatArgs p) {
     for (int q = 0; q < 16; ++q) s += red[q][cx];
     p.segpart[(size_t)r * p.L + col] = s;
   }
-  if (blockIdx.y == 0 && tid < 64) {
+  if (by == 0 && tid < 64) {
     const float* row = p.table + (size_t)p.seg_scene[r] * p.L;
     float q = 0.f;
     for (int c = tid; c < p.L; c += 64) { const float v = row[c]; q += v * v; }
@@ -464,13 +621,49 @@ __global__ __launch_bounds__(256) void seg_latgrad_kernel(const SegLatArgs p) {
   }
 }
 
+// rows [g*P/G, (g+1)*P/G) of part[P][ld] summed into out[g][ld] (fixed order): second stage of the head's partials
+struct ReduceRowsArgs { const float* part; int P, ld, n; float* out; int G; };
+__device__ __forceinline__ void reduce_rows_body(const ReduceRowsArgs& a, int bx, int g) {
+  __shared__ float red[4][64];
+  const int c = bx * 64 + (threadIdx.x & 63), ry = threadIdx.x >> 6;
+  const int beg = (int)((long long)g * a.P / a.G), end = (int)((long long)(g + 1) * a.P / a.G);
+  float s = 0.f;
+  if (c < a.n)
+    for (int r = beg + ry; r < end; r += 4) s += a.part[(size_t)r * a.ld + c];
+  red[ry][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (ry == 0 && c < a.n) {
+    const int x = threadIdx.x;
+    a.out[(size_t)g * a.ld + c] = (red[0][x] + red[1][x]) + (red[2][x] + red[3][x]);
+  }
+}
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const ReduceRowsArgs a) { reduce_rows_body(a, blockIdx.x, blockIdx.y); }
+
+// Segment mode: everything that consumes only the fused backward's per-workgroup partials, in ONE launch -- the head's
+// second reduction stage, the hoisted layers' x0 weight-gradient columns and the per-segment latent gradient.
+struct PostBwdArgs {
+  ReduceRowsArgs rr; int rr_bx, rr_n;        // blocks [0, rr_n): (bx, g) = (i % rr_bx, i / rr_bx)
+  SegDwArgs dw; int dw_n;                    // next dw_n blocks (0: weights frozen)
+  SegLatArgs lat; int lat_bx;                // the rest: (bx, by) = (i % lat_bx, i / lat_bx)
+};
+__global__ __launch_bounds__(256) void post_bwd_kernel(const PostBwdArgs p) {
+  int i = blockIdx.x;
+  if (i < p.rr_n) { reduce_rows_body(p.rr, i % p.rr_bx, i / p.rr_bx); return; }
+  i -= p.rr_n;
+  if (i < p.dw_n) { seg_dw_body(p.dw, i); return; }
+  i -= p.dw_n;
+  seg_latgrad_body(p.lat, i % p.lat_bx, i / p.lat_bx);
+}
+
 // K5b: dlat[scene] += sum over the segments of that scene (in segment order) of
 //   segpart[r] + reg_coef/n_norm * count_r * E/||E||.   One block per segment; the FIRST segment of a scene owns
 // the sum over all its later duplicates, so the result is deterministic and needs no atomics.
 // Block 0 also emits the regulariser loss  sum_r reg_coef/n_norm * count_r * ||E_r||  (train_deep_sdf.py:523-531).
 struct ScatterArgs {
   const float* segpart; const float* segnorm; const int64_t* seg_scene; const int64_t* seg_offset; int R; int L;
-  const float* table; float* dlat; float creg; float* reg_loss;
+  const float* table; float* dlat; float creg;
+  // block 0: loss_out (+)= sum(part_loss[0..n_part)) * loss_scale + regulariser loss
+  const float* part_loss; int n_part; float loss_scale; float* loss_out; int accumulate;
 };
 __global__ __launch_bounds__(256) void seg_scatter_kernel(const ScatterArgs p) {
   __shared__ float red[4];
@@ -481,7 +674,13 @@ __global__ __launch_bounds__(256) void seg_scatter_kernel(const ScatterArgs p) {
     if (p.creg != 0.f)
       for (int q = tid; q < p.R; q += 256) s += p.creg * (float)(p.seg_offset[q + 1] - p.seg_offset[q]) * p.segnorm[q];
     s = block_sum_256(s, red);
-    if (tid == 0) *p.reg_loss = s;
+    float d = 0.f;
+    for (int q = tid; q < p.n_part; q += 256) d += p.part_loss[q];
+    d = block_sum_256(d, red);
+    if (tid == 0) {
+      const float v = d * p.loss_scale + s;
+      *p.loss_out = p.accumulate ? *p.loss_out + v : v;
+    }
   }
   const int64_t j = p.seg_scene[r];
   if (tid == 0) dup = 0;
@@ -503,19 +702,6 @@ __global__ __launch_bounds__(256) void seg_scatter_kernel(const ScatterArgs p) {
       acc += v;
     }
     p.dlat[(size_t)j * p.L + c] += acc;
-  }
-}
-
-// loss_out (+)= sum(part_loss[0..n)) * scale + *extra
-__global__ __launch_bounds__(256) void loss_finish_kernel(const float* part, int n, float scale, const float* extra,
-                                                          float* out, int accumulate) {
-  __shared__ float red[4];
-  float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) s += part[i];
-  s = block_sum_256(s, red);
-  if (threadIdx.x == 0) {
-    float v = s * scale + (extra ? *extra : 0.f);
-    *out = accumulate ? *out + v : v;
   }
 }
 

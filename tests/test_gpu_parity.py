@@ -172,7 +172,9 @@ def test_full_size_properties():
 
 def test_train_step_fast_path_equals_two_call_path():
     """dsdf_train_step (finalize + Adam + weight-norm scales fused, gradient arena not written) == forward_backward +
-    adam_step: identical Adam arithmetic per element; only the row-norm summation order of the new scales differs."""
+    adam_step FROM THE SAME STATE: identical Adam arithmetic per element; only the row-norm summation order of the new
+    scales differs.  (The state is re-synchronised before every step: left alone, the ~1e-7 scale rounding feeds Adam's
+    early steps -- update ~ lr * g / (|g| + eps) -- and the two trajectories drift apart by ~1e-5 within three steps.)"""
     from deepsdf_amd.engine import make_segments
     L, B, S = 256, 8, 256
     net = orc.make_net(L, **BIG)
@@ -181,6 +183,11 @@ def test_train_step_fast_path_equals_two_call_path():
     lat0 = torch.randn(B, L, generator=torch.Generator().manual_seed(2)) / math.sqrt(L)
     a, b = HipTrainer(spec, params, lat0), HipTrainer(spec, params, lat0)
     for step in range(3):
+        for name in ("params", "exp_avg", "exp_avg_sq", "packed"):
+            getattr(b.eng, name).copy_(getattr(a.eng, name))
+        for name in ("lat", "lat_m", "lat_v"):
+            getattr(b, name).copy_(getattr(a, name))
+        assert b.eng.step == a.eng.step
         idx, xyz, gt = _big_batch(B, S, 300 + step)
         a.step(idx, xyz, gt, delta=0.1, code_bound=1.0, code_reg=True, lam=1e-4, epoch=150, lr=(5e-4, 1e-3), seed=5)
         sc, so = make_segments(idx.cuda())
@@ -190,9 +197,10 @@ def test_train_step_fast_path_equals_two_call_path():
         assert abs(float(a.eng.loss) - float(b.eng.loss)) <= 1e-6 * abs(float(a.eng.loss))
         pa, pb = a.params(), b.params()
         for k in pa:
-            assert rel_err(pb[k], pa[k]) <= 2e-6, (step, k)
-        assert rel_err(b.lat.cpu(), a.lat.cpu()) <= 2e-6
-        assert rel_err(b.eng.exp_avg.cpu(), a.eng.exp_avg.cpu()) <= 1e-5
+            assert rel_err(pb[k], pa[k]) <= 1e-6, (step, k)
+        assert rel_err(b.lat.cpu(), a.lat.cpu()) <= 1e-6
+        assert rel_err(b.eng.exp_avg.cpu(), a.eng.exp_avg.cpu()) <= 1e-6
+        assert rel_err(b.eng.exp_avg_sq.cpu(), a.eng.exp_avg_sq.cpu()) <= 1e-6
         assert rel_err(b.eng.packed.cpu(), a.eng.packed.cpu()) <= 2e-6       # W, W^T, fragment copies and scales
 
 
