@@ -23,7 +23,7 @@ class HipTrainer:
         self.dev = device
 
     def step(self, idx, xyz, gt, *, delta, code_bound, code_reg, lam, epoch, lr, batch_split=1, grad_clip=None,
-             seed=0, training=True, want_y=False, do_adam=True):
+             seed=0, training=True, want_y=False, do_adam=True, force_ragged=False):
         N = xyz.shape[0]
         idx, xyz, gt = idx.to(self.dev), xyz.to(self.dev).contiguous(), gt.to(self.dev).reshape(-1).contiguous()
         reg = lam * min(1, epoch / 100) if code_reg else 0.0
@@ -32,7 +32,7 @@ class HipTrainer:
                                               torch.chunk(gt, batch_split))):
             sc, so = make_segments(ic)
             lens = (so[1:] - so[:-1]).cpu()
-            seg_len = int(lens[0]) if bool((lens == lens[0]).all()) else 0
+            seg_len = int(lens[0]) if bool((lens == lens[0]).all()) and not force_ragged else 0   # 0: general (ragged) path
             y = torch.empty(xc.shape[0], device=self.dev) if want_y else None
             self.eng.train_forward_backward(self.lat, self.dlat, sc, so, xc.contiguous(), gc.contiguous(), n_norm=N,
                                             clamp_dist=delta, reg_coef=reg, code_bound=code_bound, training=training,

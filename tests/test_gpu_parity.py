@@ -83,23 +83,23 @@ BIG = dict(dims=[512] * 8, dropout=list(range(8)), dropout_prob=0.2, norm_layers
            xyz_in_all=False, use_tanh=False, latent_dropout=False, weight_norm=True, geom_dimension=3)
 
 
-def _big_batch(B, S, seed):
+def _big_batch(B, S, seed, G=3):
     gen = torch.Generator().manual_seed(seed)
     idx = torch.arange(B).repeat_interleave(S)
-    xyz = torch.rand(B * S, 3, generator=gen) * 2 - 1
-    c = (torch.rand(B, 3, generator=gen) - 0.5) * 0.6
+    xyz = torch.rand(B * S, G, generator=gen) * 2 - 1
+    c = (torch.rand(B, G, generator=gen) - 0.5) * 0.6
     r = 0.3 + 0.3 * torch.rand(B, 1, generator=gen)
     gt = (xyz - c[idx]).norm(dim=1, keepdim=True) - r[idx]
     return idx, xyz, gt
 
 
-def _safe_batch(net, st64, B, S, seed, delta, code_bound, drop_seed, margin=2e-5, relu_margin=1e-6):
+def _safe_batch(net, st64, B, S, seed, delta, code_bound, drop_seed, margin=2e-5, relu_margin=1e-6, G=3):
     """Seeded batch whose clamp / sign / ReLU decisions are robust: points with | |y|-delta | or |clamp(y)-clamp(t)|
     within `margin`, or any hidden pre-activation within `relu_margin` of 0 (decided by the float64 oracle), are
     re-drawn.  A clamp/sign flip of one point moves 1/N of the gradient (6e-5 at N=16384); ~10 ReLU flips out of 67 M
     pre-activations put BOTH fp32 implementations (HIP and the CPU oracle) 1.5e-4 from the fp64 truth.  That is
     discontinuity noise, not kernel error, so the comparison is made on a margin-safe batch."""
-    idx, xyz, gt = _big_batch(B, S, seed)
+    idx, xyz, gt = _big_batch(B, S, seed, G)
     gen = torch.Generator().manual_seed(seed + 999)
     lat = st64.latents.clone()
     orc.renorm_rows_(lat, idx, code_bound)
@@ -113,7 +113,7 @@ def _safe_batch(net, st64, B, S, seed, delta, code_bound, drop_seed, margin=2e-5
         if not bool(risky.any()):
             return idx, xyz, gt
         k = int(risky.sum())
-        xyz[risky] = torch.rand(k, 3, generator=gen) * 2 - 1
+        xyz[risky] = torch.rand(k, G, generator=gen) * 2 - 1
         gt[risky] = (torch.rand(k, 1, generator=gen) - 0.5) * 0.4
     raise RuntimeError("could not build a margin-safe batch")
 
@@ -202,6 +202,52 @@ def test_train_step_fast_path_equals_two_call_path():
         assert rel_err(b.eng.exp_avg.cpu(), a.eng.exp_avg.cpu()) <= 1e-6
         assert rel_err(b.eng.exp_avg_sq.cpu(), a.eng.exp_avg_sq.cpu()) <= 1e-6
         assert rel_err(b.eng.packed.cpu(), a.eng.packed.cpu()) <= 2e-6       # W, W^T, fragment copies and scales
+
+
+SEG_SHAPES = {
+    # segment mode (deepsdf_amd/csrc/fused.hpp FusedSeg) on shapes that are NOT the headline: widths off the 32/64 grid,
+    # latent sizes off the float4 grid, no skip layer / skip right after layer 0, 2-D geometry, chunked batches
+    "skip2_w64": dict(L=8, B=3, S=64, split=1, net=dict(dims=[64] * 4, dropout=[], dropout_prob=0.0, norm_layers=[0, 1, 2, 3],
+                                                      latent_in=[2], weight_norm=True, geom_dimension=3)),
+    "noskip_w40_L6_drop": dict(L=6, B=2, S=128, split=1, net=dict(dims=[40, 40, 40], dropout=[0, 1], dropout_prob=0.2,
+                                                                  norm_layers=[0, 1, 2], latent_in=[], weight_norm=True,
+                                                                  geom_dimension=3)),
+    "skip1_w96_split2": dict(L=20, B=4, S=64, split=2, net=dict(dims=[96] * 3, dropout=[0, 1, 2], dropout_prob=0.2,
+                                                                norm_layers=[0, 2], latent_in=[1], weight_norm=True,
+                                                                geom_dimension=3)),
+    "geom2_plain": dict(L=16, B=2, S=192, split=1, net=dict(dims=[72, 72, 72, 72], dropout=[], dropout_prob=0.0, norm_layers=[],
+                                                            latent_in=[2], weight_norm=False, geom_dimension=2)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SEG_SHAPES))
+def test_segment_mode_odd_shapes_vs_oracle(name):
+    """Two optimiser steps in segment mode (every scene a whole number of 64-point workgroups) against the float64
+    oracle, and the SAME batch through the general (ragged) path: both must meet the gradient tolerance."""
+    c = SEG_SHAPES[name]
+    L, B, S, G = c["L"], c["B"], c["S"], c["net"]["geom_dimension"]
+    net = orc.make_net(L, **c["net"])
+    spec = spec_from_meta(dict(L=L, net_specs=c["net"]))
+    params = orc.init_params(net, 31)
+    lat0 = torch.randn(B, L, generator=torch.Generator().manual_seed(32)) / math.sqrt(L)
+    lat0[1] *= 1.7 / lat0[1].norm()                      # one row above the max-norm bound
+    st64 = orc.TrainState.create({k: v.double() for k, v in params.items()}, lat0.double())
+    seg, rag = HipTrainer(spec, params, lat0), HipTrainer(spec, params, lat0)
+    for step in range(2):
+        idx, xyz, gt = _safe_batch(net, st64, B, S, 500 + step, 0.1, 1.0, 77, G=G)
+        r64 = orc.train_step(net, st64, idx, xyz.double(), gt.double(), delta=0.1, code_bound=1.0, epoch=130, seed=77,
+                             batch_split=c["split"])
+        for tr, kw in ((seg, {}), (rag, dict(force_ragged=True))):
+            rh = tr.step(idx, xyz, gt, delta=0.1, code_bound=1.0, code_reg=True, lam=1e-4, epoch=130, lr=(5e-4, 1e-3), seed=77,
+                         batch_split=c["split"], **kw)
+            assert abs(rh["loss"] - r64["loss"]) <= 1e-5 * abs(r64["loss"]), (step, kw)
+            for k in r64["grads"]:
+                assert rel_err(rh["grads"][k], r64["grads"][k]) <= GRAD_TOL, (step, k, kw)
+            assert rel_err(rh["dlat"], r64["dlat"]) <= GRAD_TOL, (step, kw)
+            P = tr.params()
+            for k in st64.params:
+                assert rel_err(P[k], st64.params[k]) <= PARAM_TOL, (step, k, kw)
+            assert rel_err(tr.lat.cpu(), st64.latents) <= PARAM_TOL, (step, kw)
 
 
 def test_fused_and_layered_paths_agree_on_ragged_batches(monkeypatch):
