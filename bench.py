@@ -172,17 +172,19 @@ def main():
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process; the value is
         # taken from the committed rocprofv3 --pmc summary (tools/pmc_traffic.sh -> profiles/) when present, else null
         traffic, traffic_src = None, None
-        tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        tfile = os.path.join(ROOT, "profiles", "r01_seg_pmc_traffic.json")
         if os.path.exists(tfile):
             tj = json.load(open(tfile))
             if dom in tj:
-                traffic, traffic_src = tj[dom]["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2)"
+                traffic, traffic_src = tj[dom]["hbm_bytes_per_launch"], "profiles/r01_seg_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2)"
         roofline = dict(bound="mfma", kernel=dom, achieved=kern[dom]["tflops"], peak=PEAK_TFLOPS, unit="TFLOP/s",
                         frac=kern[dom]["tflops"] / PEAK_TFLOPS, traffic=traffic, traffic_source=traffic_src,
                         avg_launch_us=kern[dom]["avg_us"], launches_per_step=kern[dom]["launches_per_step"],
                         step_achieved=step_tflops, step_frac=step_tflops / PEAK_TFLOPS, kernels=kern,
-                        note="achieved = executed 2*M*N*K of the kernel's launches / HIP-event time around them; "
-                             "step_* = 6*W_mac*pts/s (SURVEY 8d algorithmic FLOPs) over the un-instrumented timed region")
+                        note="achieved = ALGORITHMIC 2*pts*sum(in*out) of the hidden layers the kernel covers (the reference's "
+                             "dense formulation, SURVEY 8d) / HIP-event time around its launches; segment mode executes fewer MFMA "
+                             "FLOPs than that (per-scene latent products are hoisted, DESIGN.md 4); "
+                             "step_* = 6*W_mac*pts/s over the un-instrumented timed region")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

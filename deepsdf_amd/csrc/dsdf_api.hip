@@ -674,7 +674,12 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
   }
   a.n_layers = cnt;
   {
-    ProfScope ps(DSDF_PROF_FUSED_BWD, 2.0 * (double)n * wmac, st);
+    // algorithmic FLOPs of the dX chain (the reference back-propagates through every hidden layer down to x0); the
+    // executed count `wmac` is smaller: layer 0's dX and the skip layer's x0 columns come from column sums instead
+    double amac = 0;
+    for (int l = 0; l < last; ++l) amac += (double)net->in_dim[l] * net->out_dim[l];
+    (void)wmac;
+    ProfScope ps(DSDF_PROF_FUSED_BWD, 2.0 * (double)n * amac, st);
     hipLaunchKernelGGL(fused_backward_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, a);
     LAUNCH_OK("fused_backward_kernel");
   }

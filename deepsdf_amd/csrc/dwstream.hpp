@@ -144,7 +144,15 @@ __global__ __launch_bounds__(256, 1) void dw_stream_kernel(const DwArgs p) {
     const int local = item - L.full0;
     const int split = local / tf, tile = local - split * tf;
     const int kbeg = split * L.kchunk;
-    dw_item<4>(L, split, (tile / L.nfull_n) * 128, (tile % L.nfull_n) * 128, kbeg, min(p.N, kbeg + L.kchunk), fr, fh);
+    // the 4 waves of a workgroup take 4 consecutive tiles of one split: as a 2 x 2 block they share each operand panel
+    // pairwise through the CU's L1 (4 KB per k-step instead of 5 KB for a 1 x 4 strip)
+    int tm = tile / L.nfull_n, tn = tile - tm * L.nfull_n;
+    if (!(L.tiles_m & 1) && !(L.nfull_n & 1)) {
+      const int nbn = L.nfull_n >> 1, b = tile >> 2, i = tile & 3;
+      tm = 2 * (b / nbn) + (i >> 1);
+      tn = 2 * (b % nbn) + (i & 1);
+    }
+    dw_item<4>(L, split, tm * 128, tn * 128, kbeg, min(p.N, kbeg + L.kchunk), fr, fh);
   }
   if (p.n_narrow > 0) {
     const int used = p.n_full % nwaves;                 // waves busy in the last round of full items
