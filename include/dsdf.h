@@ -73,8 +73,10 @@ typedef struct DsdfBatch {
   int64_t n_points;           /* N of this chunk */
   int64_t n_norm;             /* loss normaliser: the FULL step's point count, also across ranks (:519) */
   int64_t row_offset;         /* index of this chunk's first point inside the step (dropout hash) */
-  int64_t seg_len;            /* > 0: EVERY segment has exactly this many points (the reference's B x S layout without
-                                 --batch_split); 0: irregular.  Enables the segment-sum latent-gradient path. */
+  int64_t seg_len;            /* > 0: EVERY segment has exactly this many points (the reference's B x S layout, also per
+                                 --batch_split chunk when chunks hold whole scenes); 0: irregular.  A multiple of 64
+                                 selects SEGMENT MODE: the per-scene latent products are computed once per scene instead
+                                 of once per point (same results up to fp32 summation order). */
 } DsdfBatch;
 
 typedef struct DsdfLossCfg {
