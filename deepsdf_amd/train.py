@@ -223,6 +223,8 @@ class FusedTrainStep:
             uniform = samples_per_scene
         else:
             idx = scene_rows.repeat_interleave(samples_per_scene)
+            if N % batch_split == 0 and (N // batch_split) % samples_per_scene == 0:
+                uniform = samples_per_scene      # every torch.chunk piece holds whole scenes: segment mode per chunk
             chunks = []
             for ic, xc, gc in zip(torch.chunk(idx, batch_split), torch.chunk(xyz, batch_split),
                                   torch.chunk(sdf_gt, batch_split)):
