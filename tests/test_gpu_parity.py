@@ -215,6 +215,10 @@ SEG_SHAPES = {
     "skip1_w96_split2": dict(L=20, B=4, S=64, split=2, net=dict(dims=[96] * 3, dropout=[0, 1, 2], dropout_prob=0.2,
                                                                 norm_layers=[0, 2], latent_in=[1], weight_norm=True,
                                                                 geom_dimension=3)),
+    # more segments than one pass of the segment-chunked kernels handles (seg_dw: 64 per pass, seg_hoist: 16 per wave)
+    "many_segments": dict(L=12, B=150, S=64, split=1, net=dict(dims=[48, 48, 48], dropout=[1], dropout_prob=0.2,
+                                                              norm_layers=[0, 1, 2], latent_in=[1], weight_norm=True,
+                                                              geom_dimension=3)),
     "geom2_plain": dict(L=16, B=2, S=192, split=1, net=dict(dims=[72, 72, 72, 72], dropout=[], dropout_prob=0.0, norm_layers=[],
                                                             latent_in=[2], weight_norm=False, geom_dimension=2)),
 }
