@@ -11,6 +11,7 @@
 #include <stdlib.h>
 
 #include "dwstream.hpp"
+#include "sample.hpp"
 #include "fused.hpp"
 #include "gemm.hpp"
 #include "kernels.hpp"
@@ -1139,6 +1140,25 @@ int dsdf_adam_latent_only(float* latent, const float* dlat, float* exp_avg, floa
   if (!latent || !dlat || !exp_avg || !exp_avg_sq || !cfg || n <= 0) return fail(DSDF_E_INVALID, "bad arguments");
   if (cfg->step < 1) return fail(DSDF_E_INVALID, "Adam step must be >= 1");
   return adam_launch(latent, dlat, exp_avg, exp_avg_sq, n, cfg->lr_latent, cfg, nullptr, (hipStream_t)stream);
+}
+
+int dsdf_sample_batch(const float* data, int32_t geom_dim, const int64_t* pos_start, const int64_t* n_pos,
+                      const int64_t* neg_start, const int64_t* n_neg, const int64_t* scene_ids, int64_t n_batch_scenes,
+                      int64_t subsample, uint64_t key, float* xyz_out, float* sdf_out, void* stream) {
+  if (!data || !pos_start || !n_pos || !neg_start || !n_neg || !scene_ids || !xyz_out || !sdf_out)
+    return fail(DSDF_E_INVALID, "NULL argument");
+  if (geom_dim < 1 || geom_dim > 16) return fail(DSDF_E_INVALID, "geom_dim %d out of range", geom_dim);
+  const int64_t S = 2 * (subsample / 2);
+  if (n_batch_scenes <= 0 || S <= 0 || n_batch_scenes * S > (1ll << 31) - 1) return fail(DSDF_E_INVALID, "bad batch shape");
+  SampleArgs a;
+  memset(&a, 0, sizeof(a));
+  a.data = data; a.row_floats = geom_dim + 1; a.G = geom_dim;
+  a.pos_start = pos_start; a.n_pos = n_pos; a.neg_start = neg_start; a.n_neg = n_neg;
+  a.scene_ids = scene_ids; a.B = (int)n_batch_scenes; a.S = (int)S; a.key = key; a.xyz = xyz_out; a.sdf = sdf_out;
+  const long long tot = n_batch_scenes * S;
+  hipLaunchKernelGGL(sample_batch_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  LAUNCH_OK("sample_batch_kernel");
+  return 0;
 }
 
 int dsdf_profile_enable(int32_t on) {

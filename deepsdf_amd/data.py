@@ -110,11 +110,14 @@ class SDFSamples(torch.utils.data.Dataset):
 
 
 class DeviceSampleCache:
-    """All scenes' samples resident in HBM; balanced without-replacement subsampling on the device.
+    """All scenes' samples resident in HBM; balanced without-replacement subsampling on the device in ONE kernel launch
+    (``dsdf_sample_batch``, include/dsdf.h): the per-step replacement of the reference's DataLoader workers running
+    ``unpack_sdf_samples`` (deep_sdf/data.py:74-110) + collate (train_deep_sdf.py:483-501).
 
     Layout: one [total_rows, G+1] fp32 tensor; scene k's positives are rows [pos_start[k], pos_start[k]+n_pos[k]),
-    negatives likewise.  ``sample(scene_ids, S)`` draws, per scene, the first n of a random permutation of each sign
-    (random keys + batched sort = the reference's ``randperm(len)[:n]``) and returns xyz [B*S, G], sdf [B*S].
+    negatives likewise.  ``sample(scene_ids, S)`` returns xyz [B*S', G], sdf [B*S'] with S' = 2*(S//2): per scene S'/2
+    positives then S'/2 negatives (a shortfall of one sign is taken from the other), each drawn without replacement by
+    the keyed permutation ``oracle.sample_perm`` specifies.  GPU only: there is no CPU path.
     """
 
     def __init__(self, tensors_pos_neg, geom_dimension, device):
@@ -125,13 +128,14 @@ class DeviceSampleCache:
         for pos, neg in tensors_pos_neg:
             self.pos_start.append(off); self.n_pos.append(pos.shape[0]); off += pos.shape[0]
             self.neg_start.append(off); self.n_neg.append(neg.shape[0]); off += neg.shape[0]
-            rows += [pos, neg]
+            rows += [pos[:, :geom_dimension + 1], neg[:, :geom_dimension + 1]]
+        if max(max(self.n_pos), max(self.n_neg)) > (1 << 30):
+            raise ValueError("more than 2^30 samples of one sign in a scene")
         self.data = torch.cat(rows, 0).to(self.device, torch.float32).contiguous()
-        self.max_len = max(max(self.n_pos), max(self.n_neg))
         as_dev = lambda x: torch.tensor(x, dtype=torch.int64, device=self.device)  # noqa: E731
         self.n_pos_d, self.n_neg_d = as_dev(self.n_pos), as_dev(self.n_neg)
         self.pos_start_d, self.neg_start_d = as_dev(self.pos_start), as_dev(self.neg_start)
-        self._ar = torch.arange(self.max_len, device=self.device)
+        self._draws = 0
 
     @staticmethod
     def from_files(data_source, npzfiles, geom_dimension, device):
@@ -145,24 +149,31 @@ class DeviceSampleCache:
     def __len__(self):
         return len(self.n_pos)
 
-    def _draw(self, start, length, count, generator):
-        """For every scene b: `count[b]` distinct rows out of [start[b], start[b]+length[b]) -> list of row ids."""
-        B = start.shape[0]
-        keys = torch.rand(B, self.max_len, device=self.device, generator=generator)
-        keys.masked_fill_(self._ar[None, :] >= length[:, None], 2.0)       # invalid slots sort last
-        order = torch.argsort(keys, dim=1)
-        return order + start[:, None], count
+    def draw_key(self, generator=None):
+        """64-bit key of the next draw: the generator's seed (host value, no device sync) mixed with a draw counter."""
+        seed = generator.initial_seed() if generator is not None else 0
+        self._draws += 1
+        return ((seed * 0x9E3779B97F4A7C15) + self._draws * 0xD1B54A32D192ED03) & ((1 << 64) - 1)
 
-    def sample(self, scene_ids, subsample, generator=None):
+    def sample(self, scene_ids, subsample, generator=None, key=None):
+        """scene_ids: [B] integer tensor (CPU preferred: its values are checked on the host) -> (xyz [B*S', G], sdf [B*S'])."""
+        if self.device.type != "cuda":
+            raise RuntimeError("DeviceSampleCache.sample runs on the GPU (libdsdf_hip.so dsdf_sample_batch); there is no CPU path")
+        from . import _lib
+        from .engine import _ptr, _stream
         scene_ids = torch.as_tensor(scene_ids, dtype=torch.int64)
-        counts = [_balanced_counts(self.n_pos[k], self.n_neg[k], subsample) for k in scene_ids.tolist()]
+        S = 2 * int(subsample / 2)
+        for k in scene_ids.tolist():
+            if not 0 <= k < len(self.n_pos):
+                raise IndexError(f"scene {k} is not in the cache")
+            if self.n_pos[k] + self.n_neg[k] < S:
+                raise ValueError(f"scene {k} has {self.n_pos[k] + self.n_neg[k]} samples, fewer than the {S} requested")
+        B = scene_ids.numel()
         sid = scene_ids.to(self.device)
-        prow, _ = self._draw(self.pos_start_d[sid], self.n_pos_d[sid], None, generator)
-        nrow, _ = self._draw(self.neg_start_d[sid], self.n_neg_d[sid], None, generator)
-        if all(c == counts[0] for c in counts):      # the regular case: one gather
-            cp, cn = counts[0]
-            rows = torch.cat([prow[:, :cp], nrow[:, :cn]], 1).reshape(-1)
-        else:
-            rows = torch.cat([torch.cat([prow[b, :cp], nrow[b, :cn]]) for b, (cp, cn) in enumerate(counts)])
-        smp = self.data.index_select(0, rows)
-        return smp[:, :self.G].contiguous(), smp[:, self.G].contiguous()
+        xyz = torch.empty(B * S, self.G, dtype=torch.float32, device=self.device)
+        sdf = torch.empty(B * S, dtype=torch.float32, device=self.device)
+        key = self.draw_key(generator) if key is None else int(key) & ((1 << 64) - 1)
+        _lib.check(_lib.lib().dsdf_sample_batch(_ptr(self.data), self.G, _ptr(self.pos_start_d), _ptr(self.n_pos_d),
+                                                _ptr(self.neg_start_d), _ptr(self.n_neg_d), _ptr(sid), B, int(subsample), key,
+                                                _ptr(xyz), _ptr(sdf), _stream()))
+        return xyz, sdf

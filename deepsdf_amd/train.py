@@ -197,6 +197,44 @@ def append_parameter_magnitudes(param_mag_log, decoder):
         param_mag_log.setdefault(name, []).append(param.data.norm().item())
 
 
+class EpochStats:
+    """The per-epoch log values of train_deep_sdf.py:548-590 (step losses, mean latent-vector magnitude, parameter
+    magnitudes) without draining the GPU queue: they are reduced on the device, leave it in ONE asynchronous copy into
+    pinned memory, and are consumed one epoch later (`flush` before anything is saved)."""
+
+    def __init__(self, device, steps, decoder):
+        self.names = [n[7:] if n.startswith("module.") else n for n, _ in decoder.named_parameters()]
+        self.params = [p for _, p in decoder.named_parameters()]
+        self.steps = steps
+        n = steps + 1 + len(self.names)
+        self.dev = torch.empty(2, n, device=device)
+        self.host = torch.empty(2, n).pin_memory() if torch.device(device).type == "cuda" else torch.empty(2, n)
+        self.events = [torch.cuda.Event(), torch.cuda.Event()]
+        self.pending = None                                  # slot of the epoch not consumed yet
+
+    def push(self, epoch, loss_buf, latents):
+        slot = epoch & 1
+        d = self.dev[slot]
+        d[:self.steps].copy_(loss_buf[:self.steps])
+        d[self.steps] = torch.mean(torch.norm(latents.detach(), dim=1))
+        d[self.steps + 1:].copy_(torch.stack(torch._foreach_norm([p.data for p in self.params])))
+        self.host[slot].copy_(d, non_blocking=True)
+        self.events[slot].record()
+        self.pending = slot
+
+    def pop(self, loss_log, lat_mag_log, param_mag_log):
+        """Append the pending epoch (waits for its copy; a no-op when nothing is pending)."""
+        if self.pending is None:
+            return
+        slot, self.pending = self.pending, None
+        self.events[slot].synchronize()
+        h = self.host[slot]
+        loss_log.extend(h[:self.steps].tolist())
+        lat_mag_log.append(h[self.steps].clone())
+        for name, v in zip(self.names, h[self.steps + 1:].tolist()):
+            param_mag_log.setdefault(name, []).append(v)
+
+
 # ---- the fused step ---------------------------------------------------------------------------------------------
 class FusedTrainStep:
     """train_deep_sdf.py:483-545 for one batch, on the device: chunking (--batch_split), renorm + gather + forward +
@@ -378,6 +416,7 @@ def main_function(experiment_directory, continue_from, batch_split):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
         steps_per_epoch = int(t.item())
     loss_buf = torch.zeros(max(steps_per_epoch, 1), device=device)
+    stats = EpochStats(device, steps_per_epoch, decoder)
     gen = torch.Generator(device=device)
     gen.manual_seed(int(torch.initial_seed() & 0x7FFFFFFF) + 7919 * rank)
     n_norm = scene_per_batch * num_samp_per_scene * world    # loss normaliser = GLOBAL points per step (:519)
@@ -396,7 +435,8 @@ def main_function(experiment_directory, continue_from, batch_split):
             loss_buf[it:it + 1].copy_(eng.loss)
         if world > 1:
             torch.distributed.all_reduce(loss_buf)           # per-rank partial losses share the global normaliser
-        loss_log.extend(loss_buf[:steps_per_epoch].tolist())  # the epoch's only device->host sync
+        stats.pop(loss_log, lat_mag_log, param_mag_log)      # the PREVIOUS epoch's values (its copy finished long ago)
+        stats.push(epoch, loss_buf, lat)                     # this epoch's: asynchronous, consumed one epoch later
         end = time.time()
         tot_time = time.time() - start_train
         avg = tot_time / (epoch - start_epoch + 1)
@@ -408,8 +448,8 @@ def main_function(experiment_directory, continue_from, batch_split):
             logging.info(f"Finished {epoch} ({epoch}/{num_epochs}) [{epoch / num_epochs * 100:.2f}%] in {rem} ({avg:.2f}s/epoch)")
         timing_log.append(end - start)
         lr_log.append([s.get_learning_rate(epoch) for s in lr_schedules])
-        lat_mag_log.append(get_mean_latent_vector_magnitude(lat))
-        append_parameter_magnitudes(param_mag_log, decoder)
+        if epoch in checkpoints or epoch % log_frequency == 0 or epoch == num_epochs:
+            stats.pop(loss_log, lat_mag_log, param_mag_log)  # logs are complete up to this epoch before anything is saved
         if epoch in checkpoints:
             save_all(str(epoch) + ".pth", epoch)
         if epoch % log_frequency == 0:

@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define DSDF_MAX_LAYERS 16
-#define DSDF_ABI_VERSION 4
+#define DSDF_ABI_VERSION 5
 
 enum {
   DSDF_OK = 0,
@@ -174,6 +174,22 @@ typedef struct DsdfProfile {
 } DsdfProfile;
 int dsdf_profile_enable(int32_t on);
 int dsdf_profile_read(DsdfProfile* out);
+
+/* ---- per-step subsampling --------------------------------------------------------
+ * Replaces deep_sdf/data.py:74-110 unpack_sdf_samples + the DataLoader collate (train_deep_sdf.py:483-501) for
+ * samples that are resident in HBM: for each of the B scenes, S = 2*(subsample/2) rows -- subsample/2 positives and
+ * negatives drawn WITHOUT replacement (the reference's torch.randperm(len)[:n]), a shortfall of one sign made up by
+ * the other, positives first -- gathered into xyz_out [B*S, G] / sdf_out [B*S].
+ *   data       [rows, G+1] fp32: xyz then sdf; scene k's positives are rows [pos_start[k], pos_start[k]+n_pos[k]),
+ *              its negatives [neg_start[k], ...); the four per-scene arrays are int64 on the device
+ *   scene_ids  [B] int64 (device): which scenes, in batch order
+ *   key        64-bit draw key (e.g. seed and step); the same key gives the same batch
+ * The permutation is the keyed Feistel network specified by oracle/deepsdf_oracle.py sample_perm (bit-exact).
+ * Every selected scene needs n_pos + n_neg >= S and each sign at most 2^30 rows (checked by the caller, who owns the
+ * sizes; the library cannot read device arrays on the host). */
+int dsdf_sample_batch(const float* data, int32_t geom_dim, const int64_t* pos_start, const int64_t* n_pos,
+                      const int64_t* neg_start, const int64_t* n_neg, const int64_t* scene_ids, int64_t n_batch_scenes,
+                      int64_t subsample, uint64_t key, float* xyz_out, float* sdf_out, void* stream);
 
 /* ---- building blocks (exported for the parity tests and profiling; not needed by a trainer) --------- */
 /* C[M,N] = A[M,K] * B[N,K]^T (+bias) */

@@ -498,6 +498,56 @@ def latent_step(net: Net, params, z, m, v, step, xyz, sdf_gt, *, delta, lr, l2re
 # --------------------------------------------------------------------------------------------
 # synthetic data of SURVEY 8(d): sphere SDF scenes
 # --------------------------------------------------------------------------------------------
+# Per-step subsampling: deep_sdf/data.py:74-110 unpack_sdf_samples -- per scene subsample/2
+# positive and negative rows WITHOUT replacement (torch.randperm(len)[:n]), a shortfall of one sign taken from the
+# other, positives first.  torch's Philox stream cannot be reproduced on the device, so -- like the dropout hash -- the
+# specification is an explicit keyed pseudo-random permutation; the HIP kernel (deepsdf_amd/csrc/sample.hpp) is
+# bit-exact with this restatement.
+# --------------------------------------------------------------------------------------------
+
+
+def sample_perm(i, length: int, key: int) -> np.ndarray:
+    """perm(i) for i in [0, length): 4-round Feistel network on the smallest even-bit domain >= length (at least 2 bits)
+    with cycle walking.  i: integer array; returns uint32 indices in [0, length) -- a bijection of range(length)."""
+    bits = 2
+    while bits < 32 and (1 << bits) < length:
+        bits += 1
+    bits += bits & 1
+    h = np.uint64(bits >> 1)
+    mask = np.uint64((1 << (bits >> 1)) - 1)
+    x = np.asarray(i, dtype=np.uint64).copy()
+    todo = np.ones(x.shape, dtype=bool)
+    while todo.any():
+        L, R = x[todo] >> h, x[todo] & mask
+        for r in range(4):
+            F = _lowbias32((R * np.uint64(0x9E3779B1) + np.uint64(key) + np.uint64(r * 0x85EBCA77)) & _M32) & mask
+            L, R = R, L ^ F
+        x[todo] = (L << h) | R
+        todo = x >= np.uint64(length)
+    return x.astype(np.uint32)
+
+
+def sample_key(key64: int, scene: int, sign: int) -> int:
+    """32-bit permutation key of (draw key, scene of the cache, sign: 0 positives / 1 negatives)."""
+    lo, hi = key64 & 0xFFFFFFFF, (key64 >> 32) & 0xFFFFFFFF
+    inner = int(_lowbias32((hi + ((2 * scene + sign) & 0xFFFFFFFF) * 0x9E3779B1) & 0xFFFFFFFF))
+    return int(_lowbias32(lo ^ inner))
+
+
+def sample_rows(n_pos: int, n_neg: int, subsample: int, key64: int, scene: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Row indices (into the scene's positives / negatives) of one draw: deep_sdf/data.py:83-101 with the permutation
+    above in place of torch.randperm.  len(pos) + len(neg) == 2 * (subsample // 2)."""
+    half = int(subsample / 2)
+    cp = cn = half
+    if n_pos < half:
+        cp, cn = n_pos, 2 * half - n_pos
+    elif n_neg < half:
+        cn, cp = n_neg, 2 * half - n_neg
+    return (sample_perm(np.arange(cp), n_pos, sample_key(key64, scene, 0)),
+            sample_perm(np.arange(cn), n_neg, sample_key(key64, scene, 1)))
+
+
+# --------------------------------------------------------------------------------------------
 
 
 def sphere_scene(k: int, n_points: int = 50000, unit: bool = False):

@@ -85,3 +85,35 @@ def test_errors_are_reported():
     b = C.c_size_t()
     assert lib.dsdf_workspace_bytes(C.byref(net), 10, 1, C.byref(b)) == -1
     assert b"out_dim 1" in lib.dsdf_last_error()
+
+
+def test_sample_batch_matches_the_oracle_permutation():
+    """dsdf_sample_batch (deepsdf_amd/csrc/sample.hpp) against oracle.sample_rows: the gathered rows are EXACTLY the rows
+    the specification names (integer work: bit-exact), in the reference's order (positives then negatives per scene)."""
+    from deepsdf_amd.data import DeviceSampleCache
+    from oracle import deepsdf_oracle as orc
+    sizes = [(5000, 4000), (37, 9000), (8000, 20), (129, 131), (1 << 14, 1 << 14)]
+    items, base = [], 0
+    for npos, nneg in sizes:          # a row's content encodes (scene, sign, index): xyz = (scene, index, sign), sdf = +/-(index + 1)
+        k = len(items)
+        pos = torch.stack([torch.full((npos,), float(k)), torch.arange(npos).float(), torch.zeros(npos), torch.arange(npos).float() + 1], 1)
+        neg = torch.stack([torch.full((nneg,), float(k)), torch.arange(nneg).float(), torch.ones(nneg), -(torch.arange(nneg).float() + 1)], 1)
+        items.append((pos, neg))
+    cache = DeviceSampleCache(items, 3, "cuda")
+    ids = torch.tensor([3, 0, 1, 4, 2, 0])
+    for subsample, key in ((256, 0x0123456789ABCDEF), (101, 77)):
+        xyz, sdf = cache.sample(ids, subsample, key=key)
+        S = 2 * (subsample // 2)
+        assert xyz.shape == (len(ids) * S, 3) and sdf.shape == (len(ids) * S,)
+        xyz, sdf = xyz.cpu().numpy(), sdf.cpu().numpy()
+        for b, k in enumerate(ids.tolist()):
+            p, q = orc.sample_rows(sizes[k][0], sizes[k][1], subsample, key, k)
+            blk, lab = xyz[b * S:(b + 1) * S], sdf[b * S:(b + 1) * S]
+            assert (blk[:, 0] == k).all()
+            assert np.array_equal(blk[:len(p), 1].astype(np.int64), p.astype(np.int64)) and (blk[:len(p), 2] == 0).all()
+            assert np.array_equal(blk[len(p):, 1].astype(np.int64), q.astype(np.int64)) and (blk[len(p):, 2] == 1).all()
+            assert np.array_equal(lab[:len(p)], p.astype(np.float32) + 1) and np.array_equal(lab[len(p):], -(q.astype(np.float32) + 1))
+    a = cache.sample(ids, 64, generator=torch.Generator().manual_seed(3))[0]
+    assert not torch.equal(a, cache.sample(ids, 64, generator=torch.Generator().manual_seed(3))[0])   # the draw counter advances
+    with pytest.raises(ValueError, match="fewer than"):
+        cache.sample(torch.tensor([3]), 512)

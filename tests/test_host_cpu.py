@@ -53,14 +53,34 @@ def test_data_pipeline(tmp_path, caplog):
     ds = data.SDFSamples(root, {"ds": {"cls": ["a", "b"]}}, 64, 3)
     smp, idx = ds[1]
     assert smp.shape == (64, 4) and idx == 1
-    cache = data.DeviceSampleCache.from_files(root, files[:2], 3, "cpu")
-    g = torch.Generator().manual_seed(0)
-    xyz, sdf = cache.sample(torch.tensor([0, 1, 0]), 100, generator=g)
-    assert xyz.shape == (300, 3) and sdf.shape == (300,)
-    assert int((sdf[:100] > 0).sum()) == 50 and int((sdf[100:200] > 0).sum()) == 30
-    rows = torch.cat([xyz, sdf[:, None]], 1)[:100]
-    assert torch.unique(rows, dim=0).shape[0] == 100                # without replacement
-    assert not torch.equal(cache.sample(torch.tensor([0]), 100, generator=g)[0], xyz[:100])
+    cache = data.DeviceSampleCache.from_files(root, files[:2], 3, "cpu")   # bookkeeping only: sampling is a HIP kernel
+    assert (cache.n_pos, cache.n_neg) == ([493, 30], [400, 600]) and cache.pos_start == [0, 893] and cache.neg_start == [493, 923]
+    assert cache.data.shape == (1523, 4)
+    g = torch.Generator().manual_seed(5)
+    assert cache.draw_key(g) != cache.draw_key(g)                            # a new key per draw, no device sync
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        cache.sample(torch.tensor([0, 1, 0]), 100, generator=g)
+
+
+def test_sampler_oracle_properties():
+    """oracle.sample_perm / sample_rows (the specification of deepsdf_amd/csrc/sample.hpp): a bijection for every length,
+    balanced counts with shortfall (deep_sdf/data.py:83-91), different draws for different keys, uniform coverage."""
+    from oracle import deepsdf_oracle as orc
+    for n in (1, 2, 3, 4, 5, 16, 17, 255, 256, 257, 1000, 4099):
+        assert sorted(orc.sample_perm(np.arange(n), n, 0xABCDEF01).tolist()) == list(range(n)), n
+    p, q = orc.sample_rows(10000, 9000, 257, 0x1234567890ABCDEF, 7)
+    assert len(p) == 128 and len(q) == 128 and len(set(p.tolist())) == 128 and p.max() < 10000 and q.max() < 9000
+    p, q = orc.sample_rows(30, 9000, 100, 1, 3)
+    assert len(p) == 30 and len(q) == 70 and sorted(p.tolist()) == list(range(30))
+    p, q = orc.sample_rows(9000, 12, 100, 1, 3)
+    assert len(p) == 88 and len(q) == 12
+    a = orc.sample_rows(5000, 5000, 64, 10, 0)[0]
+    assert not np.array_equal(a, orc.sample_rows(5000, 5000, 64, 11, 0)[0])      # key
+    assert not np.array_equal(a, orc.sample_rows(5000, 5000, 64, 10, 1)[0])      # scene
+    cnt = np.zeros(500)
+    for k in range(1500):
+        cnt[orc.sample_perm(np.arange(50), 500, orc.sample_key(k, 2, 1))] += 1
+    assert abs(cnt.mean() - 150) < 1e-9 and cnt.std() < 1.25 * np.sqrt(1500 * 0.1 * 0.9) and cnt.min() > 100
 
 
 def test_workspace_errors_and_dirs(tmp_path):

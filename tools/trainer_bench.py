@@ -27,6 +27,9 @@ specs = {"Description": "config 2 shape", "DataSource": os.path.join(root, "data
          "CodeRegularizationLambda": 1e-4, "CodeBound": 1.0, "LogFrequency": 10 ** 6}
 json.dump(specs, open(os.path.join(exp, "specs.json"), "w"))
 import logging; logging.disable(logging.INFO)
+specs["NumEpochs"] = 5; json.dump(specs, open(os.path.join(exp, "specs.json"), "w"))
+train.main_function(exp, None, 1); torch.cuda.synchronize()      # untimed: library load, caches, first-touch of the arenas
+specs["NumEpochs"] = epochs; json.dump(specs, open(os.path.join(exp, "specs.json"), "w"))
 t0 = time.time(); train.main_function(exp, None, 1); torch.cuda.synchronize(); t = time.time() - t0
 print(f"trainer: {epochs} epochs ({NSC//64} steps of 16384 pts each) in {t:.2f} s incl. setup")
 specs["NumEpochs"] = 3 * epochs; json.dump(specs, open(os.path.join(exp, "specs.json"), "w"))
