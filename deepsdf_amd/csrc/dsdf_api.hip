@@ -228,7 +228,7 @@ struct Plan {
   int ld_dp, ldz, ldcs, ld_part, last_blocks, nsplit, kchunk, mt;
   long long slab;
   size_t u_off, y_off, dp_off[2], dzA_off, dzB_off, slab_off, colsum_off, part_off, part2_off, partdb_off,
-      partloss_off, segpart_off, segnorm_off, regloss_off, gnorm_off, total;
+      partloss_off, segpart_off, segnorm_off, gnorm_off, total;
   // fused backward: per hidden layer l a global dP_l buffer, the forward's mask bits and per-workgroup column sums
   size_t dpl_off[DSDF_MAX_LAYERS], mask_off[DSDF_MAX_LAYERS], cs_off[DSDF_MAX_LAYERS], dwslab_off[DSDF_MAX_LAYERS];
   int nwg;
@@ -298,7 +298,6 @@ Plan make_plan(const DsdfNet* n, int64_t N, int64_t R, bool inference, bool segm
   P.partloss_off = take((size_t)P.last_blocks * 4);
   P.segpart_off = take((size_t)(R > 0 ? R : 1) * (n->latent_size > 0 ? n->latent_size : 1) * 4);
   P.segnorm_off = take((size_t)(R > 0 ? R : 1) * 4);
-  P.regloss_off = take(256);
   P.gnorm_off = take(1024 * 4);
   P.nwg = (int)((N + FROWS - 1) / FROWS);
   for (int l = 0; l < P.nl - 1; ++l) {
@@ -1107,12 +1106,28 @@ int dsdf_adam_step(const DsdfNet* net, float* params, const float* grads, float*
   hipStream_t st = (hipStream_t)stream;
   DsdfParamLayout L;
   param_layout(net, &L);
-  TRY(adam_launch(params, grads, exp_avg, exp_avg_sq, L.total, cfg->lr_decoder, cfg, cfg->grad_scale, st));
+  {   // decoder: Adam per (layer, row) + the row's new weight-norm scale in one pass
+    const Packed pk = packed_layout(net);
+    AdamRowsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nl = net->n_layers; a.p = params; a.g = grads; a.m = exp_avg; a.s = exp_avg_sq; a.scale = packed + pk.scale_off;
+    const double bc1 = 1.0 - pow((double)cfg->beta1, (double)cfg->step), bc2 = 1.0 - pow((double)cfg->beta2, (double)cfg->step);
+    a.omb1 = 1.0f - cfg->beta1; a.b2 = cfg->beta2; a.omb2 = 1.0f - cfg->beta2;
+    a.step_size = (float)((double)cfg->lr_decoder / bc1); a.bc2_sqrt = (float)sqrt(bc2); a.eps = cfg->eps; a.gscale = cfg->grad_scale;
+    int rows = 0;
+    for (int l = 0; l < net->n_layers; ++l) {
+      a.ly[l] = AdamRowsLayer{L.v_off[l], L.g_off[l], L.bias_off[l], net->out_dim[l], net->in_dim[l], rows};
+      rows += net->out_dim[l];
+    }
+    a.total_rows = rows;
+    hipLaunchKernelGGL(adam_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a);
+    LAUNCH_OK("adam_rows_kernel");
+  }
   if (n_latent_floats > 0) {
     if (!latent_table || !dlat || !lat_exp_avg || !lat_exp_avg_sq) return fail(DSDF_E_INVALID, "NULL latent argument");
     TRY(adam_launch(latent_table, dlat, lat_exp_avg, lat_exp_avg_sq, n_latent_floats, cfg->lr_latent, cfg, nullptr, st));
   }
-  return materialize(net, params, packed, st);
+  return materialize(net, params, packed, st, true);
 }
 
 int dsdf_train_step(const DsdfNet* net, float* packed, float* params, float* grads, float* exp_avg, float* exp_avg_sq,

@@ -722,6 +722,43 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// K7b: Adam on the whole decoder arena, one wave per (layer, output row) -- bias, g and the v row -- which also yields
+// the row's new weight-norm scale g / ||v|| in the same pass (same summation order as wn_scale_kernel).
+struct AdamRowsLayer { long long v_off, g_off, b_off; int out, in, row0; };   // g_off < 0: plain layer
+struct AdamRowsArgs {
+  int nl, total_rows;
+  float* p; const float* g; float* m; float* s;     // parameter / gradient / exp_avg / exp_avg_sq arenas
+  float* scale;                                     // [total_rows]
+  float omb1, b2, omb2, step_size, bc2_sqrt, eps; const float* gscale;
+  AdamRowsLayer ly[DSDF_MAX_LAYERS];
+};
+__global__ __launch_bounds__(256) void adam_rows_kernel(const AdamRowsArgs a) {
+  const int gr = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (gr >= a.total_rows) return;
+  int l = 0;
+  while (l + 1 < a.nl && gr >= a.ly[l + 1].row0) ++l;
+  const AdamRowsLayer& L = a.ly[l];
+  const int row = gr - L.row0;
+  const float gs = a.gscale ? *a.gscale : 1.f;
+  auto upd = [&](long long i) -> float {
+    const float gi = a.g[i] * gs;
+    const float mi = fmaf(a.omb1, gi - a.m[i], a.m[i]);
+    const float vi = a.b2 * a.s[i] + a.omb2 * gi * gi;
+    a.m[i] = mi; a.s[i] = vi;
+    const float pn = a.p[i] - a.step_size * (mi / (sqrtf(vi) / a.bc2_sqrt + a.eps));
+    a.p[i] = pn;
+    return pn;
+  };
+  float ss = 0.f;
+  const long long v0 = L.v_off + (long long)row * L.in;
+  for (int c = lane; c < L.in; c += 64) { const float x = upd(v0 + c); ss += x * x; }
+  ss = wave_sum(ss);
+  if (lane == 0) {
+    upd(L.b_off + row);
+    a.scale[gr] = L.g_off >= 0 ? upd(L.g_off + row) / sqrtf(ss) : 1.f;
+  }
+}
+
 // K6: global L2 norm of the decoder gradient arena (clip_grad_norm_): two deterministic stages.
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* g, long long n, float* part) {
   __shared__ float red[4];

@@ -190,13 +190,6 @@ def get_mean_latent_vector_magnitude(latent_weight):
     return torch.mean(torch.norm(latent_weight.detach(), dim=1)).cpu()
 
 
-def append_parameter_magnitudes(param_mag_log, decoder):
-    for name, param in decoder.named_parameters():
-        if len(name) > 7 and name[:7] == "module.":
-            name = name[7:]
-        param_mag_log.setdefault(name, []).append(param.data.norm().item())
-
-
 class EpochStats:
     """The per-epoch log values of train_deep_sdf.py:548-590 (step losses, mean latent-vector magnitude, parameter
     magnitudes) without draining the GPU queue: they are reduced on the device, leave it in ONE asynchronous copy into
