@@ -219,6 +219,10 @@ SEG_SHAPES = {
     "many_segments": dict(L=12, B=150, S=64, split=1, net=dict(dims=[48, 48, 48], dropout=[1], dropout_prob=0.2,
                                                               norm_layers=[0, 1, 2], latent_in=[1], weight_norm=True,
                                                               geom_dimension=3)),
+    # long segments: 64 workgroups per scene (the shipped specs go up to SamplesPerScene 16384)
+    "long_segments": dict(L=8, B=2, S=4096, split=1, net=dict(dims=[64, 64, 64], dropout=[0, 2], dropout_prob=0.2,
+                                                               norm_layers=[0, 1, 2], latent_in=[1], weight_norm=True,
+                                                               geom_dimension=3)),
     "geom2_plain": dict(L=16, B=2, S=192, split=1, net=dict(dims=[72, 72, 72, 72], dropout=[], dropout_prob=0.0, norm_layers=[],
                                                             latent_in=[2], weight_norm=False, geom_dimension=2)),
 }
