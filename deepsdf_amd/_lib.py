@@ -6,14 +6,14 @@ import os
 from .build import LIB
 
 MAX_LAYERS = 16
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class DsdfNet(C.Structure):
     _fields_ = [("n_layers", C.c_int32), ("latent_size", C.c_int32), ("geom_dim", C.c_int32),
                 ("in_dim", C.c_int32 * MAX_LAYERS), ("out_dim", C.c_int32 * MAX_LAYERS),
                 ("weight_norm_mask", C.c_uint32), ("dropout_mask", C.c_uint32), ("skip_mask", C.c_uint32),
-                ("dropout_p", C.c_float), ("use_tanh", C.c_int32)]
+                ("dropout_p", C.c_float), ("use_tanh", C.c_int32), ("fwd_bf16", C.c_int32)]
 
 
 class DsdfParamLayout(C.Structure):

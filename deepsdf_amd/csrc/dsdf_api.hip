@@ -97,6 +97,8 @@ int validate(const DsdfNet* n) {
   for (int l = 0; l < n->n_layers; ++l) {
     if (n->in_dim[l] < 1 || n->out_dim[l] < 1 || n->in_dim[l] > 2048 || n->out_dim[l] > 65536)
       return fail(DSDF_E_INVALID, "layer %d: unsupported size %d -> %d", l, n->in_dim[l], n->out_dim[l]);
+    if (n->fwd_bf16 && (n->in_dim[l] > 512 || (l < n->n_layers - 1 && n->out_dim[l] > 512)))
+      return fail(DSDF_E_INVALID, "fwd_bf16 needs every layer width <= 512 (layer %d: %d -> %d)", l, n->in_dim[l], n->out_dim[l]);
     if (l > 0) {
       const int expect = n->out_dim[l - 1] + ((n->skip_mask >> l) & 1 ? W0 : 0);
       if (n->in_dim[l] != expect) return fail(DSDF_E_INVALID, "layer %d: in_dim %d != %d", l, n->in_dim[l], expect);
@@ -113,6 +115,7 @@ struct Packed {
   int64_t scale_off;   // per-row weight-norm scales of all layers
   // fragment-ordered copies for the fused kernels: Wf (n = out, k = in), WTf (n = in, k = out)
   int64_t wf_off[DSDF_MAX_LAYERS], wtf_off[DSDF_MAX_LAYERS];
+  int64_t wfb_off[DSDF_MAX_LAYERS];   // bf16 copy of Wf (bf16 forward); offset in floats, half the size of Wf
   int uf[DSDF_MAX_LAYERS], utf[DSDF_MAX_LAYERS];   // k-units of 16 per n-tile
   int64_t total;
 };
@@ -134,6 +137,7 @@ Packed packed_layout(const DsdfNet* n) {
     p.utf[l] = 2 * ((n->out_dim[l] + 31) / 32);
     p.wf_off[l] = o;  o += ntw * p.uf[l] * 512;
     p.wtf_off[l] = o; o += ntt * p.utf[l] * 512;
+    p.wfb_off[l] = o; o += n->fwd_bf16 ? ntw * p.uf[l] * 256 : 0;
   }
   p.total = rup(o, 64);
   return p;
@@ -384,6 +388,7 @@ int materialize(const DsdfNet* net, const float* params, float* packed, hipStrea
     const bool last = l == net->n_layers - 1;
     y.Wf = last ? nullptr : packed + pk.wf_off[l];
     y.WTf = last ? nullptr : packed + pk.wtf_off[l];
+    y.Wfb = (last || !net->fwd_bf16) ? nullptr : reinterpret_cast<__bf16*>(packed + pk.wfb_off[l]);
     y.Uf = pk.uf[l]; y.UTf = pk.utf[l];
     rows += y.out;
     tiles += ((y.out + 31) / 32) * y.tcols;
@@ -471,7 +476,7 @@ int run_fused_forward(const DsdfNet* net, const Plan& P, void* ws, const float* 
   a.row_offset = row_offset;
   for (int l = 0; l < last; ++l) {
     FusedLayer& y = a.ly[l];
-    y.wf = packed + pk.wf_off[l];
+    y.wf = net->fwd_bf16 ? packed + pk.wfb_off[l] : packed + pk.wf_off[l];   // bf16 forward: the bf16 fragment copy
     y.bias = params + L.bias_off[l];
     y.out = store_act ? at<float>(ws, P.in_off[l + 1]) : nullptr;
     y.ld_out = P.ld_in[l + 1];
@@ -501,7 +506,8 @@ int run_fused_forward(const DsdfNet* net, const Plan& P, void* ws, const float* 
   if (!dbg && getenv("DSDF_LAB_DBG")) { (void)hipMalloc(&dbg, 8192 * 64 * 8); }
   a.dbg = dbg;
 #endif
-  hipLaunchKernelGGL(fused_forward_kernel, dim3((unsigned)((n + FROWS - 1) / FROWS)), dim3(256), 0, st, a);
+  if (net->fwd_bf16) hipLaunchKernelGGL(fused_forward_bf16_kernel, dim3((unsigned)((n + FROWS - 1) / FROWS)), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(fused_forward_kernel, dim3((unsigned)((n + FROWS - 1) / FROWS)), dim3(256), 0, st, a);
 #ifdef DSDF_LAB
   if (dbg && getenv("DSDF_LAB_DBG")) {
     (void)hipDeviceSynchronize();
@@ -808,6 +814,7 @@ FusedBwdHead make_head(const DsdfNet* net, const Plan& P, void* ws, const float*
 
 int check_common(const DsdfNet* net, const void* packed, const void* params, const void* ws) {
   TRY(validate(net));
+  if (net->fwd_bf16 && !fused_enabled()) return fail(DSDF_E_INVALID, "fwd_bf16 exists only in the fused kernels (DSDF_NO_FUSED is set)");
   if (!packed || !params || !ws) return fail(DSDF_E_INVALID, "NULL packed/params/workspace pointer");
   if (!aligned16(packed) || !aligned16(params) || (reinterpret_cast<uintptr_t>(ws) & 255))
     return fail(DSDF_E_INVALID, "packed/params must be 16-byte and workspace 256-byte aligned");
@@ -976,7 +983,8 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
   const int skip_l = skip_layer(net);
   const bool segsum = fusedb && b->seg_len > 0 && b->seg_len % FROWS == 0 && b->seg_len * R == n && net->n_layers > 2 &&
                       skip_l != net->n_layers - 2 &&   // the deepest hidden layer's dP column sums live in the head's partials
-                      net->geom_dim <= FGEO && net->latent_size <= HOIST_MAXL;
+                      net->geom_dim <= FGEO && net->latent_size <= HOIST_MAXL &&
+                      !net->fwd_bf16;   // the bf16 forward rounds every Linear input per point: no hoisting
   const Plan P = make_plan(net, n, R, false, segsum);
   if (ws_bytes < P.total) return fail(DSDF_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, P.total);
   hipStream_t st = (hipStream_t)stream;

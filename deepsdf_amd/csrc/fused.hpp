@@ -109,7 +109,10 @@ __device__ __forceinline__ constexpr int crow(int reg) { return (reg & 3) + 8 * 
 // Forward epilogue of one wave: bias + ReLU (+ dropout) on its 2x4 accumulators, written to the LDS slab (next
 // layer's input) and to the global activation copy.  Lean by construction: global stores are buffer stores (hardware
 // bounds check drops rows >= N and masked columns; row offsets are SCALAR), LDS stores use immediate offsets.
-template <bool DROP, bool EVEN>
+constexpr int FLDH = 520;        // slab row stride in bf16 elements (bf16 forward, fused_forward_bf16_kernel)
+
+// HS: the slab holds bf16 (row stride FLDH) instead of fp32 (row stride FLD); the global activation copy stays fp32.
+template <bool DROP, bool EVEN, bool HS = false>
 __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[2][4], const float (&biasv)[4], float* S,
                                                    const FusedLayer& L, int w, int fr, int fh, int row0, int N,
                                                    uint32_t row_offset) {
@@ -151,8 +154,14 @@ __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[2][4], co
               v1 = (hb & 0xFFFFu) >= L.drop_thr ? v1 * L.drop_scale : 0.f;
             }
           }
-          sp[rc * FLD] = v0;
-          sp[(rc + 1) * FLD] = v1;
+          if constexpr (HS) {
+            __bf16* hp = reinterpret_cast<__bf16*>(S) + (4 * fh) * FLDH + col;
+            hp[rc * FLDH] = (__bf16)v0;
+            hp[(rc + 1) * FLDH] = (__bf16)v1;
+          } else {
+            sp[rc * FLD] = v0;
+            sp[(rc + 1) * FLD] = v1;
+          }
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rsrc, voff, rc * ldb, FUSED_STORE_AUX);
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rsrc, voff, (rc + 1) * ldb, FUSED_STORE_AUX);
           mb[m] |= (v0 > 0.f ? 1u : 0u) << (2 * rp);
@@ -419,6 +428,131 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(const FusedFwdArg
 
   // last layer: 16 rows per wave, a row's `in_last` (<= 512) floats spread over the 64 lanes as two float4 chunks
   if (p.y_out == nullptr && p.u_out == nullptr) return;   // training: the backward kernel's head recomputes it from the slab
+  float4 qv[2];
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc) {
+    const int c = 4 * lane + 256 * cc;
+    qv[cc] = c < p.in_last ? *reinterpret_cast<const float4*>(p.w_last + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float blast = p.b_last[0];
+  for (int rr = 0; rr < FROWS / 4; ++rr) {
+    const int row = (FROWS / 4) * w + rr;
+    float dot = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      const int c = 4 * lane + 256 * cc;
+      if (c < p.in_last) {
+        const float4 a = *reinterpret_cast<const float4*>(S + row * FLD + c);
+        dot += a.x * qv[cc].x + a.y * qv[cc].y + a.z * qv[cc].z + a.w * qv[cc].w;
+      }
+    }
+    const float u = wave_sum(dot) + blast;
+    const float t1 = p.use_tanh ? tanhf(u) : u;
+    if (lane == 0 && row0 + row < p.N) {
+      if (p.y_out) p.y_out[row0 + row] = tanhf(t1);
+      if (p.u_out) p.u_out[row0 + row] = u;
+    }
+  }
+}
+
+// ===================================================================================================================
+// BASELINE config 5: the same forward with bf16 GEMM inputs and fp32 accumulation on v_mfma_f32_32x32x16_bf16.
+// Every hidden Linear sees its input rounded to bf16 (the slab holds bf16) and its weight rounded to bf16 (Wfb, written
+// by wn_tiles_kernel: fragment order, lane (r, h) holds k = 16u + 8h + j, j = 0..7, in ONE 16-byte load -- exactly the
+// instruction's operand layout); bias, ReLU, dropout, the stored activation copies (fp32, for the fp32 backward and dW
+// GEMMs), the 512->1 output layer and everything after it stay fp32.  Specification: oracle decoder_forward(bf16=True).
+// One k-unit of 16 is ONE MFMA per tile (32 cycles) instead of eight (512): this variant is bound by the weight stream
+// from L2, not by the matrix cores.  General mode only (x0 gathered by gather_concat_kernel).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void fused_load_x0_h(__bf16* S, const float* x0, int ldx0, int W0, int row0, int N, int col0) {
+  const int zc = (((col0 + W0) + 15) & ~15) - col0;      // columns written incl. the zero pad up to a multiple of 16
+  for (int i = threadIdx.x; i < FROWS * zc; i += 256) {
+    const int r = i / zc, c = i - r * zc;
+    float v = 0.f;
+    if (c < W0 && row0 + r < N) v = x0[(size_t)(row0 + r) * ldx0 + c];
+    S[r * FLDH + col0 + c] = (__bf16)v;
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void fused_forward_bf16_kernel(const FusedFwdArgs p) {
+  __shared__ __attribute__((aligned(16))) float S[FROWS * FLD];   // bf16 view for the hidden layers, fp32 for the output layer
+  __bf16* SH = reinterpret_cast<__bf16*>(S);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int row0 = blockIdx.x * FROWS;
+  fused_load_x0_h(SH, p.x0, p.ldx0, p.W0, row0, p.N, 0);
+  __syncthreads();
+  for (int l = 0; l < p.n_hidden; ++l) {
+    const FusedLayer& L = p.ly[l];
+    const int nu = (L.in + 15) >> 4, nact = fused_nact(L.out_dim, w);
+    const __bf16* wfb = reinterpret_cast<const __bf16*>(L.wf);
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][ni][r] = 0.f;
+    float biasv[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int col = 32 * (w + 4 * ni) + fr;
+      biasv[ni] = col < L.out_dim ? L.bias[col] : 0.f;
+    }
+    const __bf16* ap = SH + fr * FLDH + 8 * fh;
+    auto loadB = [&](bf16x8 (&b)[4], int u) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        if (ni < nact) b[ni] = *reinterpret_cast<const bf16x8*>(wfb + ((size_t)(w + 4 * ni) * L.U + u) * 512 + lane * 8);
+    };
+    bf16x8 b0[4], b1[4];
+    if (nu > 0) loadB(b0, 0);
+    for (int u = 0; u < nu; u += 2) {        // two k-units per trip: the next unit's weights are in flight under the MFMAs
+      if (u + 1 < nu) loadB(b1, u + 1);
+      {
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ap + 16 * u), a1 = *reinterpret_cast<const bf16x8*>(ap + 32 * FLDH + 16 * u);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          if (ni < nact) {
+            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0[ni], acc[0][ni], 0, 0, 0);
+            acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0[ni], acc[1][ni], 0, 0, 0);
+          }
+      }
+      if (u + 2 < nu) loadB(b0, u + 2);
+      if (u + 1 < nu) {
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ap + 16 * (u + 1)), a1 = *reinterpret_cast<const bf16x8*>(ap + 32 * FLDH + 16 * (u + 1));
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          if (ni < nact) {
+            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1[ni], acc[0][ni], 0, 0, 0);
+            acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1[ni], acc[1][ni], 0, 0, 0);
+          }
+      }
+    }
+    __syncthreads();   // every wave has finished reading the slab: it may be overwritten in place
+    const bool last_hidden = l + 1 == p.n_hidden;
+    if (L.x0_col >= 0) fused_load_x0_h(SH, p.x0, p.ldx0, p.W0, row0, p.N, L.x0_col);
+    {
+      const bool drop = L.drop_thr != 0u;
+      const bool even = ((p.row_offset + (uint32_t)row0) & 1u) == 0u;
+      if (last_hidden) {   // the output layer reads fp32: its input goes to the slab as fp32
+        if (!drop) fused_fwd_epilogue<false, true, false>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+        else if (even) fused_fwd_epilogue<true, true, false>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+        else fused_fwd_epilogue<true, false, false>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+      } else {
+        if (!drop) fused_fwd_epilogue<false, true, true>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+        else if (even) fused_fwd_epilogue<true, true, true>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+        else fused_fwd_epilogue<true, false, true>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+      }
+    }
+    if (!last_hidden && L.x0_col < 0) {      // zero pad [out_dim, roundup16) of the bf16 slab (the x0 loader pads its own end)
+      const int zc = ((L.out_dim + 15) & ~15) - L.out_dim;
+      for (int i = tid; i < FROWS * zc; i += 256) SH[(i / zc) * FLDH + L.out_dim + (i % zc)] = (__bf16)0.f;
+    }
+    __syncthreads();
+  }
+  if (p.y_out == nullptr && p.u_out == nullptr) return;   // training: the backward kernel's head recomputes it (fp32 copy)
   float4 qv[2];
 #pragma unroll
   for (int cc = 0; cc < 2; ++cc) {

@@ -211,6 +211,7 @@ __device__ __forceinline__ void seg_dw_body(const SegDwArgs& p, int bidx) {
 struct WnLayer {
   const float* v; const float* g; float* W; float* WT; int out, in, ldw, ldwt; int row0; int tile0; int tcols;
   float* Wf; float* WTf;   // fragment-ordered copies for the fused kernels (see fused.hpp), or nullptr
+  __bf16* Wfb;             // bf16 fragment-ordered copy for the bf16 forward (fused_forward_bf16_kernel), or nullptr
   int Uf, UTf;             // k-units (of 16) allocated per n-tile in Wf / WTf
 };
 struct WnAll { int nl; int total_rows; int total_tiles; float* scale; WnLayer ly[DSDF_MAX_LAYERS]; };
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) void wn_tiles_kernel(const WnAll p) {
     }
     tile[rr][tx] = w;
   }
-  if (L.WT == nullptr && L.Wf == nullptr) return;
+  if (L.WT == nullptr && L.Wf == nullptr && L.Wfb == nullptr) return;
   __syncthreads();
   if (L.WT != nullptr) {
 #pragma unroll
@@ -270,6 +271,11 @@ __global__ __launch_bounds__(256) void wn_tiles_kernel(const WnAll p) {
   if (L.Wf != nullptr) {   // B = W: n = out index (tile rows), k = in index (tile cols)
     float4 v4 = make_float4(tile[fr][kk], tile[fr][kk + 1], tile[fr][kk + 2], tile[fr][kk + 3]);
     *reinterpret_cast<float4*>(L.Wf + ((size_t)(rb * L.Uf + 2 * cb + uu) * 2 + i) * 256 + lane * 4) = v4;
+  }
+  if (L.Wfb != nullptr) {  // bf16(W), lane (r, h) holds k = 16u + 8h + j (j = 0..7) contiguously: this thread's j = 4i .. 4i+3
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    const bf16x4 h4 = {(__bf16)tile[fr][kk], (__bf16)tile[fr][kk + 1], (__bf16)tile[fr][kk + 2], (__bf16)tile[fr][kk + 3]};
+    *reinterpret_cast<bf16x4*>(L.Wfb + ((size_t)(rb * L.Uf + 2 * cb + uu) * 64 + lane) * 8 + 4 * i) = h4;
   }
   if (L.WTf != nullptr) {  // B = W^T: n = in index (tile cols), k = out index (tile rows)
     float4 v4 = make_float4(tile[kk][fr], tile[kk + 1][fr], tile[kk + 2][fr], tile[kk + 3][fr]);

@@ -32,7 +32,9 @@ class NetSpec:
     there is no silent fallback."""
 
     def __init__(self, latent_size, dims, geom_dimension, dropout=None, dropout_prob=0.0, norm_layers=(),
-                 latent_in=(), weight_norm=False, xyz_in_all=None, use_tanh=False, latent_dropout=False):
+                 latent_in=(), weight_norm=False, xyz_in_all=None, use_tanh=False, latent_dropout=False, forward_bf16=False):
+        """forward_bf16 (not a reference key; BASELINE config 5): hidden-layer forward GEMMs on bf16 MFMA with fp32
+        accumulation; backward, master weights and Adam stay fp32."""
         if xyz_in_all:
             raise NotImplementedError("xyz_in_all=True is not implemented by the HIP decoder (no shipped spec uses it)")
         if latent_dropout:
@@ -50,6 +52,7 @@ class NetSpec:
         self.latent_in = latent_in
         self.weight_norm = bool(weight_norm)
         self.use_tanh = bool(use_tanh)
+        self.forward_bf16 = bool(forward_bf16)
         d = [self.latent_size + self.geom_dimension] + self.dims + [1]
         self.n_layers = len(d) - 1
         if self.n_layers > _lib.MAX_LAYERS:
@@ -82,7 +85,7 @@ class NetSpec:
     def kwargs(self):
         return dict(dims=self.dims, geom_dimension=self.geom_dimension, dropout=self.dropout,
                     dropout_prob=self.dropout_prob, norm_layers=self.norm_layers, latent_in=self.latent_in,
-                    weight_norm=self.weight_norm, use_tanh=self.use_tanh)
+                    weight_norm=self.weight_norm, use_tanh=self.use_tanh, forward_bf16=self.forward_bf16)
 
     def c_struct(self) -> "_lib.DsdfNet":
         n = _lib.DsdfNet()
@@ -98,6 +101,7 @@ class NetSpec:
             sm |= int(self.skip[l]) << l
         n.weight_norm_mask, n.dropout_mask, n.skip_mask = wm, dm, sm
         n.dropout_p = self.dropout_prob
+        n.fwd_bf16 = int(self.forward_bf16)
         n.use_tanh = int(self.use_tanh)
         return n
 

@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define DSDF_MAX_LAYERS 16
-#define DSDF_ABI_VERSION 5
+#define DSDF_ABI_VERSION 6
 
 enum {
   DSDF_OK = 0,
@@ -50,6 +50,9 @@ typedef struct DsdfNet {
   uint32_t skip_mask;               /* bit l: layer l's input is [x || x0]  (latent_in, :88-89) */
   float dropout_p;
   int32_t use_tanh;
+  int32_t fwd_bf16;                 /* BASELINE config 5: hidden-layer forward GEMMs take bf16 inputs (weights and layer inputs
+                                       rounded to nearest-even), fp32 accumulate on v_mfma_f32_32x32x16_bf16; the output layer,
+                                       the backward pass, master weights and Adam stay fp32.  Needs every width <= 512. */
 } DsdfNet;
 
 /* Offsets (in floats) of every parameter tensor inside the decoder arena, named_parameters() order:

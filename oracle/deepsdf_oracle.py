@@ -59,6 +59,7 @@ class Net:
     layers: List[Layer]
     dropout_prob: float
     use_tanh: bool
+    forward_bf16: bool = False     # BASELINE config 5 (not a reference option): see decoder_forward
 
     @property
     def n_lin(self) -> int:
@@ -67,8 +68,8 @@ class Net:
 
 def make_net(latent_size, dims, geom_dimension, dropout=None, dropout_prob=0.0, norm_layers=(),
              latent_in=(), weight_norm=False, xyz_in_all=None, use_tanh=False,
-             latent_dropout=False) -> Net:
-    """Same constructor signature as the reference Decoder (deep_sdf_decoder.py:10-23)."""
+             latent_dropout=False, forward_bf16=False) -> Net:
+    """Same constructor signature as the reference Decoder (deep_sdf_decoder.py:10-23) (+ forward_bf16, config 5)."""
     if xyz_in_all:
         raise NotImplementedError("xyz_in_all is False in every shipped spec; not restated")
     if latent_dropout:
@@ -86,7 +87,7 @@ def make_net(latent_size, dims, geom_dimension, dropout=None, dropout_prob=0.0, 
             skip_in=l in latent_in,
             dropout=bool(dropout is not None and l in dropout and l < n_lin - 1),
         ))
-    return Net(latent_size, geom_dimension, layers, float(dropout_prob), bool(use_tanh))
+    return Net(latent_size, geom_dimension, layers, float(dropout_prob), bool(use_tanh), bool(forward_bf16))
 
 
 def param_names(net: Net) -> List[str]:
@@ -255,7 +256,13 @@ def decoder_forward(net: Net, params, x0: torch.Tensor, training: bool = False,
             x = torch.cat([x, x0], dim=1)
         sv.inputs.append(x)
         W, b = Wb[l]
-        x = x @ W.t() + b
+        if net.forward_bf16 and l < n_lin - 1:
+            # config 5: the hidden Linear's GEMM takes bf16 inputs (round to nearest even, from fp32) and accumulates wider;
+            # the saved (unrounded) input and the fp32 weight are what the backward pass uses
+            rb = lambda t: t.float().bfloat16().to(t.dtype)  # noqa: E731
+            x = rb(x) @ rb(W).t() + b
+        else:
+            x = x @ W.t() + b
         if l < n_lin - 1:
             if track_margin:
                 mn = x.abs().amin(dim=1)

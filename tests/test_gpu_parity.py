@@ -258,6 +258,45 @@ def test_segment_mode_odd_shapes_vs_oracle(name):
             assert rel_err(tr.lat.cpu(), st64.latents) <= PARAM_TOL, (step, kw)
 
 
+def test_config5_bf16_forward_vs_oracle_and_fp32():
+    """BASELINE config 5: hidden-layer forward GEMMs with bf16 inputs / fp32 accumulate (v_mfma_f32_32x32x16_bf16), backward and
+    Adam in fp32, on the 8x512 decoder at 16384 points.  Compared with (a) the oracle's bf16 emulation (same rounding
+    points; what differs is the accumulation order and the ~1e-7 differences that decide a few bf16 roundings) and (b) the
+    fp32 forward -- the tolerance the config asks to be RE-STATED: measured 2-3e-3 of the output range, asserted <= 1e-2."""
+    from deepsdf_amd.engine import Engine
+    L, B, S = 256, 64, 256
+    kw = dict(BIG)
+    net = orc.make_net(L, forward_bf16=True, **kw)
+    spec = spec_from_meta(dict(L=L, net_specs=dict(kw, forward_bf16=True)))
+    spec32 = spec_from_meta(dict(L=L, net_specs=kw))
+    params = orc.init_params(net, 5)
+    lat0 = torch.randn(B, L, generator=torch.Generator().manual_seed(6)) / math.sqrt(L)
+    # (1) inference: decode
+    x = torch.cat([lat0[torch.arange(B).repeat_interleave(S)], torch.rand(B * S, 3, generator=torch.Generator().manual_seed(7)) * 2 - 1], 1)
+    eb, e32 = Engine(spec), Engine(spec32)
+    eb.load_params(params); e32.load_params(params)
+    yb, y32 = eb.decode(x.cuda()).cpu().reshape(-1), e32.decode(x.cuda()).cpu().reshape(-1)
+    yo = orc.decoder_forward(net, params, x, training=False)[0].reshape(-1)
+    e_or, e_32 = rel_err(yb, yo), rel_err(yb, y32)
+    print(f"bf16 forward: vs oracle bf16 emulation {e_or:.2e}; vs the fp32 forward {e_32:.2e}")
+    assert e_or <= 1e-4
+    assert 1e-4 <= e_32 <= 1e-2                      # bf16 really is in the loop, and inside the re-stated tolerance
+    # (2) one optimiser step: gradients and post-Adam state against the oracle's bf16-forward step
+    st = orc.TrainState.create({k: v.clone() for k, v in params.items()}, lat0.clone())
+    st64 = orc.TrainState.create({k: v.double() for k, v in params.items()}, lat0.double())
+    idx, xyz, gt = _safe_batch(net, st64, B, S, 100, 0.1, 1.0, 4242)   # clamp/sign margins; ReLU flips cannot be excluded here:
+    ro = orc.train_step(net, st, idx, xyz, gt, delta=0.1, code_bound=1.0, epoch=57, seed=4242)
+    tr = HipTrainer(spec, params, lat0)
+    rh = tr.step(idx, xyz, gt, delta=0.1, code_bound=1.0, code_reg=True, lam=1e-4, epoch=57, lr=(5e-4, 1e-3), seed=4242)
+    assert abs(rh["loss"] - ro["loss"]) <= 1e-4 * abs(ro["loss"])
+    worst = max(rel_err(rh["grads"][k], ro["grads"][k]) for k in ro["grads"])
+    print(f"bf16 forward: max gradient rel err vs the oracle's bf16-forward step {worst:.2e}")
+    # the two bf16 forwards differ by ~1e-5 in the pre-activations (which roundings tip), so a few thousand of the 67 M ReLUs
+    # flip (fp32 mode: ~10) and each moves a gradient entry by O(1/N): discontinuity noise, measured 1-3e-3
+    assert worst <= 1e-2
+    assert rel_err(rh["dlat"], ro["dlat"]) <= 1e-2
+
+
 def test_fused_and_layered_paths_agree_on_ragged_batches(monkeypatch):
     """The two product paths (fused persistent kernels vs layer-by-layer GEMM launches, DSDF_NO_FUSED=1) on a batch the
     fast paths do not special-case: N not a multiple of 64, ragged segments, a repeated scene, odd dropout row offset

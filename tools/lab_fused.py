@@ -9,7 +9,7 @@ NET = dict(dims=[512] * 8, dropout=list(range(8)), dropout_prob=0.2, norm_layers
            weight_norm=True, geom_dimension=3)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 mode = sys.argv[2] if len(sys.argv) > 2 else "module_train"
-spec = NetSpec(256, **NET)
+spec = NetSpec(256, forward_bf16=os.environ.get("LAB_BF16") == "1", **NET)   # LAB_BF16=1: BASELINE config 5 forward
 eng = Engine(spec, "cuda")
 eng.init_like_reference(torch.Generator().manual_seed(0))
 x = torch.randn(N, 259, device="cuda") * 0.1
