@@ -328,6 +328,8 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(const FusedFwdArg
   const int fr = lane & 31, fh = lane >> 5;
   const int row0 = blockIdx.x * FROWS;
   const bool segm = p.seg.wg_per_seg > 0;
+  const uint32_t warm = warm_own_code(80 * 1024);
+  if (warm == 0x9E3779B1u && p.N < 0) S[0] = 1.f;   // never true: keeps the loads
 
   FusedBSets PB;
   const int lfirst = (segm && p.n_hidden > 1) ? 1 : 0;   // first layer with an MFMA pass (segment mode: layer 0 has none)
@@ -686,6 +688,8 @@ __global__ __launch_bounds__(256, 2) void fused_backward_kernel(const FusedBwdAr
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int row0 = blockIdx.x * FROWS;
+  const uint32_t warm = warm_own_code(64 * 1024);
+  if (warm == 0x9E3779B1u && p.N < 0) S[0] = 1.f;   // never true: keeps the loads
   if (p.xyz != nullptr && tid < FROWS) {
     float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row0 + tid < p.N) {
