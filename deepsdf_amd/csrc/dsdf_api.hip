@@ -696,9 +696,13 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
       hipLaunchKernelGGL(reduce_rows_kernel, dim3(rr_bx, LAST_GROUPS), dim3(256), 0, st, rr);
       LAUNCH_OK("reduce_rows_kernel");
     }
-  } else {   // one launch for everything that consumes only the backward's per-workgroup partials (kernels.hpp post_bwd_kernel)
-    PostBwdArgs q;
-    memset(&q, 0, sizeof(q));
+  }
+  // segment mode: everything that consumes only the backward's per-workgroup partials (kernels.hpp post_bwd_role) -- run by
+  // the workgroups the dW launch leaves idle, or by a launch of its own when there is no dW launch / no idle workgroup
+  PostBwdArgs q;
+  memset(&q, 0, sizeof(q));
+  int lat_n = 0;
+  if (segmode) {
     if (want_dw) {
       q.rr = rr; q.rr_bx = rr_bx; q.rr_n = rr_bx * LAST_GROUPS;
       SegDwArgs& d = q.dw;
@@ -721,7 +725,12 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     g.seg_scene = sb->seg_scene; g.table = sb->table;
     g.segpart = at<float>(ws, P.segpart_off); g.segnorm = at<float>(ws, P.segnorm_off);
     q.lat_bx = sb->R;
-    const int lat_n = sb->R * ((net->latent_size + 15) / 16);
+    lat_n = sb->R * ((net->latent_size + 15) / 16);
+  }
+  const int cus = chip_waves() / 4;
+  const int dw_busy = want_dw ? ((P.dw.n_full + P.dw.n_narrow + 3) / 4 < cus ? (P.dw.n_full + P.dw.n_narrow + 3) / 4 : cus) : 0;
+  const bool post_rides = segmode && want_dw && cus - dw_busy >= 8;   // enough idle workgroups to finish well inside the dW time
+  if (segmode && !post_rides) {
     hipLaunchKernelGGL(post_bwd_kernel, dim3((unsigned)(q.rr_n + q.dw_n + lat_n)), dim3(256), 0, st, q);
     LAUNCH_OK("post_bwd_kernel");
   }
@@ -740,10 +749,12 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
       y.nsplit = P.dw.nsplit[l]; y.kchunk = P.dw.kchunk[l]; y.full0 = P.dw.full0[l]; y.narrow0 = P.dw.narrow0[l];
       fl += 2.0 * (double)n * y.M * net->in_dim[l];   // algorithmic (segment mode executes fewer: hoisted x0 columns)
     }
-    int grid = (d.n_full + d.n_narrow + 3) / 4;
-    if (grid > chip_waves() / 4) grid = chip_waves() / 4;
+    PostBwdArgs none;
+    memset(&none, 0, sizeof(none));
+    int grid = dw_busy < 1 ? 1 : dw_busy;
     ProfScope ps(DSDF_PROF_DW_STREAM, fl, st);
-    hipLaunchKernelGGL(dw_stream_kernel, dim3(grid), dim3(256), 0, st, d);
+    if (post_rides) hipLaunchKernelGGL(dw_stream_kernel, dim3(cus), dim3(256), 0, st, d, q, lat_n, dw_busy);
+    else hipLaunchKernelGGL(dw_stream_kernel, dim3(grid), dim3(256), 0, st, d, none, 0, grid);
     LAUNCH_OK("dw_stream_kernel");
   }
   if (want_dw) {   // split-K sums, weight-norm backward and bias gradients of ALL layers (last layer included) in one launch

@@ -11,6 +11,7 @@
 #pragma once
 #include "common.hpp"
 #include "fused.hpp"   // crow()
+#include "kernels.hpp" // PostBwdArgs: the small post-backward roles ride on this launch's idle workgroups
 
 namespace dsdf {
 
@@ -131,11 +132,25 @@ __device__ __forceinline__ void dw_item(const DwLayer& L, int split, int m0, int
     }
 }
 
-__global__ __launch_bounds__(256, 1) void dw_stream_kernel(const DwArgs p) {
+// `busy_wg` workgroups (= ceil(items / 4)) stream the dW tiles; the launch covers the whole chip, and the workgroups beyond
+// them -- the items never fill it exactly (96 tiles x 10 splits = 960 of 1024 waves for the 8x512 net) -- work through
+// the post-backward roles of kernels.hpp (head partials, x0 columns of dW, per-segment latent gradient) meanwhile, so
+// those cost no launch of their own on the critical path.  post.rr_n + post.dw_n + post_lat_n == 0: nothing to do.
+__global__ __launch_bounds__(256, 1) void dw_stream_kernel(const DwArgs p, const PostBwdArgs post, const int post_lat_n,
+                                                           const int busy_wg) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int fr = lane & 31, fh = lane >> 5;
-  const int nwaves = gridDim.x * 4;
-  const int wave = xcd_remap(blockIdx.x, gridDim.x) * 4 + w;
+  const int lwg = xcd_remap(blockIdx.x, gridDim.x);
+  if (lwg >= busy_wg) {
+    const int total = post.rr_n + post.dw_n + post_lat_n;
+    for (int i = lwg - busy_wg; i < total; i += (int)gridDim.x - busy_wg) {
+      __syncthreads();   // the roles reuse their static LDS arrays
+      post_bwd_role(post, i);
+    }
+    return;
+  }
+  const int nwaves = busy_wg * 4;
+  const int wave = lwg * 4 + w;
   for (int item = wave; item < p.n_full; item += nwaves) {
     int l = 0;
     while (l + 1 < p.n_layers && item >= p.ly[l + 1].full0) ++l;

@@ -652,14 +652,14 @@ struct PostBwdArgs {
   SegDwArgs dw; int dw_n;                    // next dw_n blocks (0: weights frozen)
   SegLatArgs lat; int lat_bx;                // the rest: (bx, by) = (i % lat_bx, i / lat_bx)
 };
-__global__ __launch_bounds__(256) void post_bwd_kernel(const PostBwdArgs p) {
-  int i = blockIdx.x;
+__device__ __forceinline__ void post_bwd_role(const PostBwdArgs& p, int i) {
   if (i < p.rr_n) { reduce_rows_body(p.rr, i % p.rr_bx, i / p.rr_bx); return; }
   i -= p.rr_n;
   if (i < p.dw_n) { seg_dw_body(p.dw, i); return; }
   i -= p.dw_n;
   seg_latgrad_body(p.lat, i % p.lat_bx, i / p.lat_bx);
 }
+__global__ __launch_bounds__(256) void post_bwd_kernel(const PostBwdArgs p) { post_bwd_role(p, blockIdx.x); }
 
 // K5b: dlat[scene] += sum over the segments of that scene (in segment order) of
 //   segpart[r] + reg_coef/n_norm * count_r * E/||E||.   One block per segment; the FIRST segment of a scene owns
