@@ -368,7 +368,21 @@ int launch_last(const LastArgs& a, int blocks, hipStream_t st) {
   return 0;
 }
 
-int materialize(const DsdfNet* net, const float* params, float* packed, hipStream_t st, bool scales_ready = false) {
+// Adam constants of one parameter group (torch/optim/adam.py single-tensor form; bias corrections in double on the host)
+AdamRide adam_ride(float* p, const float* g, float* m, float* v, int64_t n, float lr, const DsdfAdamCfg* c) {
+  AdamRide a;
+  memset(&a, 0, sizeof(a));
+  const double bc1 = 1.0 - pow((double)c->beta1, (double)c->step), bc2 = 1.0 - pow((double)c->beta2, (double)c->step);
+  a.p = p; a.g = g; a.m = m; a.v = v; a.n = n;
+  a.blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  a.omb1 = 1.0f - c->beta1; a.b2 = c->beta2; a.omb2 = 1.0f - c->beta2;
+  a.step_size = (float)((double)lr / bc1); a.bc2_sqrt = (float)sqrt(bc2); a.eps = c->eps;
+  return a;
+}
+
+// ride != nullptr: a dense Adam update (the latent table) done by extra blocks of the wn_tiles launch
+int materialize(const DsdfNet* net, const float* params, float* packed, hipStream_t st, bool scales_ready = false,
+                const AdamRide* ride = nullptr) {
   DsdfParamLayout L;
   param_layout(net, &L);
   const Packed pk = packed_layout(net);
@@ -398,7 +412,8 @@ int materialize(const DsdfNet* net, const float* params, float* packed, hipStrea
     hipLaunchKernelGGL(wn_scale_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a);
     LAUNCH_OK("wn_scale_kernel");
   }
-  hipLaunchKernelGGL(wn_tiles_kernel, dim3(tiles), dim3(256), 0, st, a);
+  if (ride != nullptr) a.adam = *ride;
+  hipLaunchKernelGGL(wn_tiles_kernel, dim3(tiles + a.adam.blocks), dim3(256), 0, st, a);
   LAUNCH_OK("wn_tiles_kernel");
   return 0;
 }
@@ -1144,7 +1159,8 @@ int dsdf_adam_step(const DsdfNet* net, float* params, const float* grads, float*
   }
   if (n_latent_floats > 0) {
     if (!latent_table || !dlat || !lat_exp_avg || !lat_exp_avg_sq) return fail(DSDF_E_INVALID, "NULL latent argument");
-    TRY(adam_launch(latent_table, dlat, lat_exp_avg, lat_exp_avg_sq, n_latent_floats, cfg->lr_latent, cfg, nullptr, st));
+    const AdamRide ride = adam_ride(latent_table, dlat, lat_exp_avg, lat_exp_avg_sq, n_latent_floats, cfg->lr_latent, cfg);
+    return materialize(net, params, packed, st, true, &ride);
   }
   return materialize(net, params, packed, st, true);
 }
@@ -1165,8 +1181,8 @@ int dsdf_train_step(const DsdfNet* net, float* packed, float* params, float* gra
     return dsdf_adam_step(net, params, grads, exp_avg, exp_avg_sq, latent_table, dlat, lat_exp_avg, lat_exp_avg_sq, nlat, adam,
                           packed, stream);
   hipStream_t st = (hipStream_t)stream;
-  TRY(adam_launch(latent_table, dlat, lat_exp_avg, lat_exp_avg_sq, nlat, adam->lr_latent, adam, nullptr, st));
-  return materialize(net, params, packed, st, true);
+  const AdamRide ride = adam_ride(latent_table, dlat, lat_exp_avg, lat_exp_avg_sq, nlat, adam->lr_latent, adam);
+  return materialize(net, params, packed, st, true, &ride);   // latent Adam + W / W^T / fragment copies in one launch
 }
 
 int dsdf_adam_latent_only(float* latent, const float* dlat, float* exp_avg, float* exp_avg_sq, int64_t n,

@@ -214,7 +214,12 @@ struct WnLayer {
   __bf16* Wfb;             // bf16 fragment-ordered copy for the bf16 forward (fused_forward_bf16_kernel), or nullptr
   int Uf, UTf;             // k-units (of 16) allocated per n-tile in Wf / WTf
 };
-struct WnAll { int nl; int total_rows; int total_tiles; float* scale; WnLayer ly[DSDF_MAX_LAYERS]; };
+// (an optional dense Adam update -- the latent table -- rides on the same launch: blocks >= total_tiles, kernels.hpp adam_kernel math)
+struct AdamRide {
+  float* p; const float* g; float* m; float* v; long long n; int blocks;   // blocks == 0: none
+  float omb1, b2, omb2, step_size, bc2_sqrt, eps;
+};
+struct WnAll { int nl; int total_rows; int total_tiles; float* scale; AdamRide adam; WnLayer ly[DSDF_MAX_LAYERS]; };
 
 __global__ __launch_bounds__(256) void wn_scale_kernel(const WnAll p) {
   const int gr = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -240,6 +245,17 @@ __global__ __launch_bounds__(256) void wn_scale_kernel(const WnAll p) {
 __global__ __launch_bounds__(256) void wn_tiles_kernel(const WnAll p) {
   __shared__ float tile[32][33];
   const int t = blockIdx.x;
+  if (t >= p.total_tiles) {   // Adam on a dense table (torch single-tensor math, same expressions as adam_kernel)
+    const AdamRide& a = p.adam;
+    for (long long i = (long long)(t - p.total_tiles) * 256 + threadIdx.x; i < a.n; i += (long long)a.blocks * 256) {
+      const float gi = a.g[i];
+      const float mi = fmaf(a.omb1, gi - a.m[i], a.m[i]);
+      const float vi = a.b2 * a.v[i] + a.omb2 * gi * gi;
+      a.m[i] = mi; a.v[i] = vi;
+      a.p[i] = a.p[i] - a.step_size * (mi / (sqrtf(vi) / a.bc2_sqrt + a.eps));
+    }
+    return;
+  }
   int l = 0;
   while (l + 1 < p.nl && t >= p.ly[l + 1].tile0) ++l;
   const WnLayer& L = p.ly[l];
