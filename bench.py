@@ -81,8 +81,8 @@ def cpu_baseline(seconds=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--scenes-per-batch", type=int, default=64,
                     help="NOT the headline config: scale the batch (x 256 samples) to see large-batch behaviour")
     ap.add_argument("--no-cpu-baseline", action="store_true")

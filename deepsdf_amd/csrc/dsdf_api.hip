@@ -653,7 +653,8 @@ struct FuseAdam { const DsdfAdamCfg* cfg; float* params; float* exp_avg; float* 
 // Backward with the fused dX chain (fused.hpp): K3's second stage + last layer finalize, ONE launch for the whole
 // dX chain (writes every dP_l, column sums, latent-gradient inputs), then dW (split-K) + finalize per layer.
 // Segment mode (sb != nullptr): what the weight gradients of the hoisted layers need from the batch
-struct SegBwd { const FusedSeg* seg; const int64_t* seg_scene; const float* table; int R; };
+struct SegBwd { const FusedSeg* seg; const int64_t* seg_scene; const float* table; int R;
+                const ScatterArgs* scatter; bool* scatter_done; };   // the dense latent-gradient scatter may ride on the finalize launch
 
 int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float* packed, const float* params, int64_t n,
                        int training, float* grads, int accumulate, int ncols_dz, bool* used_dzB, hipStream_t st,
@@ -814,8 +815,14 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
       ++fa.n;
     }
     fa.row0[fa.n] = rows;
-    hipLaunchKernelGGL(finalize_all_kernel, dim3(rows), dim3(256), 0, st, fa);
-    LAUNCH_OK("finalize_all_kernel");
+    if (segmode && sb->scatter != nullptr) {
+      hipLaunchKernelGGL(finalize_scatter_kernel, dim3(rows + sb->R), dim3(256), 0, st, fa, *sb->scatter, rows);
+      LAUNCH_OK("finalize_scatter_kernel");
+      *sb->scatter_done = true;
+    } else {
+      hipLaunchKernelGGL(finalize_all_kernel, dim3(rows), dim3(256), 0, st, fa);
+      LAUNCH_OK("finalize_all_kernel");
+    }
   }
   return 0;
 }
@@ -1058,11 +1065,20 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
 
   bool used_dzB = false;
   const bool want_dw = cfg->frozen_decoder == 0;
+  ScatterArgs sc;   // dense latent gradient + regulariser + loss (block 0); launched below unless it rode on the finalize launch
+  memset(&sc, 0, sizeof(sc));
+  sc.segpart = at<float>(ws, P.segpart_off); sc.segnorm = at<float>(ws, P.segnorm_off);
+  sc.seg_scene = b->seg_scene; sc.seg_offset = b->seg_offset;
+  sc.R = (int)R; sc.L = Lc; sc.table = latent_table; sc.dlat = dlat;
+  sc.creg = cfg->reg_coef / (float)b->n_norm;
+  sc.part_loss = at<float>(ws, P.partloss_off); sc.n_part = fusedb ? P.nwg : P.last_blocks;
+  sc.loss_scale = 1.0f / (float)b->n_norm; sc.loss_out = loss_out; sc.accumulate = accumulate;
+  bool scatter_done = false;
   if (fusedb) {
     FusedBwdHead h = make_head(net, P, ws, packed, params, HEAD_TRAIN, cfg->training);
     h.gt = b->sdf_gt; h.delta = cfg->clamp_dist; h.inv_n = 1.0f / (float)b->n_norm; h.y_out = sdf_out;
     const FuseAdam* use = (fz != nullptr && want_dw && !accumulate) ? fz : nullptr;
-    const SegBwd sb{&seg, b->seg_scene, latent_table, (int)R};
+    const SegBwd sb{&seg, b->seg_scene, latent_table, (int)R, &sc, &scatter_done};
     TRY(run_backward_fused(net, P, ws, packed, params, n, cfg->training, grads, accumulate, segsum ? 0 : Lc, &used_dzB, st, want_dw, h,
                            use, segsum ? &sb : nullptr));
     if (use != nullptr && adam_fused) *adam_fused = 1;
@@ -1079,15 +1095,10 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
     hipLaunchKernelGGL(seg_reduce_kernel, dim3((unsigned)R, (Lc + 63) / 64), dim3(256), 0, st, s);
     LAUNCH_OK("seg_reduce_kernel");
   }
-  ScatterArgs sc;
-  memset(&sc, 0, sizeof(sc));
-  sc.segpart = s.segpart; sc.segnorm = s.segnorm; sc.seg_scene = b->seg_scene; sc.seg_offset = b->seg_offset;
-  sc.R = (int)R; sc.L = Lc; sc.table = latent_table; sc.dlat = dlat;
-  sc.creg = cfg->reg_coef / (float)b->n_norm;
-  sc.part_loss = at<float>(ws, P.partloss_off); sc.n_part = fusedb ? P.nwg : P.last_blocks;
-  sc.loss_scale = 1.0f / (float)b->n_norm; sc.loss_out = loss_out; sc.accumulate = accumulate;
-  hipLaunchKernelGGL(seg_scatter_kernel, dim3((unsigned)R), dim3(256), 0, st, sc);   // + the loss (block 0)
-  LAUNCH_OK("seg_scatter_kernel");
+  if (!scatter_done) {
+    hipLaunchKernelGGL(seg_scatter_kernel, dim3((unsigned)R), dim3(256), 0, st, sc);   // + the loss (block 0)
+    LAUNCH_OK("seg_scatter_kernel");
+  }
   return 0;
 }
 }  // namespace

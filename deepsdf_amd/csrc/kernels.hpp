@@ -687,10 +687,10 @@ struct ScatterArgs {
   // block 0: loss_out (+)= sum(part_loss[0..n_part)) * loss_scale + regulariser loss
   const float* part_loss; int n_part; float loss_scale; float* loss_out; int accumulate;
 };
-__global__ __launch_bounds__(256) void seg_scatter_kernel(const ScatterArgs p) {
+__device__ __forceinline__ void seg_scatter_body(const ScatterArgs& p, int r) {
   __shared__ float red[4];
   __shared__ int dup;
-  const int r = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   if (r == 0) {
     float s = 0.f;
     if (p.creg != 0.f)
@@ -725,6 +725,18 @@ __global__ __launch_bounds__(256) void seg_scatter_kernel(const ScatterArgs p) {
     }
     p.dlat[(size_t)j * p.L + c] += acc;
   }
+}
+
+__global__ __launch_bounds__(256) void seg_scatter_kernel(const ScatterArgs p) { seg_scatter_body(p, blockIdx.x); }
+
+// finalize_all_kernel with the dense latent-gradient scatter (+ loss) as extra blocks: in segment mode the scatter's inputs
+// exist before the finalize launch, so the two share it (blocks >= rows take one segment each)
+__global__ __launch_bounds__(256) void finalize_scatter_kernel(const FinAll p, const ScatterArgs sc, const int rows) {
+  if ((int)blockIdx.x >= rows) { seg_scatter_body(sc, (int)blockIdx.x - rows); return; }
+  __shared__ float red[4];
+  int l = 0;
+  while (l + 1 < p.n && (int)blockIdx.x >= p.row0[l + 1]) ++l;
+  finalize_row(p.f[l], blockIdx.x - p.row0[l], red);
 }
 
 // ---------------------------------------------------------------------------------------------------
