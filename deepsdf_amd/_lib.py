@@ -6,7 +6,7 @@ import os
 from .build import LIB
 
 MAX_LAYERS = 16
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class DsdfNet(C.Structure):
@@ -37,9 +37,9 @@ class DsdfAdamCfg(C.Structure):
                 ("beta2", C.c_float), ("eps", C.c_float), ("grad_scale", C.c_void_p)]
 
 
-PROF_CLASSES = 7
+PROF_CLASSES = 8
 PROF_NAMES = ("gemm_nt_kernel", "gemm_tn_kernel", "last_layer_kernel", "fused_forward_kernel", "fused_backward_kernel",
-              "dw_stream_kernel", "other")
+              "dw_stream_kernel", "other", "fused_fwd_bwd_kernel")
 
 
 class DsdfProfile(C.Structure):

@@ -479,7 +479,9 @@ int run_hoist(const DsdfNet* net, const Plan& P, void* ws, const float* packed, 
 // seg != nullptr: segment mode (fused.hpp FusedSeg) -- x0 is not read at all, seg->h[] / seg->U come from run_hoist
 int run_fused_forward(const DsdfNet* net, const Plan& P, void* ws, const float* packed, const float* params, int64_t n,
                       int training, const uint32_t* keys, uint32_t row_offset, bool store_act, float* y_out, float* u_out,
-                      hipStream_t st, const FusedSeg* seg = nullptr) {
+                      hipStream_t st, const FusedSeg* seg = nullptr, FusedFwdArgs* defer = nullptr) {
+  // defer != nullptr: fill *defer and launch nothing -- the caller hands it to run_backward_fused, which launches forward and
+  // backward as ONE kernel (fused_fwd_bwd_kernel)
   DsdfParamLayout L;
   param_layout(net, &L);
   const Packed pk = packed_layout(net);
@@ -513,6 +515,7 @@ int run_fused_forward(const DsdfNet* net, const Plan& P, void* ws, const float* 
   if (seg != nullptr) a.seg = *seg;
   a.w_last = packed + pk.w_off[last]; a.b_last = params + L.bias_off[last]; a.in_last = net->in_dim[last];
   a.use_tanh = net->use_tanh; a.y_out = y_out; a.u_out = u_out;
+  if (defer != nullptr) { *defer = a; return 0; }
   double wmac = 0;
   for (int l = 0; l < last; ++l) wmac += (double)net->in_dim[l] * net->out_dim[l];
   ProfScope ps(DSDF_PROF_FUSED_FWD, 2.0 * (double)n * wmac, st);
@@ -658,7 +661,8 @@ struct SegBwd { const FusedSeg* seg; const int64_t* seg_scene; const float* tabl
 
 int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float* packed, const float* params, int64_t n,
                        int training, float* grads, int accumulate, int ncols_dz, bool* used_dzB, hipStream_t st,
-                       bool want_dw, const FusedBwdHead& head, const FuseAdam* fz = nullptr, const SegBwd* sb = nullptr) {
+                       bool want_dw, const FusedBwdHead& head, const FuseAdam* fz = nullptr, const SegBwd* sb = nullptr,
+                       const FusedFwdArgs* fwd = nullptr) {   // fwd: the deferred forward of the same points -> one launch for both
   DsdfParamLayout L;
   param_layout(net, &L);
   const Packed pk = packed_layout(net);
@@ -701,9 +705,15 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     double amac = 0;
     for (int l = 0; l < last; ++l) amac += (double)net->in_dim[l] * net->out_dim[l];
     (void)wmac;
-    ProfScope ps(DSDF_PROF_FUSED_BWD, 2.0 * (double)n * amac, st);
-    hipLaunchKernelGGL(fused_backward_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, a);
-    LAUNCH_OK("fused_backward_kernel");
+    if (fwd != nullptr) {
+      ProfScope ps(DSDF_PROF_FUSED_FWD_BWD, 4.0 * (double)n * amac, st);   // forward + dX chain
+      hipLaunchKernelGGL(fused_fwd_bwd_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
+      LAUNCH_OK("fused_fwd_bwd_kernel");
+    } else {
+      ProfScope ps(DSDF_PROF_FUSED_BWD, 2.0 * (double)n * amac, st);
+      hipLaunchKernelGGL(fused_backward_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, a);
+      LAUNCH_OK("fused_backward_kernel");
+    }
   }
   const ReduceRowsArgs rr{at<float>(ws, P.part_off), P.nwg, P.ld_part, P.ld_part, at<float>(ws, P.part2_off), LAST_GROUPS};
   const int rr_bx = (P.ld_part + 63) / 64;
@@ -1034,15 +1044,17 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
   }
   FusedSeg seg;
   memset(&seg, 0, sizeof(seg));
+  FusedFwdArgs fwd_args;                                   // fp32 fused path: forward + backward go out as ONE launch below
+  const bool merged = fusedb && !net->fwd_bf16;   // (the bf16 forward is its own kernel)
   if (segsum) {
     TRY(run_hoist(net, P, ws, packed, latent_table, b, &seg, st));
     TRY(run_fused_forward(net, P, ws, packed, params, n, cfg->training, cfg->dropout_key, (uint32_t)b->row_offset, true,
-                          nullptr, nullptr, st, &seg));
+                          nullptr, nullptr, st, &seg, merged ? &fwd_args : nullptr));
   } else {
     TRY(run_gather(net, P, ws, latent_table, b, nullptr, 0, n, st));
     if (fusedb)
       TRY(run_fused_forward(net, P, ws, packed, params, n, cfg->training, cfg->dropout_key, (uint32_t)b->row_offset, true,
-                            nullptr, nullptr, st));
+                            nullptr, nullptr, st, nullptr, merged ? &fwd_args : nullptr));
     else
       TRY(run_hidden_forward(net, P, ws, packed, params, n, cfg->training, cfg->dropout_key, (uint32_t)b->row_offset, st));
   }
@@ -1080,7 +1092,7 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
     const FuseAdam* use = (fz != nullptr && want_dw && !accumulate) ? fz : nullptr;
     const SegBwd sb{&seg, b->seg_scene, latent_table, (int)R, &sc, &scatter_done};
     TRY(run_backward_fused(net, P, ws, packed, params, n, cfg->training, grads, accumulate, segsum ? 0 : Lc, &used_dzB, st, want_dw, h,
-                           use, segsum ? &sb : nullptr));
+                           use, segsum ? &sb : nullptr, merged ? &fwd_args : nullptr));
     if (use != nullptr && adam_fused) *adam_fused = 1;
   } else {
     TRY(run_backward(net, P, ws, packed, params, n, cfg->training, grads, accumulate, Lc, &used_dzB, st, want_dw));

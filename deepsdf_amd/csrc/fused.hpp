@@ -319,16 +319,15 @@ __device__ __forceinline__ void fused_hoist_init(f32x16 (&acc)[2][4], const floa
   }
 }
 
-__global__ __launch_bounds__(256, 2) void fused_forward_kernel(const FusedFwdArgs p) {
-  __shared__ __attribute__((aligned(16))) float S[FROWS * FLD];
-  __shared__ float4 xs[FROWS];                       // segment mode: xyz of the 64 points (zero padded)
-  __shared__ float hu[FHOIST][FMAXW];                // segment mode: U_s of the hoisted layers
-  __shared__ float4 hwx[FHOIST][FMAXW];              //               and their xyz weight columns
+// S: the slab; xs: segment mode, xyz of the 64 points (zero padded); hu / hwx: segment mode, U_s of the hoisted layers and
+// their xyz weight columns.  On return in the training form (no y_out / u_out) the slab holds the last hidden activation.
+__device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float* S, float4* xs, float (*hu)[FMAXW],
+                                                   float4 (*hwx)[FMAXW], int warm_bytes) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int row0 = blockIdx.x * FROWS;
   const bool segm = p.seg.wg_per_seg > 0;
-  const uint32_t warm = warm_own_code(80 * 1024);
+  const uint32_t warm = warm_own_code(warm_bytes);
   if (warm == 0x9E3779B1u && p.N < 0) S[0] = 1.f;   // never true: keeps the loads
 
   FusedBSets PB;
@@ -455,6 +454,14 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(const FusedFwdArg
       if (p.u_out) p.u_out[row0 + row] = u;
     }
   }
+}
+
+__global__ __launch_bounds__(256, 2) void fused_forward_kernel(const FusedFwdArgs p) {
+  __shared__ __attribute__((aligned(16))) float S[FROWS * FLD];
+  __shared__ float4 xs[FROWS];
+  __shared__ float hu[FHOIST][FMAXW];
+  __shared__ float4 hwx[FHOIST][FMAXW];
+  fused_forward_body(p, S, xs, hu, hwx, 80 * 1024);
 }
 
 // ===================================================================================================================
@@ -682,14 +689,17 @@ __device__ __forceinline__ void fused_bwd_epilogue(const f32x16 (&acc)[2][4], fl
   }
 }
 
-__global__ __launch_bounds__(256, 2) void fused_backward_kernel(const FusedBwdArgs p) {
-  __shared__ __attribute__((aligned(16))) float S[FROWS * FLD];
-  __shared__ float4 xs[FROWS];   // segment mode: xyz of the 64 points (zero padded)
+// slab_ready: the slab already holds the last hidden activation (the merged forward+backward kernel) -- no reload, no code
+// warm-up; hred / hsc: scratch of the head's cross-wave reductions.
+__device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float* S, float4* xs, float (*hred)[2 * FMAXW],
+                                                    float (*hsc)[2], bool slab_ready) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int row0 = blockIdx.x * FROWS;
-  const uint32_t warm = warm_own_code(64 * 1024);
-  if (warm == 0x9E3779B1u && p.N < 0) S[0] = 1.f;   // never true: keeps the loads
+  if (!slab_ready) {
+    const uint32_t warm = warm_own_code(64 * 1024);
+    if (warm == 0x9E3779B1u && p.N < 0) S[0] = 1.f;   // never true: keeps the loads
+  }
   if (p.xyz != nullptr && tid < FROWS) {
     float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row0 + tid < p.N) {
@@ -706,10 +716,8 @@ __global__ __launch_bounds__(256, 2) void fused_backward_kernel(const FusedBwdAr
     fused_load_x0(S, p.dp_in, p.ld_in, p.w_in, row0, p.N, 0);
     fused_zero_pad(S, p.w_in);
   } else {
-    __shared__ float hred[4][2 * FMAXW];
-    __shared__ float hsc[4][2];
     const FusedBwdHead& H = p.head;
-    fused_load_x0(S, H.a_last, H.ld_a, H.in_last, row0, p.N, 0);
+    if (!slab_ready) fused_load_x0(S, H.a_last, H.ld_a, H.in_last, row0, p.N, 0);
     float4 qv[2], dwa[2], csa[2];
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
@@ -818,6 +826,30 @@ __global__ __launch_bounds__(256, 2) void fused_backward_kernel(const FusedBwdAr
     fused_zero_pad(S, L.mask_cols);
     __syncthreads();
   }
+}
+
+__global__ __launch_bounds__(256, 2) void fused_backward_kernel(const FusedBwdArgs p) {
+  __shared__ __attribute__((aligned(16))) float S[FROWS * FLD];
+  __shared__ float4 xs[FROWS];
+  __shared__ float hred[4][2 * FMAXW];
+  __shared__ float hsc[4][2];
+  fused_backward_body(p, S, xs, hred, hsc, false);
+}
+
+// Training step, segment or general mode: forward and backward of the SAME 64 points by the same workgroup in one launch.
+// The last hidden activation stays in the slab for the head (no 33 MB re-read), one launch / prologue / instruction
+// warm-up less.  The forward-only scratch (hu, hwx) and the head's (hred, hsc) share LDS.
+__global__ __launch_bounds__(256, 2) void fused_fwd_bwd_kernel(const FusedFwdArgs f, const FusedBwdArgs b) {
+  __shared__ __attribute__((aligned(16))) float S[FROWS * FLD];
+  __shared__ float4 xs[FROWS];
+  __shared__ float4 scratch[FHOIST * FMAXW + FHOIST * FMAXW / 4];   // 20 KB: hu [2][512] floats + hwx [2][512] float4
+  float (*hu)[FMAXW] = reinterpret_cast<float (*)[FMAXW]>(scratch);
+  float4 (*hwx)[FMAXW] = reinterpret_cast<float4 (*)[FMAXW]>(scratch + FHOIST * FMAXW / 4);
+  float (*hred)[2 * FMAXW] = reinterpret_cast<float (*)[2 * FMAXW]>(scratch);            // 16 KB
+  float (*hsc)[2] = reinterpret_cast<float (*)[2]>(scratch + 4 * 2 * FMAXW / 4);
+  fused_forward_body(f, S, xs, hu, hwx, 150 * 1024);
+  __syncthreads();
+  fused_backward_body(b, S, xs, hred, hsc, true);
 }
 
 }  // namespace dsdf

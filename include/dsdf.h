@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define DSDF_MAX_LAYERS 16
-#define DSDF_ABI_VERSION 6
+#define DSDF_ABI_VERSION 7
 
 enum {
   DSDF_OK = 0,
@@ -166,12 +166,12 @@ int dsdf_adam_latent_only(float* latent, const float* dlat, float* exp_avg, floa
 
 /* ---- diagnostics: per-kernel-class device time from HIP events recorded on the caller's stream around every
  * launch of that class (bench.py's roofline object).  Off by default; thread-local; read synchronises. */
-#define DSDF_PROF_CLASSES 7
+#define DSDF_PROF_CLASSES 8
 enum { DSDF_PROF_GEMM_NT = 0, DSDF_PROF_GEMM_TN = 1, DSDF_PROF_LAST = 2, DSDF_PROF_FUSED_FWD = 3, DSDF_PROF_FUSED_BWD = 4,
-       DSDF_PROF_DW_STREAM = 5, DSDF_PROF_OTHER = 6 };
+       DSDF_PROF_DW_STREAM = 5, DSDF_PROF_OTHER = 6, DSDF_PROF_FUSED_FWD_BWD = 7 /* training: forward + backward in one launch */ };
 typedef struct DsdfProfile {
   double ms[DSDF_PROF_CLASSES];     /* summed event-to-event time per class */
-  double flops[DSDF_PROF_CLASSES];  /* summed 2*M*N*K (executed, incl. tile padding excluded) per class */
+  double flops[DSDF_PROF_CLASSES];  /* summed ALGORITHMIC 2*M*N*K of the GEMMs each launch covers (the reference's dense form) */
   int64_t count[DSDF_PROF_CLASSES]; /* launches per class */
   int32_t dropped;                  /* 1 if the event pool overflowed (results incomplete) */
 } DsdfProfile;
