@@ -515,7 +515,11 @@ int run_fused_forward(const DsdfNet* net, const Plan& P, void* ws, const float* 
   if (seg != nullptr) a.seg = *seg;
   a.w_last = packed + pk.w_off[last]; a.b_last = params + L.bias_off[last]; a.in_last = net->in_dim[last];
   a.use_tanh = net->use_tanh; a.y_out = y_out; a.u_out = u_out;
-  if (defer != nullptr) { *defer = a; return 0; }
+  if (defer != nullptr) {
+    a.ly[last - 1].out = nullptr;   // the last hidden activation is consumed from the slab by the backward head: no global copy
+    *defer = a;
+    return 0;
+  }
   double wmac = 0;
   for (int l = 0; l < last; ++l) wmac += (double)net->in_dim[l] * net->out_dim[l];
   ProfScope ps(DSDF_PROF_FUSED_FWD, 2.0 * (double)n * wmac, st);
