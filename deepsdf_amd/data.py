@@ -155,8 +155,10 @@ class DeviceSampleCache:
         self._draws += 1
         return ((seed * 0x9E3779B97F4A7C15) + self._draws * 0xD1B54A32D192ED03) & ((1 << 64) - 1)
 
-    def sample(self, scene_ids, subsample, generator=None, key=None):
-        """scene_ids: [B] integer tensor (CPU preferred: its values are checked on the host) -> (xyz [B*S', G], sdf [B*S'])."""
+    def sample(self, scene_ids, subsample, generator=None, key=None, scene_ids_device=None):
+        """scene_ids: [B] integer tensor (CPU preferred: its values are checked on the host) -> (xyz [B*S', G], sdf [B*S']).
+        scene_ids_device: the same ids already on the GPU (int64) -- saves the per-call host->device copy, which on pageable
+        memory makes the host wait for all queued GPU work."""
         if self.device.type != "cuda":
             raise RuntimeError("DeviceSampleCache.sample runs on the GPU (libdsdf_hip.so dsdf_sample_batch); there is no CPU path")
         from . import _lib
@@ -169,7 +171,7 @@ class DeviceSampleCache:
             if self.n_pos[k] + self.n_neg[k] < S:
                 raise ValueError(f"scene {k} has {self.n_pos[k] + self.n_neg[k]} samples, fewer than the {S} requested")
         B = scene_ids.numel()
-        sid = scene_ids.to(self.device)
+        sid = scene_ids.to(self.device) if scene_ids_device is None else scene_ids_device
         xyz = torch.empty(B * S, self.G, dtype=torch.float32, device=self.device)
         sdf = torch.empty(B * S, dtype=torch.float32, device=self.device)
         key = self.draw_key(generator) if key is None else int(key) & ((1 << 64) - 1)

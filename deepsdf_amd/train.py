@@ -249,7 +249,11 @@ class FusedTrainStep:
         reg = self.lam * min(1, epoch / 100) if self.code_reg else 0.0
         if batch_split == 1:
             seg_scene = scene_rows
-            seg_off = torch.arange(0, N + 1, samples_per_scene, dtype=torch.int64, device=xyz.device)
+            ck = (N, samples_per_scene)
+            if getattr(self, "_seg_off_key", None) != ck:      # the same every step: built once
+                self._seg_off = torch.arange(0, N + 1, samples_per_scene, dtype=torch.int64, device=xyz.device)
+                self._seg_off_key = ck
+            seg_off = self._seg_off
             chunks = [(seg_scene, seg_off, xyz, sdf_gt)]
             uniform = samples_per_scene
         else:
@@ -410,6 +414,8 @@ def main_function(experiment_directory, continue_from, batch_split):
         steps_per_epoch = int(t.item())
     loss_buf = torch.zeros(max(steps_per_epoch, 1), device=device)
     stats = EpochStats(device, steps_per_epoch, decoder)
+    order_pinned = [torch.empty(n_local, dtype=torch.int64).pin_memory() for _ in range(2)]
+    order_device = [torch.empty(n_local, dtype=torch.int64, device=device) for _ in range(2)]
     gen = torch.Generator(device=device)
     gen.manual_seed(int(torch.initial_seed() & 0x7FFFFFFF) + 7919 * rank)
     n_norm = scene_per_batch * num_samp_per_scene * world    # loss normaliser = GLOBAL points per step (:519)
@@ -420,10 +426,17 @@ def main_function(experiment_directory, continue_from, batch_split):
         lr0, lr1 = lr_schedules[0].get_learning_rate(epoch), lr_schedules[1].get_learning_rate(epoch)
         optimizer_all.set_lrs(lr0, lr1)
         order = torch.randperm(n_local)                      # DataLoader(shuffle=True)
+        # ONE asynchronous upload of the epoch's order (pinned, double-buffered): a pageable host->device copy per step
+        # would make the host wait for the queued GPU work every step
+        opin = order_pinned[epoch & 1]
+        opin.copy_(order)
+        order_dev = order_device[epoch & 1]
+        order_dev.copy_(opin, non_blocking=True)
         for it in range(steps_per_epoch):
-            scenes = order[it * scene_per_batch:(it + 1) * scene_per_batch]
-            xyz, sdf_gt = cache.sample(scenes, num_samp_per_scene, generator=gen)
-            fused(scenes.to(device), 2 * int(num_samp_per_scene / 2), xyz, sdf_gt, epoch, lr0, lr1,
+            sl = slice(it * scene_per_batch, (it + 1) * scene_per_batch)
+            scenes, scenes_dev = order[sl], order_dev[sl]
+            xyz, sdf_gt = cache.sample(scenes, num_samp_per_scene, generator=gen, scene_ids_device=scenes_dev)
+            fused(scenes_dev, 2 * int(num_samp_per_scene / 2), xyz, sdf_gt, epoch, lr0, lr1,
                   batch_split=batch_split, n_norm=n_norm)
             loss_buf[it:it + 1].copy_(eng.loss)
         if world > 1:

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from oracle import deepsdf_oracle as orc
 from deepsdf_amd import train
-epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 root = tempfile.mkdtemp()
 d = os.path.join(root, "data", "SdfSamples", "synth", "spheres"); os.makedirs(d)
 names = []
