@@ -1049,7 +1049,10 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
   FusedSeg seg;
   memset(&seg, 0, sizeof(seg));
   FusedFwdArgs fwd_args;                                   // fp32 fused path: forward + backward go out as ONE launch below
-  const bool merged = fusedb && !net->fwd_bf16;   // (the bf16 forward is its own kernel)
+  bool merged = fusedb && !net->fwd_bf16;   // (the bf16 forward is its own kernel)
+#ifdef DSDF_LAB
+  if (getenv("DSDF_LAB_DBG")) merged = false;   // lab builds: per-layer stamps are dumped after a forward launch of its own
+#endif
   if (segsum) {
     TRY(run_hoist(net, P, ws, packed, latent_table, b, &seg, st));
     TRY(run_fused_forward(net, P, ws, packed, params, n, cfg->training, cfg->dropout_key, (uint32_t)b->row_offset, true,
