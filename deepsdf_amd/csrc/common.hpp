@@ -42,12 +42,16 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 // Pull this kernel's own instructions into L2 as DATA at its very start (one 64-byte line per lane-load, results unused).
 // The big kernels evict each other's code from the instruction cache AND from L2 (hundreds of MB stream through between
 // two launches), and a lone wave per SIMD has nothing to hide an instruction-fetch miss behind; a miss that hits L2
-// costs a fraction of one that goes to HBM.  `bytes` must not exceed the kernel's text size (it is followed by other
-// kernels of the same code object in any case).
+// costs a fraction of one that goes to HBM.  `bytes` is clamped to the text that really follows (dsdf_text_end_marker).
+__device__ __noinline__ void dsdf_text_end_marker();   // defined LAST in dsdf_api.hip: an address inside .text behind every kernel
 __device__ __forceinline__ uint32_t warm_own_code(int bytes) {
   uint64_t pc;
   asm volatile("s_getpc_b64 %0" : "=s"(pc));
   const char* base = reinterpret_cast<const char*>(pc & ~63ull);
+  // never read past the code object's text: clamp to the marker function (if the compiler ever places it in front of this
+  // kernel the room is negative and nothing is read)
+  const long long room = reinterpret_cast<const char*>(reinterpret_cast<void*>(&dsdf_text_end_marker)) - base;
+  if (bytes > room) bytes = room > 0 ? (int)room : 0;
   uint32_t acc = 0;
   for (int off = (int)threadIdx.x * 64; off < bytes; off += 256 * 64) acc ^= *reinterpret_cast<const uint32_t*>(base + off);
   return acc;   // the caller keeps it alive (e.g. folds it into a store that never happens)
