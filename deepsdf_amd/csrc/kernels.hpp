@@ -149,13 +149,35 @@ __device__ __forceinline__ void seg_dw_body(const SegDwArgs& p, int bidx) {
     for (int r = 0; r < SDW_ROWS; ++r) acc[k][r] = 0.f;
   for (int s0 = 0; s0 < p.R; s0 += 64) {
     __syncthreads();
+    if (p.wg_per_seg <= 2 * min(64, p.R - s0)) {   // many short segments: one thread per (row, segment), its workgroups one after the other
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int sl = s_ld + 32 * q, sg = s0 + sl;
-      float a = 0.f;
-      if (sg < p.R && i0 + r_ld < p.out[t])
-        for (int g = 0; g < p.wg_per_seg; ++g) a += cs[(size_t)(sg * p.wg_per_seg + g) * p.ldcs + i0 + r_ld];
-      css[sl][r_ld] = a;
+      for (int q = 0; q < 2; ++q) {
+        const int sl = s_ld + 32 * q, sg = s0 + sl;
+        float a = 0.f;
+        if (sg < p.R && i0 + r_ld < p.out[t])
+          for (int g = 0; g < p.wg_per_seg; ++g) a += cs[(size_t)(sg * p.wg_per_seg + g) * p.ldcs + i0 + r_ld];
+        css[sl][r_ld] = a;
+      }
+    } else {                       // few long segments (up to 16384 samples per scene): 32 threads share a segment's workgroups
+      for (int sl = 0; sl < 64; ++sl) {
+        const int sg = s0 + sl;
+        float a = 0.f;
+        if (sg < p.R && i0 + r_ld < p.out[t])
+          for (int g = s_ld; g < p.wg_per_seg; g += 32) a += cs[(size_t)(sg * p.wg_per_seg + g) * p.ldcs + i0 + r_ld];
+        xred[s_ld][r_ld][0] = a;   // (xred is free here: its xyz partials are written after this loop)
+        __syncthreads();
+        if (tid < SDW_ROWS) {
+          float v = 0.f;
+#pragma unroll
+          for (int q = 0; q < 32; ++q) v += xred[q][tid][0];
+          css[sl][tid] = v;
+        }
+        __syncthreads();
+        if (sg + 1 >= p.R) {       // the remaining slots of this pass are empty
+          for (int z = sl + 1 + (tid >> 3); z < 64; z += 32) css[z][r_ld] = 0.f;
+          break;
+        }
+      }
     }
     if (tid < 64) srow[tid] = s0 + tid < p.R ? (long long)p.seg_scene[s0 + tid] * p.L : 0;
     __syncthreads();

@@ -227,6 +227,12 @@ SEG_SHAPES = {
     "long_segments": dict(L=8, B=2, S=4096, split=1, net=dict(dims=[64, 64, 64], dropout=[0, 2], dropout_prob=0.2,
                                                                norm_layers=[0, 1, 2], latent_in=[1], weight_norm=True,
                                                                geom_dimension=3)),
+    # one scene of 8192 points: 128 workgroups per segment (the per-segment sums take their parallel form)
+    # (ONE scene: many weight-gradient entries are ~1e-8 = Adam's eps, where the first step's update lr*g/(|g|+eps) turns a
+    # 1e-5 relative gradient difference into a few 1e-5 of the parameter scale -> its own post-Adam tolerance)
+    "one_long_scene": dict(L=8, B=1, S=8192, split=1, param_tol=5e-5, net=dict(dims=[64, 64, 64], dropout=[1], dropout_prob=0.2,
+                                                              norm_layers=[0, 1, 2], latent_in=[1], weight_norm=True,
+                                                              geom_dimension=3)),
     "geom2_plain": dict(L=16, B=2, S=192, split=1, net=dict(dims=[72, 72, 72, 72], dropout=[], dropout_prob=0.0, norm_layers=[],
                                                             latent_in=[2], weight_norm=False, geom_dimension=2)),
 }
@@ -257,9 +263,10 @@ def test_segment_mode_odd_shapes_vs_oracle(name):
                 assert rel_err(rh["grads"][k], r64["grads"][k]) <= GRAD_TOL, (step, k, kw)
             assert rel_err(rh["dlat"], r64["dlat"]) <= GRAD_TOL, (step, kw)
             P = tr.params()
+            ptol = c.get("param_tol", PARAM_TOL)
             for k in st64.params:
-                assert rel_err(P[k], st64.params[k]) <= PARAM_TOL, (step, k, kw)
-            assert rel_err(tr.lat.cpu(), st64.latents) <= PARAM_TOL, (step, kw)
+                assert rel_err(P[k], st64.params[k]) <= ptol, (step, k, kw)
+            assert rel_err(tr.lat.cpu(), st64.latents) <= ptol, (step, kw)
 
 
 def test_config5_bf16_forward_vs_oracle_and_fp32():

@@ -1,0 +1,35 @@
+"""Non-headline configurations quoted in DESIGN.md: BASELINE config 4 (latent-only reconstruction, 8000 pts/iter per shape,
+batched over shapes) and the locality extreme of config 2 (ONE scene x 16384 points per step)."""
+import math, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, bench
+from deepsdf_amd.engine import Engine
+from deepsdf_amd.net import NetSpec
+from deepsdf_amd.reconstruct import reconstruct
+dev = torch.device("cuda", 0)
+eng = Engine(NetSpec(bench.L, **bench.NET), dev)
+eng.init_like_reference(torch.Generator().manual_seed(0))
+# config 4: B shapes x 8000 (-> 7936 = 124 x 64) points, frozen decoder, 100 iterations
+for B in (1, 16, 64):
+    S = 7936
+    xyz = torch.rand(B, S, 3, device=dev) * 2 - 1
+    sdf = xyz.norm(dim=2) - 0.5
+    reconstruct(eng, xyz, sdf, num_iterations=20)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    reconstruct(eng, xyz, sdf, num_iterations=100)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 100
+    print(f"config 4: {B:3d} shapes x {S} pts: {dt*1e3:.3f} ms/iteration = {B*S/dt/1e6:.2f} M point-samples/s ({B/dt:.0f} shape-iterations/s)")
+# locality extreme: one scene, 16384 points per step
+lat = (torch.randn(1, bench.L) / math.sqrt(bench.L)).to(dev)
+dlat, m, v = torch.zeros_like(lat), torch.zeros_like(lat), torch.zeros_like(lat)
+xyz = torch.rand(16384, 3, device=dev) * 2 - 1
+gt = xyz.norm(dim=1) - 0.5
+sc = torch.zeros(1, dtype=torch.int64, device=dev); so = torch.tensor([0, 16384], dtype=torch.int64, device=dev)
+def step():
+    eng.train_step(lat, dlat, m, v, sc, so, xyz, gt, n_norm=16384, clamp_dist=0.1, reg_coef=1e-6, code_bound=1.0,
+                   lr_decoder=5e-4, lr_latent=1e-3, training=True, seed=0, seg_len=16384)
+for _ in range(60): step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(200): step()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 200
+print(f"config 2, B=1 x S=16384: {dt*1e3:.3f} ms/step = {16384/dt/1e6:.2f} M point-samples/s")
