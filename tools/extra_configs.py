@@ -33,3 +33,18 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(200): step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 200
 print(f"config 2, B=1 x S=16384: {dt*1e3:.3f} ms/step = {16384/dt/1e6:.2f} M point-samples/s")
+# the shipped big setting: 64 scenes x 16384 samples = 1,048,576 points per step (256 workgroups per scene)
+B, S = 64, 16384
+lat = (torch.randn(B, bench.L) / math.sqrt(bench.L)).to(dev)
+dlat, m, v = torch.zeros_like(lat), torch.zeros_like(lat), torch.zeros_like(lat)
+xyz = torch.rand(B * S, 3, device=dev) * 2 - 1
+gt = xyz.norm(dim=1) - 0.5
+sc = torch.arange(B, dtype=torch.int64, device=dev); so = torch.arange(0, B * S + 1, S, dtype=torch.int64, device=dev)
+def big():
+    eng.train_step(lat, dlat, m, v, sc, so, xyz, gt, n_norm=B * S, clamp_dist=0.1, reg_coef=1e-6, code_bound=1.0,
+                   lr_decoder=5e-4, lr_latent=1e-3, training=True, seed=0, seg_len=S)
+for _ in range(3): big()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(10): big()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+print(f"64 scenes x 16384 samples (1,048,576 pts/step): {dt*1e3:.2f} ms/step = {B*S/dt/1e6:.2f} M point-samples/s; workspace {eng._ws.numel()/2**30:.1f} GiB")
