@@ -194,8 +194,27 @@ __device__ __forceinline__ void fused_prefetch_b(FusedBSets& B, const float* wf,
   }
 }
 
+// Weights come through a buffer resource: the address of k-unit u of n-tile t is scalar ((t U + u) * 2 KiB, an SGPR
+// soffset) plus a per-lane constant, so the loads need NO vector address arithmetic (a lone wave pays for every VALU
+// instruction it issues between its MFMAs).
+struct FusedBView { __amdgpu_buffer_rsrc_t rsrc; int tbase[4]; int voff; };   // tbase[ni] = (w + 4 ni) * U; voff = lane * 16
+__device__ __forceinline__ FusedBView fused_bview(const float* wf, int U, int w, int lane) {
+  FusedBView v;
+  v.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, 0x7FFFFFFF, 0x00020000);
+  const int ws = __builtin_amdgcn_readfirstlane(w);
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) v.tbase[ni] = (ws + 4 * ni) * U;
+  v.voff = lane * 16;
+  return v;
+}
+__device__ __forceinline__ float4 fused_bload(const FusedBView& B, int ni, int u, int half) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(B.rsrc, B.voff + 1024 * half, (B.tbase[ni] + u) * 2048, 0);
+  return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+}
+
 template <int NACT>
-__device__ __forceinline__ void fused_kloop(f32x16 (&acc)[2][4], const float* ap, const float* const (&bp)[4], int nu,
+__device__ __forceinline__ void fused_kloop(f32x16 (&acc)[2][4], const float* ap, const FusedBView& bv, int nu,
                                             FusedBSets& PB) {
   // Three named register sets rotate over the k-units: the WEIGHTS of unit u+2 (global, fragment order) and the
   // ACTIVATIONS of unit u+1 (LDS slab) are requested before the 16 NACT MFMAs of unit u issue, so neither the L2
@@ -210,8 +229,8 @@ __device__ __forceinline__ void fused_kloop(f32x16 (&acc)[2][4], const float* ap
   auto loadB = [&](float4 (&b)[NACT][2], int u) {
 #pragma unroll
     for (int ni = 0; ni < NACT; ++ni) {
-      b[ni][0] = *reinterpret_cast<const float4*>(bp[ni] + (size_t)u * 512);
-      b[ni][1] = *reinterpret_cast<const float4*>(bp[ni] + (size_t)u * 512 + 256);
+      b[ni][0] = fused_bload(bv, ni, u, 0);
+      b[ni][1] = fused_bload(bv, ni, u, 1);
     }
   };
   auto readA = [&](float4 (&a)[4], int u) {
@@ -279,13 +298,13 @@ __device__ __forceinline__ void fused_kloop(f32x16 (&acc)[2][4], const float* ap
   if (u + 1 < nu) mma(a1, b1);
 }
 
-__device__ __forceinline__ void fused_kloop_dispatch(f32x16 (&acc)[2][4], const float* ap, const float* const (&bp)[4],
+__device__ __forceinline__ void fused_kloop_dispatch(f32x16 (&acc)[2][4], const float* ap, const FusedBView& bv,
                                                      int nu, int nact, FusedBSets& PB) {
   switch (nact) {
-    case 4: fused_kloop<4>(acc, ap, bp, nu, PB); break;
-    case 3: fused_kloop<3>(acc, ap, bp, nu, PB); break;
-    case 2: fused_kloop<2>(acc, ap, bp, nu, PB); break;
-    case 1: fused_kloop<1>(acc, ap, bp, nu, PB); break;
+    case 4: fused_kloop<4>(acc, ap, bv, nu, PB); break;
+    case 3: fused_kloop<3>(acc, ap, bv, nu, PB); break;
+    case 2: fused_kloop<2>(acc, ap, bv, nu, PB); break;
+    case 1: fused_kloop<1>(acc, ap, bv, nu, PB); break;
     default: break;
   }
 }
@@ -386,9 +405,7 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[m][ni][r] = 0.f;
     }
-    const float* bp[4];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) bp[ni] = L.wf + (size_t)(w + 4 * ni) * L.U * 512 + lane * 4;
+    const FusedBView bv = fused_bview(L.wf, L.U, w, lane);
     const float* ap = S + fr * FLD + 8 * fh;
     // epilogue operands are fetched BEFORE the k-loop: a load issued after the epilogue's global stores would have
     // to wait for them (vmcnt is in-order and counts stores)
@@ -399,7 +416,7 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
       biasv[ni] = col < L.out_dim ? L.bias[col] : 0.f;
     }
     if (nu > 0) {
-      fused_kloop_dispatch(acc, ap, bp, nu, fused_nact(L.out_dim, w), PB);
+      fused_kloop_dispatch(acc, ap, bv, nu, fused_nact(L.out_dim, w), PB);
       if (l + 1 < p.n_hidden) {   // next layer's first weights travel while this layer's epilogue runs
         const FusedLayer& Ln = p.ly[l + 1];
         fused_prefetch_b(PB, Ln.wf, Ln.U, w, lane, fused_nact(Ln.out_dim, w), (Ln.in + 15) >> 4);
@@ -809,13 +826,11 @@ __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float
       for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][ni][r] = 0.f;
-    const float* bp[4];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) bp[ni] = L.wtf + (size_t)(w + 4 * ni) * L.U * 512 + lane * 4;
+    const FusedBView bv = fused_bview(L.wtf, L.U, w, lane);
     const float* ap = S + fr * FLD + 8 * fh;
     uint4 mq = make_uint4(0u, 0u, 0u, 0u);
     if (L.maskbits != nullptr) mq = *reinterpret_cast<const uint4*>(L.maskbits + ((size_t)blockIdx.x * 256 + tid) * 4);
-    fused_kloop_dispatch(acc, ap, bp, nu, fused_nact(L.ncols, w), PB);
+    fused_kloop_dispatch(acc, ap, bv, nu, fused_nact(L.ncols, w), PB);
     if (i + 1 < p.n_layers) {
       const FusedBwdLayer& Ln = p.ly[i + 1];
       fused_prefetch_b(PB, Ln.wtf, Ln.U, w, lane, fused_nact(Ln.ncols, w), (Ln.K + 15) >> 4);
