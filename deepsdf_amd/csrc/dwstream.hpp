@@ -138,8 +138,8 @@ __device__ __forceinline__ void dw_item(const DwLayer& L, int split, int m0, int
 // those cost no launch of their own on the critical path.  post.rr_n + post.dw_n + post_lat_n == 0: nothing to do.
 __global__ __launch_bounds__(256, 1) void dw_stream_kernel(const DwArgs p, const PostBwdArgs post, const int post_lat_n,
                                                            const int busy_wg) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int fr = lane & 31, fh = lane >> 5;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: item, K range and the
+  const int fr = lane & 31, fh = lane >> 5;                                                  // ring's bounds checks stay scalar
   const int lwg = xcd_remap(blockIdx.x, gridDim.x);
   if (lwg >= busy_wg) {
     const int total = post.rr_n + post.dw_n + post_lat_n;
