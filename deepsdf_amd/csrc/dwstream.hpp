@@ -43,9 +43,19 @@ template <int NJ>
 __device__ __forceinline__ void dw_item(const DwLayer& L, int split, int m0, int n0, int kbeg, int kend, int fr, int fh) {
   typedef typename DwVec<NJ>::type bvec;
   const int nsteps = (kend - kbeg) >> 1;                    // full k-steps of 2 points
-  const float* ap = L.dp + (size_t)(kbeg + fh) * L.ld_dp + m0 + 4 * fr;
-  const float* bq = L.act + (size_t)(kbeg + fh) * L.ld_act + n0 + NJ * fr;
-  const size_t astep = (size_t)2 * L.ld_dp, bstep = (size_t)2 * L.ld_act;
+  const float* bq = L.act + (size_t)(kbeg + fh) * L.ld_act + n0 + NJ * fr;   // narrow tiles (NJ < 4): plain loads
+  const size_t bstep = (size_t)2 * L.ld_act;
+  // the streamed loads go through buffer resources based at the item's first row: the address of k-step q is a SCALAR
+  // offset (q * step bytes, < 2^31) plus a per-lane constant -- no vector address arithmetic between the MFMAs
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(L.dp + (size_t)kbeg * L.ld_dp), 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(L.act + (size_t)kbeg * L.ld_act), 0, 0x7FFFFFFF, 0x00020000);
+  const int voa = (fh * L.ld_dp + m0 + 4 * fr) * 4, vob = (fh * L.ld_act + n0 + NJ * fr) * 4;
+  const int astepb = 8 * L.ld_dp, bstepb = 8 * L.ld_act;
+  auto lda = [&](int q) -> float4 {
+    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(ra, voa, q * astepb, 0);
+    return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+  };
 
   f32x16 acc[4][NJ];
 #pragma unroll
@@ -55,11 +65,17 @@ __device__ __forceinline__ void dw_item(const DwLayer& L, int split, int m0, int
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[DW_RING];
-  bvec rb[DW_RING];
+  float4 rga[DW_RING];
+  bvec rgb[DW_RING];
   auto ldb = [&](const float* q) -> bvec {
     if constexpr (NJ == 3) { bvec v; v.x = q[0]; v.y = q[1]; v.z = q[2]; return v; }   // rows are only 4-byte aligned for NJ*fr
     else return *reinterpret_cast<const bvec*>(q);
+  };
+  auto ldbq = [&](int q) -> bvec {            // k-step q of the B operand
+    if constexpr (NJ == 4) {
+      const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rb, vob, q * bstepb, 0);
+      return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+    } else return ldb(bq + (size_t)q * bstep);
   };
   auto mma = [&](const float4& a, const bvec& b) {
     const float av[4] = {a.x, a.y, a.z, a.w};
@@ -75,8 +91,8 @@ __device__ __forceinline__ void dw_item(const DwLayer& L, int split, int m0, int
 #pragma unroll
   for (int q = 0; q < DW_RING - 1; ++q) {
     if (q < nsteps) {
-      ra[q] = *reinterpret_cast<const float4*>(ap + q * astep);
-      rb[q] = ldb(bq + q * bstep);
+      rga[q] = lda(q);
+      rgb[q] = ldbq(q);
     }
   }
   int s = 0;
@@ -85,16 +101,16 @@ __device__ __forceinline__ void dw_item(const DwLayer& L, int split, int m0, int
     for (int q = 0; q < DW_RING; ++q) {
       const int nxt = s + q + DW_RING - 1;
       if (nxt < nsteps) {
-        ra[(q + DW_RING - 1) % DW_RING] = *reinterpret_cast<const float4*>(ap + (size_t)nxt * astep);
-        rb[(q + DW_RING - 1) % DW_RING] = ldb(bq + (size_t)nxt * bstep);
+        rga[(q + DW_RING - 1) % DW_RING] = lda(nxt);
+        rgb[(q + DW_RING - 1) % DW_RING] = ldbq(nxt);
       }
-      mma(ra[q], rb[q]);
+      mma(rga[q], rgb[q]);
     }
   }
   // tail: the remaining (< DW_RING) full steps are already in ring slots 0..rem-1
 #pragma unroll
   for (int q = 0; q < DW_RING - 1; ++q)
-    if (s + q < nsteps) mma(ra[q], rb[q]);
+    if (s + q < nsteps) mma(rga[q], rgb[q]);
   if ((kend - kbeg) & 1) {                                   // odd last point: lanes of the second half contribute zero
     const int k = kend - 1;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
