@@ -762,7 +762,8 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
   // the idle workgroups take the role blocks one after the other: that stays inside the dW time for batches of up to one
   // workgroup per CU (measured: 16384 points, 1168 role blocks on 16 workgroups, dW time unchanged); larger batches put
   // the roles on the critical path (65536 points: -5 %), so they get their own (wide) launch there
-  const bool post_rides = segmode && want_dw && cus - dw_busy >= 8 && P.nwg <= cus;
+  static const bool no_ride = [] { const char* e = getenv("DSDF_NO_RIDE"); return e && e[0] == '1'; }();   // A/B switch
+  const bool post_rides = segmode && want_dw && cus - dw_busy >= 8 && P.nwg <= cus && !no_ride;
   if (segmode && !post_rides) {
     hipLaunchKernelGGL(post_bwd_kernel, dim3((unsigned)(q.rr_n + q.dw_n + lat_n)), dim3(256), 0, st, q);
     LAUNCH_OK("post_bwd_kernel");
