@@ -943,6 +943,30 @@ int dsdf_decode(const DsdfNet* net, const float* packed, const float* params, co
   return launch_last<LAST_FWD>(a, blocks, st);
 }
 
+int dsdf_decode_latent(const DsdfNet* net, const float* packed, const float* params, const float* latent, const float* xyz,
+                       int64_t n, float* sdf_out, void* ws, size_t ws_bytes, void* stream) {
+  TRY(check_common(net, packed, params, ws));
+  if (n == 0) return 0;
+  if (!latent || !xyz || !sdf_out || n < 0) return fail(DSDF_E_INVALID, "bad latent/xyz/sdf_out");
+  if (!fused_enabled() || !fused_eligible(net) || net->fwd_bf16 || net->geom_dim > FGEO || net->latent_size > HOIST_MAXL ||
+      net->latent_size < 1 || net->n_layers < 3)
+    return fail(DSDF_E_INVALID, "dsdf_decode_latent needs the fp32 fused forward (widths <= 512, geom_dim <= 4): use dsdf_decode");
+  Plan P = make_plan(net, n, 0, true);
+  const size_t need = P.total > 16384 ? P.total : 16384;
+  if (ws_bytes < need) return fail(DSDF_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  // ONE segment covering every point: the segment-mode forward with the latent's products hoisted (fused.hpp FusedSeg)
+  HIP_OK(hipMemsetAsync(ws, 0, 8, st));                 // seg_scene[0] = 0: the "table" is the single latent row
+  P.hoistU_off = 256; P.ldu = FMAXW;                    // U [1][2][512] behind it
+  DsdfBatch b;
+  memset(&b, 0, sizeof(b));
+  b.seg_scene = at<int64_t>(ws, 0); b.n_segments = 1; b.xyz = xyz; b.n_points = n; b.seg_len = n;
+  FusedSeg seg;
+  TRY(run_hoist(net, P, ws, packed, latent, &b, &seg, st));
+  seg.wg_per_seg = (int)((n + FROWS - 1) / FROWS);      // every workgroup belongs to segment 0
+  return run_fused_forward(net, P, ws, packed, params, n, 0, nullptr, 0, false, sdf_out, nullptr, st, &seg);
+}
+
 int dsdf_module_forward(const DsdfNet* net, const float* packed, const float* params, const float* input,
                         int64_t ld_in, int64_t n, int32_t training, const uint32_t* dropout_key, float* sdf_out,
                         void* ws, size_t ws_bytes, void* stream) {

@@ -136,6 +136,26 @@ class Engine:
                                             ws.numel(), _stream()))
         return out.view(n, 1)
 
+    def decode_latent(self, latent, xyz, max_chunk=1 << 20):
+        """decode_sdf with ONE code for every query point: latent [L] (or [1, L]), xyz [n, G] -> sdf [n, 1].  The [n, L+G]
+        input is never materialised (dsdf_decode_latent: the latent's products are hoisted out of the per-point work)."""
+        self._fresh_weights()
+        z = latent.to(self.device, torch.float32).reshape(-1).contiguous()
+        x = xyz.to(self.device, torch.float32).contiguous()
+        if z.numel() != self.spec.latent_size or x.dim() != 2 or x.shape[1] != self.spec.geom_dimension:
+            raise ValueError(f"expected latent [{self.spec.latent_size}] and xyz [n, {self.spec.geom_dimension}]")
+        n = x.shape[0]
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        b = C.c_size_t()
+        _lib.check(self.lib.dsdf_decode_workspace_bytes(C.byref(self.cnet), min(max(n, 64), max_chunk), C.byref(b)))
+        ws = self._workspace(max(b.value, 16384))
+        for s in range(0, n, max_chunk):
+            e = min(n, s + max_chunk)
+            _lib.check(self.lib.dsdf_decode_latent(C.byref(self.cnet), _ptr(self.packed), _ptr(self.params), _ptr(z),
+                                                   C.c_void_p(x.data_ptr() + 4 * s * x.shape[1]), e - s,
+                                                   C.c_void_p(out.data_ptr() + 4 * s), _ptr(ws), ws.numel(), _stream()))
+        return out.view(n, 1)
+
     # ---- module path (autograd) -----------------------------------------------------------------------------
     def module_forward(self, x, training, seed=0, step=0):
         self._fresh_weights()

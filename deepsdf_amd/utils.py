@@ -27,9 +27,21 @@ def configure_logging(args):
 
 
 def decode_sdf(decoder, latent_vector, queries):
-    """sdf = decoder([latent (broadcast) || queries]); latent_vector None => queries already carry the code."""
+    """sdf = decoder([latent (broadcast) || queries]); latent_vector None => queries already carry the code.
+
+    Inference with ONE code for all query points (every caller of the reference's decode_sdf, deep_sdf/utils.py:54-65) never
+    builds the [n, L+G] input: ``Engine.decode_latent`` hoists the code's products out of the per-point work.  Anything that
+    needs autograd, training-mode dropout, a DataParallel wrapper's module or several codes takes the module path."""
     if latent_vector is None:
-        inputs = queries
-    else:
-        inputs = torch.cat([latent_vector.expand(queries.shape[0], -1), queries], 1)
+        return decoder(queries)
+    dec = decoder.module if isinstance(decoder, torch.nn.DataParallel) else decoder
+    grad = torch.is_grad_enabled() and (latent_vector.requires_grad or queries.requires_grad
+                                        or any(p.requires_grad for p in dec.parameters()))
+    spec = getattr(dec, "spec", None)
+    if (spec is not None and not grad and not dec.training and latent_vector.numel() == spec.latent_size and queries.is_cuda
+            and not spec.forward_bf16 and spec.geom_dimension <= 4 and max(spec.dims) <= 512 and len(spec.dims) >= 2):
+        eng = dec._engine_for(queries.device)
+        eng.weights_dirty = True   # parameters may have been changed by any optimizer since the last call
+        return eng.decode_latent(latent_vector, queries)
+    inputs = torch.cat([latent_vector.expand(queries.shape[0], -1), queries], 1)
     return decoder(inputs)

@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define DSDF_MAX_LAYERS 16
-#define DSDF_ABI_VERSION 7
+#define DSDF_ABI_VERSION 8
 
 enum {
   DSDF_OK = 0,
@@ -118,6 +118,14 @@ int dsdf_materialize_weights(const DsdfNet* net, const float* params, float* pac
  * input [n, L+G] (latent first, xyz last) with row stride ld_in floats -> sdf [n]. */
 int dsdf_decode(const DsdfNet* net, const float* packed, const float* params, const float* input, int64_t ld_in,
                 int64_t n, float* sdf_out, void* ws, size_t ws_bytes, void* stream);
+
+/* deep_sdf/utils.py:54-65 decode_sdf with ONE latent vector for all query points (what every caller does: mesh.py:61-70,
+ * 262-271): sdf = Decoder.eval()([latent.expand(n) || xyz]).  The [n, L+G] input is never built: W[:, latent] latent is
+ * computed once and enters the forward as the accumulators' initial value (segment mode).  latent [L],
+ * xyz [n, G], sdf_out [n]; workspace: dsdf_decode_workspace_bytes.  Needs the fp32 fused forward (widths <= 512,
+ * geom_dim <= 4, at least two hidden layers), otherwise DSDF_E_INVALID: use dsdf_decode. */
+int dsdf_decode_latent(const DsdfNet* net, const float* packed, const float* params, const float* latent, const float* xyz,
+                       int64_t n, float* sdf_out, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- module path: Decoder.forward / autograd backward on an explicit input (plugin seam,
  * train_deep_sdf.py:275,514).  forward keeps activations in ws; backward consumes them. */

@@ -70,6 +70,35 @@ def test_golden_eval_forward(name):
     assert rel_err(y.cpu().reshape(-1), g.get("out/y")) <= FWD_TOL
 
 
+@pytest.mark.parametrize("name", ["g8_eval_8x512", "g8_eval_6x128"])
+def test_decode_latent_single_code(name):
+    """dsdf_decode_latent (ONE code for all points, its products hoisted) == dsdf_decode on the materialised [n, L+G] input
+    == the oracle, for n off the 64 grid; and deep_sdf.utils.decode_sdf takes that path in eval mode."""
+    from deepsdf_amd.engine import Engine
+    from deepsdf_amd.decoder import Decoder
+    from deepsdf_amd.utils import decode_sdf
+    g = Golden(name)
+    L = g.meta["L"]
+    net = orc.make_net(L, **g.meta["net_specs"])
+    params = orc.init_params(net, g.meta["seed"])
+    eng = Engine(spec_from_meta(g.meta))
+    eng.load_params(params)
+    gen = torch.Generator().manual_seed(3)
+    z = torch.randn(L, generator=gen) / math.sqrt(L)
+    for n in (1, 63, 1000, 70001):
+        xyz = torch.rand(n, 3, generator=gen) * 2 - 1
+        x = torch.cat([z.expand(n, -1), xyz], 1)
+        yo = orc.decoder_forward(net, params, x, training=False)[0].reshape(-1)
+        yl = eng.decode_latent(z.cuda(), xyz.cuda()).cpu().reshape(-1)
+        yd = eng.decode(x.cuda()).cpu().reshape(-1)
+        assert rel_err(yl, yo) <= FWD_TOL and rel_err(yl, yd) <= FWD_TOL, n
+    dec = Decoder(L, **g.meta["net_specs"]).cuda().eval()
+    dec.load_state_dict({k: v for k, v in params.items()})
+    with torch.no_grad():
+        ys = decode_sdf(dec, z.cuda()[None, :], xyz.cuda())
+    assert ys.shape == (xyz.shape[0], 1) and rel_err(ys.cpu().reshape(-1), yo) <= FWD_TOL
+
+
 def test_real_weights_known_answer():
     from deepsdf_amd.engine import Engine
     g = Golden("g6_real_weights")

@@ -48,3 +48,17 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(10): big()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
 print(f"64 scenes x 16384 samples (1,048,576 pts/step): {dt*1e3:.2f} ms/step = {B*S/dt/1e6:.2f} M point-samples/s; workspace {eng._ws.numel()/2**30:.1f} GiB")
+# inference: one code, 1 M query points -- the [n, L+G] input materialised (dsdf_decode) vs hoisted (dsdf_decode_latent)
+n = 1 << 20
+z = torch.randn(bench.L, device=dev) / math.sqrt(bench.L)
+q = torch.rand(n, 3, device=dev) * 2 - 1
+def dec_cat():
+    return eng.decode(torch.cat([z.expand(n, -1), q], 1))
+def dec_lat():
+    return eng.decode_latent(z, q)
+for name, f in (("decode_sdf as the reference does it (cat + dsdf_decode)", dec_cat), ("dsdf_decode_latent", dec_lat)):
+    for _ in range(3): f()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): f()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+    print(f"inference, 1 code x {n} points, {name}: {dt*1e3:.2f} ms = {n/dt/1e6:.1f} M points/s")
