@@ -147,7 +147,10 @@ def main():
     dist.barrier()
     torch.cuda.synchronize()
     elapsed = dist.max_over_ranks(time.perf_counter() - t0, dev)
-    loss = float(eng.loss.item())
+    loss_t = eng.loss.detach().clone().reshape(1)
+    if world > 1:                      # every rank holds its partial of the globally normalised loss (train_deep_sdf.py:519)
+        dist.allreduce_sum_(loss_t)
+    loss = float(loss_t.item())
     if not math.isfinite(loss):
         raise SystemExit("non-finite loss in the timed region")
 
