@@ -3,7 +3,20 @@ ScenesPerBatch 64 x SamplesPerScene 256 = 16384 pts/step, 4 steps per epoch).  U
 import json, os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from oracle import deepsdf_oracle as orc
+
+
+def sphere_scene(k, n_points):
+    """Synthetic sphere-SDF scene in the on-disk sample format (pos / neg arrays [*, 4] fp32)."""
+    rng = np.random.default_rng(1234 + k)
+    c, r = rng.uniform(-0.3, 0.3, 3), rng.uniform(0.3, 0.6)
+    h = n_points // 2
+    d = rng.normal(size=(n_points - h, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pts = np.concatenate([rng.uniform(-1, 1, (h, 3)), c + r * d + rng.normal(0, 0.05, (n_points - h, 3))], 0)
+    s = np.concatenate([pts, (np.linalg.norm(pts - c, axis=1) - r)[:, None]], 1).astype(np.float32)
+    return s[s[:, 3] >= 0], s[s[:, 3] < 0]
+
+
 from deepsdf_amd import train
 epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 root = tempfile.mkdtemp()
@@ -11,7 +24,7 @@ d = os.path.join(root, "data", "SdfSamples", "synth", "spheres"); os.makedirs(d)
 names = []
 NSC = 256
 for k in range(NSC):
-    pos, neg = orc.sphere_scene(k, 20000)
+    pos, neg = sphere_scene(k, 20000)
     np.savez(os.path.join(d, f"s{k}.npz"), pos=pos, neg=neg); names.append(f"s{k}")
 json.dump({"synth": {"spheres": names}}, open(os.path.join(root, "split.json"), "w"))
 exp = os.path.join(root, "exp"); os.makedirs(exp)
