@@ -752,13 +752,16 @@ __device__ __forceinline__ void seg_scatter_body(const ScatterArgs& p, int r) {
 __global__ __launch_bounds__(256) void seg_scatter_kernel(const ScatterArgs p) { seg_scatter_body(p, blockIdx.x); }
 
 // finalize_all_kernel with the dense latent-gradient scatter (+ loss) as extra blocks: in segment mode the scatter's inputs
-// exist before the finalize launch, so the two share it (blocks >= rows take one segment each)
+// exist before the finalize launch, so the two share it (the first R blocks take one segment each)
 __global__ __launch_bounds__(256) void finalize_scatter_kernel(const FinAll p, const ScatterArgs sc, const int rows) {
-  if ((int)blockIdx.x >= rows) { seg_scatter_body(sc, (int)blockIdx.x - rows); return; }
+  // the scatter blocks come FIRST: they are a chain of dependent loads (latency, not bandwidth) and would otherwise start
+  // only after every finalize block has been dispatched, as the tail of the launch
+  if ((int)blockIdx.x < sc.R) { seg_scatter_body(sc, (int)blockIdx.x); return; }
   __shared__ float red[4];
+  const int b = (int)blockIdx.x - sc.R;
   int l = 0;
-  while (l + 1 < p.n && (int)blockIdx.x >= p.row0[l + 1]) ++l;
-  finalize_row(p.f[l], blockIdx.x - p.row0[l], red);
+  while (l + 1 < p.n && b >= p.row0[l + 1]) ++l;
+  finalize_row(p.f[l], b - p.row0[l], red);
 }
 
 // ---------------------------------------------------------------------------------------------------
