@@ -80,3 +80,22 @@ def test_size_queries_survive_degenerate_batches(lib):
         assert lib.dsdf_workspace_bytes(C.byref(net), n, 1 if n else 0, C.byref(b)) == 0 and b.value > 0
         assert lib.dsdf_decode_workspace_bytes(C.byref(net), n, C.byref(b)) == 0
     assert lib.dsdf_workspace_bytes(C.byref(net), -1, 0, C.byref(b)) == -1
+
+
+def test_argument_errors_are_reported_before_any_launch(lib):
+    """Entry points validate their arguments on the host and fail with a message (no GPU needed to see that)."""
+    from deepsdf_amd import _lib
+    from deepsdf_amd.net import NetSpec
+    lib.dsdf_last_error.restype = C.c_char_p
+    assert lib.dsdf_sample_batch(None, 3, None, None, None, None, None, 4, 64, 1, None, None, None) == -1
+    assert b"NULL" in lib.dsdf_last_error()
+    dummy = C.c_void_p(256)     # never dereferenced: the shape checks come first
+    assert lib.dsdf_sample_batch(dummy, 0, dummy, dummy, dummy, dummy, dummy, 4, 64, 1, dummy, dummy, None) == -1
+    assert b"geom_dim" in lib.dsdf_last_error()
+    assert lib.dsdf_sample_batch(dummy, 3, dummy, dummy, dummy, dummy, dummy, 4, 1, 1, dummy, dummy, None) == -1   # 2*(1//2) == 0 rows
+    # the bf16 forward exists for widths <= 512 only, and the single-code decode needs the fp32 fused forward
+    wide = NetSpec(8, [640, 640], 3, forward_bf16=True).c_struct()
+    n = C.c_int64()
+    assert lib.dsdf_packed_floats(C.byref(wide), C.byref(n)) == -1 and b"fwd_bf16" in lib.dsdf_last_error()
+    net = NetSpec(8, [64, 64], 3).c_struct()
+    assert lib.dsdf_decode_latent(C.byref(net), None, None, None, None, 10, None, None, 0, None) == -1
