@@ -15,6 +15,12 @@
 //
 // k-permutation: within a unit of 16, lane (r, h) holds k = 16u + 8h + j (j = 0..7) for BOTH operands, so MFMA j
 // contracts k in {16u + j, 16u + 8 + j}: a permutation of the sum order only.
+//
+// A lone wave pays for every instruction it issues between its MFMAs, so per-load address arithmetic lives on the scalar
+// unit (FusedBView: buffer resource + SGPR tile/unit offsets; the epilogues' buffer stores with scalar row offsets).
+// Kernels: fused_forward_kernel (inference / module path), fused_backward_kernel (module path), fused_fwd_bwd_kernel
+// (training: both bodies in one launch, the last hidden activation stays in the slab), fused_forward_bf16_kernel
+// (BASELINE config 5).  Segment mode (FusedSeg) hoists the per-scene latent products out of the per-point work.
 #pragma once
 #include <type_traits>
 

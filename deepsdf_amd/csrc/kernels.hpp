@@ -1,6 +1,7 @@
 // kernels.hpp -- the HBM-bound kernels around the GEMMs (gfx950): latent renorm/gather/concat, weight-norm
 // materialisation, last-layer GEMV + tanh + clamped-L1 + its backward, split-K/weight-norm finalisation,
-// segmented latent-gradient reduction, fused Adam.  All reductions are deterministic (fixed order).
+// segmented latent-gradient reduction, fused Adam; segment mode: per-scene hoisting (seg_hoist), the x0 columns of the weight
+// gradients and the per-segment latent gradient from per-workgroup sums (post_bwd roles).  All reductions are deterministic.
 #pragma once
 #include "common.hpp"
 
