@@ -1,11 +1,13 @@
 """Build libdsdf_hip.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc.  No torch involved."""
+import glob
 import os
 import shutil
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "dsdf_api.hip")
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("dsdf_api.hip", "gemm.hpp", "kernels.hpp", "common.hpp")] + [
+# every kernel source is a dependency: a stale .so would travel to the GPU box and be the thing measured
+DEPS = sorted(glob.glob(os.path.join(HERE, "csrc", "*.hip")) + glob.glob(os.path.join(HERE, "csrc", "*.hpp"))) + [
     os.path.join(os.path.dirname(HERE), "include", "dsdf.h")]
 LIB = os.environ.get("DSDF_LIB_PATH") or os.path.join(HERE, "libdsdf_hip.so")   # override: lab builds only
 

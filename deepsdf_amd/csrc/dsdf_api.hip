@@ -10,6 +10,8 @@
 
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "dwstream.hpp"
 #include "sample.hpp"
 #include "fused.hpp"
@@ -167,16 +169,21 @@ struct DwSched {
   long long slab[DSDF_MAX_LAYERS];
   int n_full, n_narrow;
 };
+// waves of the CURRENT device (4 per CU).  The CU count is an immutable property of a device, cached per device ordinal
+// (relaxed atomics: every writer stores the same value), so processes / threads driving different devices each get
+// their own device's schedule -- no first-device-wins global.
 int chip_waves() {
-  static int waves = 0;
-  if (waves == 0) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-      waves = 4 * cus;
-    else
-      waves = 4 * 256;   // MI355X
+  constexpr int MAXDEV = 64;
+  static std::atomic<int> cache[MAXDEV];
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 4 * 256;   // MI355X
+  if (dev < MAXDEV) {
+    const int w = cache[dev].load(std::memory_order_relaxed);
+    if (w > 0) return w;
   }
+  int waves = 4 * 256;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) waves = 4 * cus;
+  if (dev < MAXDEV) cache[dev].store(waves, std::memory_order_relaxed);
   return waves;
 }
 int skip_layer(const DsdfNet* n) {

@@ -9,8 +9,14 @@ latent rows are owned by exactly one rank, so they need no communication at all.
 """
 import os
 
-import torch
-import torch.distributed as dist
+# ROCr / RCCL read their HSA_* / NCCL_* variables when the HIP runtime initialises, i.e. at the first torch.cuda call of
+# the process: defaults must therefore be in the environment BEFORE anything touches the GPU -- at import time of this
+# module (deepsdf_amd/__init__.py imports it first), not inside init().  This pool's host driver only supports dmabuf
+# IPC: without HSA_ENABLE_IPC_MODE_LEGACY=0, RCCL's hipIpcGetMemHandle fails with "invalid argument".
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch                          # noqa: E402  (importing torch does not initialise HIP)
+import torch.distributed as dist      # noqa: E402
 
 
 def env_world():
@@ -27,7 +33,6 @@ def init(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             torch.cuda.set_device(local)
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver only supports dmabuf IPC
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
 
@@ -44,6 +49,16 @@ def allreduce_sum_(flat):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
+
+
+def allreduce_sum_async(flat):
+    """Start the in-place SUM all-reduce of a flat fp32 arena and return its Work handle (None for a single process).
+    With the nccl (= RCCL) backend the collective runs on RCCL's own stream, ordered after everything already enqueued on
+    the current stream; kernels enqueued on the current stream before ``work.wait()`` overlap with it, and ``wait()`` makes
+    the current stream (not the host) wait.  With gloo (CPU tests, single-card rehearsal) ``wait()`` blocks the host."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+    return None
 
 
 def is_multi():

@@ -229,7 +229,15 @@ class Engine:
                                            C.c_void_p(self.clip.data_ptr() + 4), _ptr(ws), ws.numel(), _stream()))
         return self.clip
 
+    def adam_latents(self, latents, dlat, lat_m, lat_v, lr_latent, *, betas=(0.9, 0.999), eps=1e-8):
+        """Adam on the latent table alone, as step `self.step + 1` (the data-parallel step runs it under the decoder
+        gradient's all-reduce; the following adam_step(None, ...) advances the shared step counter)."""
+        cfg = _lib.DsdfAdamCfg(self.step + 1, 0.0, float(lr_latent), betas[0], betas[1], eps, None)
+        _lib.check(self.lib.dsdf_adam_latent_only(_ptr(latents), _ptr(dlat), _ptr(lat_m), _ptr(lat_v), latents.numel(),
+                                                  C.byref(cfg), _stream()))
+
     def adam_step(self, latents, dlat, lat_m, lat_v, lr_decoder, lr_latent, *, clip=False, betas=(0.9, 0.999), eps=1e-8):
+        """Adam on the decoder arena (+ the latent table unless `latents` is None) and weight re-materialisation."""
         self.step += 1
         cfg = _lib.DsdfAdamCfg(self.step, float(lr_decoder), float(lr_latent), betas[0], betas[1], eps,
                                (self.clip.data_ptr() + 4) if clip else None)

@@ -241,8 +241,10 @@ class FusedTrainStep:
         self.code_bound, self.grad_clip, self.seed = code_bound, grad_clip, seed
 
     def __call__(self, scene_rows, samples_per_scene, xyz, sdf_gt, epoch, lr_decoder, lr_latent, batch_split=1,
-                 n_norm=None):
-        """scene_rows [B] (rows of self.lat), xyz [B*S, G], sdf_gt [B*S]; returns nothing (loss in eng.loss)."""
+                 n_norm=None, under_allreduce=None):
+        """scene_rows [B] (rows of self.lat), xyz [B*S, G], sdf_gt [B*S]; returns nothing (loss in eng.loss).
+        under_allreduce: optional callable that enqueues work independent of this step's decoder gradient (e.g. the next
+        batch's sampling); it runs exactly once per call, under the gradient all-reduce when there is one."""
         N = xyz.shape[0]
         n_norm = N if n_norm is None else n_norm
         uniform = 0
@@ -271,6 +273,8 @@ class FusedTrainStep:
             self.eng.train_step(self.lat, self.dlat, self.lat_m, self.lat_v, sc, so, xc, gc, n_norm=n_norm,
                                 clamp_dist=self.clamp_dist, reg_coef=reg, code_bound=self.code_bound, lr_decoder=lr_decoder,
                                 lr_latent=lr_latent, training=True, seed=self.seed, seg_len=uniform)
+            if under_allreduce is not None:
+                under_allreduce()
             return
         row0 = 0
         for ci, (sc, so, xc, gc) in enumerate(chunks):
@@ -278,10 +282,25 @@ class FusedTrainStep:
                                             reg_coef=reg, code_bound=self.code_bound, training=True, seed=self.seed,
                                             row_offset=row0, accumulate=ci > 0, seg_len=uniform)
             row0 += xc.shape[0]
-        dist.allreduce_sum_(self.eng.grads)
+        # Data parallel (train_deep_sdf.py:353 replaced): ONE sum all-reduce of the decoder-gradient
+        # arena, issued asynchronously (RCCL runs it on its own stream, ordered after the finalize launch that wrote the
+        # arena).  Everything that does not need the reduced gradient is enqueued on the compute stream meanwhile: the Adam
+        # update of this rank's latent rows (their gradient is complete and private to the owner rank) and `under_allreduce`
+        # (the trainer passes the NEXT batch's sampling kernel).  The decoder's Adam + weight re-materialisation wait for it.
+        work = dist.allreduce_sum_async(self.eng.grads)
+        if work is not None:
+            self.eng.adam_latents(self.lat, self.dlat, self.lat_m, self.lat_v, lr_latent)
+            if under_allreduce is not None:
+                under_allreduce()
+            work.wait()                       # nccl: the compute stream waits for RCCL's stream (no host block)
         if self.grad_clip is not None:
             self.eng.grad_norm(self.grad_clip)
-        self.eng.adam_step(self.lat, self.dlat, self.lat_m, self.lat_v, lr_decoder, lr_latent, clip=self.grad_clip is not None)
+        if work is not None:
+            self.eng.adam_step(None, None, None, None, lr_decoder, lr_latent, clip=self.grad_clip is not None)
+        else:
+            self.eng.adam_step(self.lat, self.dlat, self.lat_m, self.lat_v, lr_decoder, lr_latent, clip=self.grad_clip is not None)
+            if under_allreduce is not None:
+                under_allreduce()
 
 
 # ---- driver ---------------------------------------------------------------------------------------------------------
@@ -406,19 +425,37 @@ def main_function(experiment_directory, continue_from, batch_split):
     logging.info("Number of shape code parameters: {} (# codes {}, code dim {})".format(
         num_scenes * latent_size, num_scenes, latent_size))
 
+    # Batch semantics at world > 1.  The reference wraps the decoder in nn.DataParallel (train_deep_sdf.py:353), which
+    # SPLITS the one ScenesPerBatch batch over the GPUs (:514): the same specs.json trains with the same global batch and
+    # learning rate on any number of GPUs.  Default here = the same: every rank takes ScenesPerBatch / world scenes per
+    # step.  DSDF_SCENES_PER_BATCH_PER_RANK=1 keeps ScenesPerBatch scenes PER RANK instead (weak scaling: the global batch
+    # grows with the world size and the learning rate is NOT rescaled -- a different optimisation problem, opt-in only).
     n_local = hi - lo
-    steps_per_epoch = n_local // scene_per_batch            # drop_last=True (:374)
+    per_rank = os.environ.get("DSDF_SCENES_PER_BATCH_PER_RANK") == "1"
+    if world > 1 and not per_rank:
+        if scene_per_batch % world != 0:
+            raise RuntimeError("ScenesPerBatch {} is not divisible by the {} data-parallel ranks (nn.DataParallel would split "
+                               "the batch unevenly; set DSDF_SCENES_PER_BATCH_PER_RANK=1 for a per-rank batch)".format(
+                                   scene_per_batch, world))
+        local_batch = scene_per_batch // world
+    else:
+        local_batch = scene_per_batch
+    steps_per_epoch = n_local // local_batch                 # drop_last=True (:374)
     if world > 1:                                            # every rank must take the same number of steps
         t = torch.tensor([steps_per_epoch], device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
         steps_per_epoch = int(t.item())
-    loss_buf = torch.zeros(max(steps_per_epoch, 1), device=device)
+    if steps_per_epoch == 0:
+        raise RuntimeError("no full batch: {} scenes on the smallest of {} rank(s) but {} scenes per batch and rank "
+                           "(the reference's DataLoader(drop_last=True) would train nothing either)".format(
+                               n_local, world, local_batch))
+    loss_buf = torch.zeros(steps_per_epoch, device=device)
     stats = EpochStats(device, steps_per_epoch, decoder)
     order_pinned = [torch.empty(n_local, dtype=torch.int64).pin_memory() for _ in range(2)]
     order_device = [torch.empty(n_local, dtype=torch.int64, device=device) for _ in range(2)]
     gen = torch.Generator(device=device)
     gen.manual_seed(int(torch.initial_seed() & 0x7FFFFFFF) + 7919 * rank)
-    n_norm = scene_per_batch * num_samp_per_scene * world    # loss normaliser = GLOBAL points per step (:519)
+    n_norm = local_batch * num_samp_per_scene * world        # loss normaliser = GLOBAL points per step (:519)
     start_train = time.time()
     for epoch in range(start_epoch, num_epochs + 1):
         start = time.time()
@@ -432,12 +469,22 @@ def main_function(experiment_directory, continue_from, batch_split):
         opin.copy_(order)
         order_dev = order_device[epoch & 1]
         order_dev.copy_(opin, non_blocking=True)
+
+        def draw(it):
+            sl = slice(it * local_batch, (it + 1) * local_batch)
+            xyz, sdf_gt = cache.sample(order[sl], num_samp_per_scene, generator=gen, scene_ids_device=order_dev[sl])
+            return order_dev[sl], xyz, sdf_gt
+
+        nxt = [draw(0)]
         for it in range(steps_per_epoch):
-            sl = slice(it * scene_per_batch, (it + 1) * scene_per_batch)
-            scenes, scenes_dev = order[sl], order_dev[sl]
-            xyz, sdf_gt = cache.sample(scenes, num_samp_per_scene, generator=gen, scene_ids_device=scenes_dev)
+            scenes_dev, xyz, sdf_gt = nxt[0]
+
+            def prefetch(it=it):                             # the next batch's sampling kernel: independent of this step's
+                if it + 1 < steps_per_epoch:                 # gradients, so at world > 1 it runs under their all-reduce
+                    nxt[0] = draw(it + 1)
+
             fused(scenes_dev, 2 * int(num_samp_per_scene / 2), xyz, sdf_gt, epoch, lr0, lr1,
-                  batch_split=batch_split, n_norm=n_norm)
+                  batch_split=batch_split, n_norm=n_norm, under_allreduce=prefetch)
             loss_buf[it:it + 1].copy_(eng.loss)
         if world > 1:
             torch.distributed.all_reduce(loss_buf)           # per-rank partial losses share the global normaliser
