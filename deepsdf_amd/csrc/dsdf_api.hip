@@ -1043,6 +1043,63 @@ int dsdf_module_backward(const DsdfNet* net, const float* packed, const float* p
   return 0;
 }
 
+// Forward-mode tangent of the decoder at the point of the last dsdf_module_forward on this workspace:
+//   t_0 = tangent;  t_{l+1} = (in_l-tangent W_l^T) * [a_{l+1} > 0] * mask_scale   (same ReLU / dropout decisions as the primal:
+//   the mask is read off the stored activations);  skip layer: in-tangent = [t_l | tangent];  out = tanh' ... tanh' (t_last w_last)
+// Layer-by-layer MFMA GEMM launches (gemm.hpp) -- this is the one-extra-pass tool of mesh.py:420, not the training hot path.
+int dsdf_module_jvp(const DsdfNet* net, const float* packed, const float* params, const float* tangent, int64_t ld_t,
+                    int64_t n, int32_t training, float* jvp_out, void* ws, size_t ws_bytes, void* stream) {
+  TRY(check_common(net, packed, params, ws));
+  if (n == 0) return 0;
+  if (!tangent || !jvp_out || n < 0 || ld_t < net->in_dim[0]) return fail(DSDF_E_INVALID, "bad tangent/jvp_out/ld_t");
+  const Plan P = make_plan(net, n, 0, false);
+  if (ws_bytes < P.total) return fail(DSDF_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, P.total);
+  hipStream_t st = (hipStream_t)stream;
+  const Packed pk = packed_layout(net);
+  const int last = net->n_layers - 1;
+  float* t0 = at<float>(ws, P.dzA_off);                      // the input tangent in a 16-byte-aligned, zero-padded layout
+  HIP_OK(hipMemsetAsync(t0, 0, (size_t)n * P.ldz * 4, st));
+  HIP_OK(hipMemsetAsync(at<float>(ws, P.dp_off[0]), 0, (size_t)n * P.ld_dp * 4, st));
+  HIP_OK(hipMemsetAsync(at<float>(ws, P.dp_off[1]), 0, (size_t)n * P.ld_dp * 4, st));
+  {
+    const long long tot = (long long)n * P.W0;
+    hipLaunchKernelGGL(add2_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, tangent, (int)ld_t, (const float*)nullptr, 0,
+                       t0, (long long)P.ldz, (int)n, P.W0);
+    LAUNCH_OK("add2_kernel(tangent)");
+  }
+  int cur = 0;
+  for (int l = 0; l < last; ++l) {
+    float* in_t = l == 0 ? t0 : at<float>(ws, P.dp_off[cur]);
+    if (l > 0 && ((net->skip_mask >> l) & 1)) {              // [t_l | tangent of x0]  (deep_sdf_decoder.py:88-89)
+      const long long tot = (long long)n * P.W0;
+      hipLaunchKernelGGL(add2_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, t0, P.ldz, (const float*)nullptr, 0,
+                         in_t + net->out_dim[l - 1], (long long)P.ld_dp, (int)n, P.W0);
+      LAUNCH_OK("add2_kernel(skip tangent)");
+    }
+    NtArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = in_t; a.lda = l == 0 ? P.ldz : P.ld_dp;
+    a.B = packed + pk.w_off[l]; a.ldb = pk.ldw[l];
+    a.C = at<float>(ws, P.dp_off[l == 0 ? 0 : cur ^ 1]); a.ldc = P.ld_dp;
+    a.M = (int)n; a.N = net->out_dim[l]; a.K = net->in_dim[l];
+    a.act = at<float>(ws, P.in_off[l + 1]); a.ldact = P.ld_in[l + 1];
+    a.mask_cols = net->out_dim[l]; a.mask_scale = mask_scale_of(net, l, training);
+    TRY(launch_nt<EPI_BWD>(a, st));
+    if (l > 0) cur ^= 1;
+  }
+  NtArgs a;                                                   // du = t_last . w_last
+  memset(&a, 0, sizeof(a));
+  a.A = at<float>(ws, P.dp_off[cur]); a.lda = P.ld_dp;
+  a.B = packed + pk.w_off[last]; a.ldb = pk.ldw[last];
+  a.C = at<float>(ws, P.y_off); a.ldc = 1;
+  a.M = (int)n; a.N = 1; a.K = net->in_dim[last];
+  TRY(launch_nt<EPI_PLAIN>(a, st));
+  hipLaunchKernelGGL(jvp_tail_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, at<float>(ws, P.y_off),
+                     at<float>(ws, P.u_off), jvp_out, (int)n, net->use_tanh);
+  LAUNCH_OK("jvp_tail_kernel");
+  return 0;
+}
+
 }  // extern "C"
 
 namespace {

@@ -850,6 +850,18 @@ __global__ void add2_kernel(const float* a, int lda, const float* b, int ldb, fl
   o[(size_t)r * ldo + c] = v;
 }
 
+// tangent of the output nonlinearity (deep_sdf_decoder.py:94-95,108-109): y = tanh(t1), t1 = use_tanh ? tanh(u) : u
+//   dy = (1 - y^2) (1 - t1^2 if use_tanh) du, with u the last layer's saved pre-activation
+__global__ void jvp_tail_kernel(const float* du, const float* u, float* out, int n, int use_tanh) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float t1 = use_tanh ? tanhf(u[i]) : u[i];
+  const float y = tanhf(t1);
+  float d = du[i] * (1.f - y * y);
+  if (use_tanh) d *= 1.f - t1 * t1;
+  out[i] = d;
+}
+
 __global__ void dropout_mask_kernel(uint32_t key, uint32_t thr, int rows, int cols, uint32_t row_offset, uint8_t* out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)rows * cols) return;

@@ -37,8 +37,43 @@ class _Linear(nn.Module):
             self.register_parameter("bias", None)
 
 
+def _check_token(dec, token, what):
+    if token != dec._fwd_calls:
+        raise RuntimeError(f"deepsdf_amd.Decoder: {what} after a newer forward(): activations live in one "
+                           "workspace per module; call it before the next forward")
+
+
+class _DecoderBwdFn(torch.autograd.Function):
+    """The backward pass as a differentiable function of the incoming gradient: d_input = J^T dy is LINEAR in dy, so its
+    own backward is the forward-mode tangent J u (dsdf_module_jvp).  This is what makes the double-backward trick of
+    ``torch.autograd.functional.jvp`` work through the decoder (deep_sdf/mesh.py:420).  Parameter gradients are returned
+    but not differentiable a second time."""
+
+    @staticmethod
+    def forward(ctx, dec, dy, token, n, training, need_x):
+        _check_token(dec, token, "backward()")
+        eng = dec._engine
+        d_sdf = dy.reshape(-1).contiguous().to(torch.float32)
+        d_in = eng.module_backward(d_sdf, n, training, need_x, accumulate=False)
+        grads = tuple(eng.view(eng.grads, p).clone() for p in dec.spec.params)
+        ctx.dec, ctx.token, ctx.n, ctx.training = dec, token, n, training
+        ctx.mark_non_differentiable(*grads)
+        if d_in is None:
+            d_in = torch.zeros(0, device=dy.device)             # placeholder output (input needed no gradient)
+            ctx.mark_non_differentiable(d_in)
+        return (d_in,) + grads
+
+    @staticmethod
+    def backward(ctx, g_d_in, *g_params):
+        _check_token(ctx.dec, ctx.token, "double backward")
+        if g_d_in is None:
+            return (None,) * 6
+        ju = ctx.dec._engine.module_jvp(g_d_in, ctx.n, ctx.training)    # d <u, J^T dy> / d dy = J u
+        return None, ju, None, None, None, None
+
+
 class _DecoderFn(torch.autograd.Function):
-    """Autograd bridge of the module path (dsdf_module_forward / dsdf_module_backward)."""
+    """Autograd bridge of the module path (dsdf_module_forward / dsdf_module_backward / dsdf_module_jvp)."""
 
     @staticmethod
     def forward(ctx, dec, x, *params):
@@ -52,15 +87,18 @@ class _DecoderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        dec = ctx.dec
-        if ctx.token != dec._fwd_calls:
-            raise RuntimeError("deepsdf_amd.Decoder: backward() after a newer forward(): activations live in one "
-                               "workspace per module; call backward before the next forward")
-        eng = dec._engine
-        d_sdf = dy.reshape(-1).contiguous().to(torch.float32)
-        d_in = eng.module_backward(d_sdf, ctx.n, ctx.training, ctx.need_x, accumulate=False)
-        grads = tuple(eng.view(eng.grads, p).clone() for p in dec.spec.params)
-        return (None, d_in) + grads
+        out = _DecoderBwdFn.apply(ctx.dec, dy, ctx.token, ctx.n, ctx.training, ctx.need_x)
+        return (None, out[0] if ctx.need_x else None) + tuple(out[1:])
+
+    @staticmethod
+    def jvp(ctx, _dec, x_t, *param_ts):
+        """Forward-mode AD (torch.autograd.forward_ad) with respect to the INPUT: one tangent pass through the same GEMMs."""
+        if any(t is not None for t in param_ts):
+            raise NotImplementedError("deepsdf_amd.Decoder: forward-mode tangents of the parameters are not supported")
+        _check_token(ctx.dec, ctx.token, "jvp")
+        if x_t is None:
+            return None
+        return ctx.dec._engine.module_jvp(x_t, ctx.n, ctx.training)
 
 
 class Decoder(nn.Module):
@@ -148,6 +186,26 @@ class Decoder(nn.Module):
         if self._engine is not None:
             self._engine.weights_dirty = True
         return out
+
+    def export_torchscript(self, example_input, path=None):
+        """TorchScript module of this decoder for libtorch consumers (create_libtorch_executable.py:4-24), built from a
+        stock-torch eval-mode twin on the CPU (deepsdf_amd/export.py) -- export tooling, not a compute path."""
+        from .export import export_torchscript
+        return export_torchscript(self, example_input, path)
+
+    def jvp(self, input, tangent):
+        """(sdf, J . tangent) for input, tangent [N, L+G]: the forward-mode derivative of forward() w.r.t. its input in
+        the module's current train/eval mode, one tangent pass after the primal pass (no double backward needed)."""
+        if input.shape != tangent.shape or input.dim() != 2 or input.shape[1] != self.spec.in_dim[0]:
+            raise ValueError(f"expected input and tangent [N, {self.spec.in_dim[0]}]")
+        x = input.detach().to(torch.float32)
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        eng = self._engine_for(x.device)
+        eng.weights_dirty = True
+        self._fwd_calls += 1
+        y = eng.module_forward(x, self.training, seed=self.dropout_seed, step=self._fwd_calls)
+        return y, eng.module_jvp(tangent.detach(), x.shape[0], self.training)
 
     # ---- forward ---------------------------------------------------------------------------------------------
     def forward(self, input):

@@ -176,6 +176,19 @@ class Engine:
                                                  self.spec.in_dim[0], _ptr(ws), ws.numel(), _stream()))
         return d_in
 
+    def module_jvp(self, tangent, n, training):
+        """J . tangent at the point of the last module_forward: tangent [n, L+G] -> [n, 1] (dsdf_module_jvp)."""
+        t = tangent.to(self.device, torch.float32)
+        if t.dim() != 2 or t.shape != (n, self.spec.in_dim[0]):
+            raise ValueError(f"expected tangent [{n}, {self.spec.in_dim[0]}], got {tuple(t.shape)}")
+        if t.stride(1) != 1:
+            t = t.contiguous()
+        ws = self.train_workspace(n, 0)
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.dsdf_module_jvp(C.byref(self.cnet), _ptr(self.packed), _ptr(self.params), _ptr(t), t.stride(0), n,
+                                            int(training), _ptr(out), _ptr(ws), ws.numel(), _stream()))
+        return out.view(n, 1)
+
     # ---- training --------------------------------------------------------------------------------------------
     def train_forward_backward(self, latents, dlat, seg_scene, seg_offset, xyz, sdf_gt, *, n_norm, clamp_dist,
                                reg_coef, code_bound, training=True, seed=0, row_offset=0, accumulate=False,

@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define DSDF_MAX_LAYERS 16
-#define DSDF_ABI_VERSION 8
+#define DSDF_ABI_VERSION 9
 
 enum {
   DSDF_OK = 0,
@@ -136,6 +136,13 @@ int dsdf_module_backward(const DsdfNet* net, const float* packed, const float* p
                          int64_t n, int32_t training, float* grads /*arena, overwritten or accumulated*/,
                          int32_t accumulate, float* d_input /*[n, ld_din] or NULL*/, int64_t ld_din,
                          void* ws, size_t ws_bytes, void* stream);
+/* Forward-mode tangent (Jacobian-vector product) of Decoder.forward at the point of the LAST dsdf_module_forward on this
+ * workspace: jvp_out [n] = d sdf / d input . tangent, tangent [n, ld_t] (L+G columns used).  What
+ * torch.autograd.functional.jvp computes through the reference decoder in deep_sdf/mesh.py:420 (d vertices / d latent
+ * control points) by double backward; here it is one extra pass through the same GEMMs with the primal pass's ReLU /
+ * dropout decisions.  May be called any number of times after one forward (before or after dsdf_module_backward). */
+int dsdf_module_jvp(const DsdfNet* net, const float* packed, const float* params, const float* tangent, int64_t ld_t,
+                    int64_t n, int32_t training, float* jvp_out, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- training step ---------------------------------------------------------------------------------
  * dsdf_train_forward_backward = train_deep_sdf.py:509-533 for one chunk: max-norm renorm of the looked-up

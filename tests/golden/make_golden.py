@@ -29,6 +29,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 from oracle import deepsdf_oracle as orc  # noqa: E402
+from tests.golden_io import sphere_npz  # noqa: E402
 
 REF = "/root/reference"
 
@@ -253,10 +254,29 @@ def case_forward_eval(Decoder, name, *, L, net_specs, N, seed):
     print("wrote", name)
 
 
+def ref_trainer_module():
+    """The reference's train_deep_sdf.py imported as a module (container only).  Its package __init__ star-imports mesh /
+    metrics modules whose third-party dependencies are not installed and are not on the hot path: empty stub modules are
+    registered for them first; nothing from them is ever called."""
+    import types
+    for name in ("plyfile", "skimage", "skimage.measure", "splinepy", "trimesh"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)              # `import deep_sdf` inside the reference trainer must find the REFERENCE package
+    for k in [k for k in sys.modules if k == "deep_sdf" or k.startswith("deep_sdf.")]:
+        del sys.modules[k]
+    spec = importlib.util.spec_from_file_location("ref_train_deep_sdf", os.path.join(REF, "train_deep_sdf.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert os.path.realpath(sys.modules["deep_sdf"].__file__).startswith(REF), sys.modules["deep_sdf"].__file__
+    return mod
+
+
 def case_lr(name):
-    """G5: schedule values from the reference's schedule classes' formulas, evaluated by the reference
-    code itself is impossible without importing train_deep_sdf.py (needs matplotlib etc.); the formulas
-    (train_deep_sdf.py:28-56) are three one-liners, so this golden stores hand-evaluated doubles."""
+    """G5: learning-rate schedule values produced by the REFERENCE's own schedule classes
+    (train_deep_sdf.py:23-93: get_learning_rate_schedules -> Step / Warmup / Constant .get_learning_rate)."""
+    ref = ref_trainer_module()
     specs = [
         {"Type": "Step", "Initial": 0.0005, "Interval": 500, "Factor": 0.5},
         {"Type": "Step", "Initial": 0.001, "Interval": 500, "Factor": 0.5},
@@ -264,21 +284,87 @@ def case_lr(name):
         {"Type": "Constant", "Value": 3e-4},
     ]
     epochs = [0, 1, 499, 500, 501, 1000, 2001]
-    # literal python arithmetic of the reference's get_learning_rate bodies
-    vals = []
-    for s in specs:
-        row = []
-        for e in epochs:
-            if s["Type"] == "Step":
-                row.append(s["Initial"] * (s["Factor"] ** (e // s["Interval"])))
-            elif s["Type"] == "Warmup":
-                row.append(s["Final"] if e > s["Length"] else s["Initial"] + (s["Final"] - s["Initial"]) * e / s["Length"])
-            else:
-                row.append(s["Value"])
-        vals.append(row)
+    schedules = ref.get_learning_rate_schedules({"LearningRateSchedule": specs})
+    vals = [[float(sch.get_learning_rate(e)) for e in epochs] for sch in schedules]
+    try:
+        ref.get_learning_rate_schedules({"LearningRateSchedule": [{"Type": "Cosine"}]})
+        unknown = None
+    except Exception as e:                       # the error text the drop-in trainer mirrors (:86-91)
+        unknown = str(e)
     with open(os.path.join(HERE, name + ".json"), "w") as f:
-        json.dump({"specs": specs, "epochs": epochs, "values": vals}, f, indent=1)
+        json.dump({"specs": specs, "epochs": epochs, "values": vals, "unknown_type_error": unknown,
+                   "source": "reference train_deep_sdf.get_learning_rate_schedules (imported, container only)"}, f, indent=1)
     print("wrote", name)
+
+
+def case_reference_run(name):
+    """G10: an experiment directory WRITTEN BY THE REFERENCE TRAINER: its own main_function (train_deep_sdf.py:255-581)
+    runs 3 epochs on a synthetic 4-scene data set in a temp dir (CPU), then the TENSORS of ModelParameters/latest.pth,
+    OptimizerParameters/latest.pth, LatentCodes/latest.pth and Logs.pth are stored as arrays (data only: no pickle, no
+    reference code) together with an eval-mode forward of the trained decoder.  Pins f4's checkpoint half:
+    tests rebuild the .pth files from these arrays and resume from them with this repo's trainer."""
+    import tempfile
+    ref = ref_trainer_module()
+    import deep_sdf.workspace as rws           # the REFERENCE's workspace module (asserted in ref_trainer_module)
+    tmp = tempfile.mkdtemp(prefix="g10_")
+    data = os.path.join(tmp, "data")
+    os.makedirs(os.path.join(data, "SdfSamples", "synth", "spheres"))
+    names = [f"s{k}" for k in range(4)]
+    for k, nme in enumerate(names):
+        sphere_npz(os.path.join(data, "SdfSamples", "synth", "spheres", nme + ".npz"), k)
+    split = os.path.join(tmp, "split.json")
+    json.dump({"synth": {"spheres": names}}, open(split, "w"))
+    exp = os.path.join(tmp, "exp")
+    os.makedirs(exp)
+    net_specs = dict(dims=[32] * 4, dropout=[0, 1, 2, 3], dropout_prob=0.2, norm_layers=[0, 1, 2, 3], latent_in=[2],
+                     xyz_in_all=False, use_tanh=False, latent_dropout=False, weight_norm=True, geom_dimension=3)
+    specs = {"Description": "g10 reference run", "DataSource": data, "TrainSplit": split, "TestSplit": split,
+             "ReconstructionSplit": split, "NetworkArch": "deep_sdf_decoder", "NetworkSpecs": net_specs, "CodeLength": 4,
+             "NumEpochs": 3, "SnapshotFrequency": 3, "AdditionalSnapshots": [],
+             "LearningRateSchedule": [{"Type": "Step", "Initial": 0.0005, "Interval": 2, "Factor": 0.5},
+                                      {"Type": "Step", "Initial": 0.001, "Interval": 2, "Factor": 0.5}],
+             "SamplesPerScene": 512, "ScenesPerBatch": 2, "DataLoaderThreads": 0, "ClampingDistance": 0.1,
+             "CodeRegularization": True, "CodeRegularizationLambda": 1e-4, "CodeBound": 1.0, "LogFrequency": 1}
+    json.dump(specs, open(os.path.join(exp, "specs.json"), "w"))
+    torch.manual_seed(1010)
+    ref.main_function(exp, None, 1)
+    files = {sub: sorted(os.listdir(os.path.join(exp, sub))) for sub in ("ModelParameters", "OptimizerParameters", "LatentCodes")}
+    # files our own run of the reference wrote a moment ago: plain dicts of tensors / lists
+    m = torch.load(os.path.join(exp, "ModelParameters", "latest.pth"), weights_only=True)
+    o = torch.load(os.path.join(exp, "OptimizerParameters", "latest.pth"), weights_only=True)
+    lc = torch.load(os.path.join(exp, "LatentCodes", "latest.pth"), weights_only=True)
+    lg = torch.load(os.path.join(exp, "Logs.pth"), weights_only=True)
+    dec = rws.load_trained_model(exp, "latest").eval()      # the reference's own loader (workspace.py:212-242)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.cat([lc["latent_codes"]["weight"][torch.arange(64) % 4], torch.rand(64, 3, generator=gen) * 2 - 1], 1)
+    with torch.no_grad():
+        y = dec(x)
+    osd = o["optimizer_state_dict"]
+    meta = dict(specs={k: v for k, v in specs.items() if k not in ("DataSource", "TrainSplit", "TestSplit", "ReconstructionSplit")},
+                scene_names=names, files=files, epochs=dict(model=m["epoch"], optimizer=o["epoch"], latent=lc["epoch"], logs=lg["epoch"]),
+                model_keys=list(m["model_state_dict"].keys()),
+                param_groups=[{k: (list(v) if isinstance(v, (list, tuple)) else v) for k, v in g.items()} for g in osd["param_groups"]],
+                opt_state_ids=[int(i) for i in osd["state"].keys()],
+                step_dtype=str(osd["state"][0]["step"].dtype), step_shape=list(osd["state"][0]["step"].shape),
+                param_magnitude_keys=list(lg["param_magnitude"].keys()), n_loss=len(lg["loss"]),
+                log_value_types=dict(loss=type(lg["loss"][0]).__name__, timing=type(lg["timing"][0]).__name__,
+                                     latent_magnitude=type(lg["latent_magnitude"][0]).__name__,
+                                     learning_rate=type(lg["learning_rate"][0]).__name__))
+    out = {"meta": np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)}
+    out.update(pack("model", m["model_state_dict"]))
+    for i, st in osd["state"].items():
+        out.update(pack(f"opt{int(i)}", {k: v for k, v in st.items()}))
+    out.update(pack("latent", lc["latent_codes"]))
+    out.update(pack("logs", {"loss": torch.tensor(lg["loss"], dtype=torch.float64),
+                             "learning_rate": torch.tensor(lg["learning_rate"], dtype=torch.float64),
+                             "timing": torch.tensor(lg["timing"], dtype=torch.float64),
+                             "latent_magnitude": torch.stack([torch.as_tensor(v) for v in lg["latent_magnitude"]]).double()}))
+    out.update(pack("logs_pm", {k: torch.tensor([float(v) for v in vs], dtype=torch.float64) for k, vs in lg["param_magnitude"].items()}))
+    out.update(pack("eval", {"x": x, "y": y.reshape(-1)}))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    import shutil
+    shutil.rmtree(tmp)
+    print("wrote", name, "epochs", meta["epochs"], "files", files)
 
 
 def case_real_weights(name):
@@ -353,6 +439,32 @@ def case_latent_only(Decoder, name, *, L, net_specs, N, iters, seed, delta=0.1, 
     print("wrote", name)
 
 
+def case_checkpoint_layout(Decoder, name):
+    """G9: the KEY LAYOUT of the reference's checkpoints (train_deep_sdf.py:96-143): model_state_dict under
+    nn.DataParallel, optimizer_state_dict of Adam with the two param groups after one step, latent_codes."""
+    specs = dict(dims=[16] * 2, dropout=[0, 1], dropout_prob=0.0, norm_layers=[0, 1], latent_in=(), xyz_in_all=False,
+                 use_tanh=False, latent_dropout=False, weight_norm=True, geom_dimension=3)
+    dec = torch.nn.DataParallel(Decoder(3, **specs))
+    lat = torch.nn.Embedding(5, 3, max_norm=1.0)
+    opt = torch.optim.Adam([{"params": dec.parameters(), "lr": 5e-4}, {"params": lat.parameters(), "lr": 1e-3}])
+    x = torch.cat([lat(torch.tensor([0, 1, 1])), torch.rand(3, 3)], 1)
+    dec(x).sum().backward()
+    opt.step()
+    osd = opt.state_dict()
+    out = {
+        "model_state_dict": {k: list(v.shape) for k, v in dec.state_dict().items()},
+        "latent_codes": {k: list(v.shape) for k, v in lat.state_dict().items()},
+        "optimizer_param_groups": [{k: (v if k != "params" else list(v)) for k, v in g.items()} for g in osd["param_groups"]],
+        "optimizer_state": {str(i): {k: (list(v.shape) if torch.is_tensor(v) else v) for k, v in st.items()}
+                            for i, st in osd["state"].items()},
+        "optimizer_step_value": float(osd["state"][0]["step"]),
+        "optimizer_step_dtype": str(osd["state"][0]["step"].dtype),
+    }
+    with open(os.path.join(HERE, name + ".json"), "w") as f:
+        json.dump(out, f, indent=1, default=lambda o: list(o) if isinstance(o, tuple) else str(o))
+    print("wrote", name)
+
+
 def main():
     torch.set_num_threads(4)
     Decoder = ref_decoder_cls()
@@ -392,37 +504,14 @@ def main():
     case_forward_eval(Decoder, "g8_eval_6x128", L=1, net_specs=dict(
         dims=[128] * 6, dropout=list(range(8)), dropout_prob=0.2, norm_layers=list(range(8)), latent_in=[2],
         xyz_in_all=False, use_tanh=False, latent_dropout=False, weight_norm=True, geom_dimension=3), N=100, seed=82)
+    case_reference_run("g10_reference_run")          # LAST: it puts the reference's deep_sdf package into sys.modules
 
 
-if __name__ == "__main__" and "--layout-only" not in sys.argv:
-    main()
-
-
-def case_checkpoint_layout(Decoder, name):
-    """G9: the KEY LAYOUT of the reference's checkpoints (train_deep_sdf.py:96-143): model_state_dict under
-    nn.DataParallel, optimizer_state_dict of Adam with the two param groups after one step, latent_codes."""
-    specs = dict(dims=[16] * 2, dropout=[0, 1], dropout_prob=0.0, norm_layers=[0, 1], latent_in=(), xyz_in_all=False,
-                 use_tanh=False, latent_dropout=False, weight_norm=True, geom_dimension=3)
-    dec = torch.nn.DataParallel(Decoder(3, **specs))
-    lat = torch.nn.Embedding(5, 3, max_norm=1.0)
-    opt = torch.optim.Adam([{"params": dec.parameters(), "lr": 5e-4}, {"params": lat.parameters(), "lr": 1e-3}])
-    x = torch.cat([lat(torch.tensor([0, 1, 1])), torch.rand(3, 3)], 1)
-    dec(x).sum().backward()
-    opt.step()
-    osd = opt.state_dict()
-    out = {
-        "model_state_dict": {k: list(v.shape) for k, v in dec.state_dict().items()},
-        "latent_codes": {k: list(v.shape) for k, v in lat.state_dict().items()},
-        "optimizer_param_groups": [{k: (v if k != "params" else list(v)) for k, v in g.items()} for g in osd["param_groups"]],
-        "optimizer_state": {str(i): {k: (list(v.shape) if torch.is_tensor(v) else v) for k, v in st.items()}
-                            for i, st in osd["state"].items()},
-        "optimizer_step_value": float(osd["state"][0]["step"]),
-        "optimizer_step_dtype": str(osd["state"][0]["step"].dtype),
-    }
-    with open(os.path.join(HERE, name + ".json"), "w") as f:
-        json.dump(out, f, indent=1, default=lambda o: list(o) if isinstance(o, tuple) else str(o))
-    print("wrote", name)
-
-
-if __name__ == "__main__" and "--layout-only" in sys.argv:
-    case_checkpoint_layout(ref_decoder_cls(), "g9_checkpoint_layout")
+if __name__ == "__main__":
+    if "--layout-only" in sys.argv:
+        case_checkpoint_layout(ref_decoder_cls(), "g9_checkpoint_layout")
+    elif "--reference-trainer-only" in sys.argv:      # the two cases that import the reference's train_deep_sdf.py
+        case_lr("g5_lr_schedules")
+        case_reference_run("g10_reference_run")
+    else:
+        main()

@@ -33,3 +33,52 @@ def rel_err(a, b):
     """norm-wise relative error ||a-b|| / max(||b||, tiny) in float64."""
     a, b = a.double().reshape(-1), b.double().reshape(-1)
     return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
+def sphere_npz(path, k, n=6000):
+    """Synthetic scene k (sphere SDF) in the on-disk format of sdf_sampler/sdf_sampler.py:146: pos / neg [*, 4]."""
+    g = np.random.default_rng(1234 + k)
+    c = g.uniform(-0.3, 0.3, 3) if k else np.zeros(3)
+    r = g.uniform(0.3, 0.6) if k else 0.5
+    x = np.concatenate([g.uniform(-1, 1, (n // 2, 3)),
+                        c + r * (lambda d: d / np.linalg.norm(d, axis=1, keepdims=True))(g.normal(size=(n - n // 2, 3)))
+                        + g.normal(0, 0.05, (n - n // 2, 3))]).astype(np.float32)
+    sdf = (np.linalg.norm(x - c, axis=1) - r).astype(np.float32)
+    rows = np.concatenate([x, sdf[:, None]], 1)
+    np.savez(path, pos=rows[sdf >= 0], neg=rows[sdf < 0])
+
+
+def write_reference_experiment(root, name="g10_reference_run", which=("latest.pth",)):
+    """Rebuild, from the arrays of golden G10, the experiment directory the REFERENCE trainer wrote (train_deep_sdf.py:96-143,
+    179-199): ModelParameters/ OptimizerParameters/ LatentCodes/ <which> + Logs.pth + specs.json, plus the synthetic data
+    set it trained on.  Returns (experiment_dir, data_dir, golden)."""
+    g = Golden(name)
+    m = g.meta
+    data = os.path.join(root, "data")
+    os.makedirs(os.path.join(data, "SdfSamples", "synth", "spheres"), exist_ok=True)
+    for k, nme in enumerate(m["scene_names"]):
+        sphere_npz(os.path.join(data, "SdfSamples", "synth", "spheres", nme + ".npz"), k)
+    split = os.path.join(root, "split.json")
+    json.dump({"synth": {"spheres": m["scene_names"]}}, open(split, "w"))
+    exp = os.path.join(root, "exp")
+    os.makedirs(exp, exist_ok=True)
+    specs = dict(m["specs"], DataSource=data, TrainSplit=split, TestSplit=split, ReconstructionSplit=split)
+    json.dump(specs, open(os.path.join(exp, "specs.json"), "w"))
+    ep = m["epochs"]
+    model = {k: g.get("model/" + k) for k in m["model_keys"]}
+    state = {i: {"step": g.get(f"opt{i}/step"), "exp_avg": g.get(f"opt{i}/exp_avg"), "exp_avg_sq": g.get(f"opt{i}/exp_avg_sq")}
+             for i in m["opt_state_ids"]}
+    osd = {"state": state, "param_groups": [dict(pg, betas=tuple(pg["betas"])) for pg in m["param_groups"]]}
+    for sub, payload in (("ModelParameters", {"epoch": ep["model"], "model_state_dict": model}),
+                         ("OptimizerParameters", {"epoch": ep["optimizer"], "optimizer_state_dict": osd}),
+                         ("LatentCodes", {"epoch": ep["latent"], "latent_codes": {"weight": g.get("latent/weight")}})):
+        os.makedirs(os.path.join(exp, sub), exist_ok=True)
+        for f in which:
+            torch.save(payload, os.path.join(exp, sub, f))
+    pm = {k: [float(v) for v in g.get("logs_pm/" + k)] for k in m["param_magnitude_keys"]}
+    torch.save({"epoch": ep["logs"], "loss": [float(v) for v in g.get("logs/loss")],
+                "learning_rate": [[float(a) for a in row] for row in g.get("logs/learning_rate")],
+                "timing": [float(v) for v in g.get("logs/timing")],
+                "latent_magnitude": [v.float() for v in g.get("logs/latent_magnitude")], "param_magnitude": pm},
+               os.path.join(exp, "Logs.pth"))
+    return exp, data, g

@@ -99,16 +99,15 @@ def test_two_rank_hip_step_equals_single_process_and_oracle(tmp_path):
         assert a["step"] == b["step"] == step + 1
         # (ii) single-process HIP
         xyz, gt = steps[step]["xyz"].cuda(), steps[step]["gt"].reshape(-1).cuda()
-        losses = []
         for r, (lo, hi) in enumerate(shards):
             sc, so = make_segments(torch.arange(lo, hi).repeat_interleave(S).cuda())
             eng.train_forward_backward(lat, dlat, sc, so, xyz[lo * S:hi * S].contiguous(), gt[lo * S:hi * S].contiguous(),
                                        n_norm=N, clamp_dist=0.1, reg_coef=1e-4 * 0.57, code_bound=1.0, training=True,
                                        seed=seed_base + r, row_offset=0, accumulate=r > 0, seg_len=S)
-            losses.append(float(eng.loss))
+        loss1 = float(eng.loss)                                          # accumulate=True adds the chunk's loss to the first one's
         g1 = eng.grads.cpu().clone()
         eng.adam_step(lat, dlat, lat_m, lat_v, 5e-4, 1e-3)
-        assert abs(float(a["loss"]) - sum(losses)) <= 1e-6 * abs(sum(losses)), step
+        assert abs(float(a["loss"]) - loss1) <= 1e-6 * abs(loss1), step
         assert rel_err(a["grads"], g1) <= 1e-6, step                     # all-reduce == accumulation over the shards
         assert rel_err(a["params"], eng.params.cpu()) <= 1e-6, step
         assert rel_err(a["exp_avg"], eng.exp_avg.cpu()) <= 1e-6 and rel_err(a["exp_avg_sq"], eng.exp_avg_sq.cpu()) <= 2e-6, step

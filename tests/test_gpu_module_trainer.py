@@ -204,3 +204,115 @@ def test_reconstruct_cli_writes_codes(tmp_path):
     assert sorted(os.listdir(d)) == ["s0.pth", "s1.pth", "s2.pth", "s3.pth"]
     code = torch.load(os.path.join(d, "s0.pth"), weights_only=True)
     assert code.shape == (1, 1, 4) and bool(torch.isfinite(code).all())
+
+
+def test_resume_from_a_checkpoint_written_by_the_reference_trainer(tmp_path):
+    """SURVEY 8f row f4, checkpoint half.  Golden G10 holds the tensors of an experiment the REFERENCE's main_function wrote
+    (train_deep_sdf.py:96-143,179-199).  (1) the downstream-consumer loader + HIP eval forward reproduce the reference's
+    outputs on those weights; (2) `-c latest` resumes from it and trains on; (3) what this trainer then writes has the
+    reference's keys, shapes, dtypes and optimizer-group options."""
+    from deepsdf_amd import train, workspace as ws
+    from tests.golden_io import write_reference_experiment
+    exp, _, g = write_reference_experiment(str(tmp_path))
+    m = g.meta
+    decoder = ws.load_trained_model(exp, "latest")
+    decoder.eval()
+    with torch.no_grad():
+        y = decoder(g.get("eval/x").cuda())
+    assert rel_err(y.cpu().reshape(-1), g.get("eval/y")) <= 1e-5
+    lat = ws.load_latent_vectors(exp, "latest")
+    assert torch.equal(lat.cpu(), g.get("latent/weight"))
+    specs = json.load(open(os.path.join(exp, "specs.json")))
+    specs["NumEpochs"], specs["SnapshotFrequency"] = 5, 5
+    json.dump(specs, open(os.path.join(exp, "specs.json"), "w"))
+    torch.manual_seed(3)
+    train.main_function(exp, "latest", 1)
+    logs = torch.load(os.path.join(exp, "Logs.pth"), weights_only=True)
+    ref_loss = [float(v) for v in g.get("logs/loss")]
+    assert logs["epoch"] == 5 and len(logs["loss"]) == 10 and logs["loss"][:6] == ref_loss     # the reference's log is kept
+    assert logs["learning_rate"][:3] == [[float(a) for a in r] for r in g.get("logs/learning_rate")]
+    assert logs["learning_rate"][3:] == [[5e-4 * 0.25, 1e-3 * 0.25]] * 2
+    assert all(math.isfinite(v) for v in logs["loss"])
+    assert sum(logs["loss"][6:]) / 4 <= 1.5 * sum(ref_loss[4:]) / 2                           # training continues, no restart jump
+    assert list(logs["param_magnitude"].keys()) == m["param_magnitude_keys"] and all(len(v) == 5 for v in logs["param_magnitude"].values())
+    mo = torch.load(os.path.join(exp, "ModelParameters", "5.pth"), weights_only=True)
+    assert mo["epoch"] == 5 and list(mo["model_state_dict"].keys()) == m["model_keys"]
+    moved = 0.0
+    for k, v in mo["model_state_dict"].items():
+        ref = g.get("model/" + k)
+        assert v.dtype == ref.dtype and v.shape == ref.shape, k
+        moved = max(moved, rel_err(v, ref))
+    assert 0 < moved < 0.1                                                                     # same run, a few Adam steps further
+    o = torch.load(os.path.join(exp, "OptimizerParameters", "5.pth"), weights_only=True)["optimizer_state_dict"]
+    assert sorted(o["state"].keys()) == m["opt_state_ids"]
+    for i in m["opt_state_ids"]:
+        for k in ("step", "exp_avg", "exp_avg_sq"):
+            ref = g.get(f"opt{i}/{k}")
+            assert o["state"][i][k].dtype == ref.dtype and tuple(o["state"][i][k].shape) == tuple(ref.shape), (i, k)
+        assert float(o["state"][i]["step"]) == 10.0                                           # 6 reference steps + 4 of ours
+    strip = lambda pg: {k: (list(v) if isinstance(v, (tuple, list)) else v) for k, v in pg.items() if k != "lr"}  # noqa: E731
+    assert [strip(pg) for pg in o["param_groups"]] == [strip(pg) for pg in m["param_groups"]]
+    lc = torch.load(os.path.join(exp, "LatentCodes", "5.pth"), weights_only=True)
+    assert lc["epoch"] == 5 and list(lc["latent_codes"].keys()) == ["weight"] and lc["latent_codes"]["weight"].shape == (4, 4)
+
+
+JVP_CASES = {
+    # the shipped small-net shape: last layer weight-normed, use_tanh (tanh o tanh), skip right after layer 0
+    "tiny_lastnorm_tanh": dict(L=2, N=333, net=dict(dims=[32] * 4, dropout=[0, 1, 2, 3], dropout_prob=0.2, norm_layers=list(range(8)),
+                                                    latent_in=[1], weight_norm=True, use_tanh=True, geom_dimension=3)),
+    # the headline architecture; N off every tile grid
+    "8x512": dict(L=256, N=1000, net=dict(dims=[512] * 8, dropout=list(range(8)), dropout_prob=0.2, norm_layers=list(range(8)),
+                                          latent_in=[4], weight_norm=True, use_tanh=False, geom_dimension=3)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(JVP_CASES))
+def test_decoder_jvp_vs_oracle(name):
+    """forward-mode derivative d sdf / d input . tangent (deep_sdf/mesh.py:420 pushes latent-space tangents
+    through the decoder with torch.autograd.functional.jvp = double backward).  Truth: torch.autograd.functional.jvp of the
+    ORACLE's forward in float64 on the CPU.  HIP: (a) Decoder.jvp (one tangent pass, dsdf_module_jvp), (b) the reference's
+    own call, torch.autograd.functional.jvp through Decoder.forward (double backward: _DecoderBwdFn), (c) forward-mode AD
+    (torch.autograd.forward_ad) -- in eval mode and in train mode (the tangent sees the primal pass's dropout decisions)."""
+    import torch.autograd.forward_ad as fwAD
+    from deepsdf_amd.decoder import Decoder
+    c = JVP_CASES[name]
+    L, N = c["L"], c["N"]
+    net = orc.make_net(L, **c["net"])
+    params = orc.init_params(net, 17)
+    p64 = {k: v.double() for k, v in params.items()}
+    gen = torch.Generator().manual_seed(18)
+    x = torch.cat([torch.randn(N, L, generator=gen) / math.sqrt(L), torch.rand(N, 3, generator=gen) * 2 - 1], 1)
+    _, sv = orc.decoder_forward(net, p64, x.double(), training=False, track_margin=True)
+    x[sv.min_abs_pre < 1e-6] += 0.01                                    # keep every ReLU decision away from fp32 noise
+    tangents = {"latent_only": torch.cat([torch.randn(N, L, generator=gen), torch.zeros(N, 3)], 1),   # mesh.py:420
+                "full": torch.randn(N, L + 3, generator=gen)}
+    dec = Decoder(L, **c["net"]).cuda()
+    dec.load_state_dict(params)
+    for training in (False, True):
+        dec.train(training)
+        for tname, v in tangents.items():
+            y, jv = dec.jvp(x.cuda(), v.cuda())
+            masks = orc.dropout_masks(net, dec.dropout_seed, dec._fwd_calls, N) if training else None
+            f64 = lambda inp: orc.decoder_forward(net, p64, inp, training=training, masks=masks)[0]   # noqa: E731
+            yo, jo = torch.autograd.functional.jvp(f64, x.double(), v.double())
+            assert rel_err(y.cpu(), yo) <= FWD_TOL, (training, tname)
+            e = rel_err(jv.cpu(), jo)
+            print(f"jvp {name} training={training} {tname}: rel err vs fp64 oracle {e:.2e}")
+            assert e <= 2e-5, (training, tname)
+    dec.eval()
+    v = tangents["latent_only"]
+    yo, jo = torch.autograd.functional.jvp(lambda inp: orc.decoder_forward(net, p64, inp, training=False)[0], x.double(), v.double())
+    y2, j2 = torch.autograd.functional.jvp(lambda q: dec(q), x.cuda(), v.cuda())        # (b) the reference's call
+    assert rel_err(y2.cpu(), yo) <= FWD_TOL and rel_err(j2.cpu(), jo) <= 2e-5
+    with fwAD.dual_level():                                                            # (c) forward-mode AD
+        out = dec(fwAD.make_dual(x.cuda(), v.cuda()))
+        y3, j3 = fwAD.unpack_dual(out)
+    assert j3 is not None and rel_err(y3.cpu(), yo) <= FWD_TOL and rel_err(j3.cpu(), jo) <= 2e-5
+    # ordinary backward still works after the double-backward machinery (parameter + input gradients)
+    xg = x.cuda().requires_grad_(True)
+    dec(xg).sum().backward()
+    _, svo = orc.decoder_forward(net, p64, x.double(), training=False)
+    go, dx0 = orc.decoder_backward(net, p64, svo, torch.ones(N, 1, dtype=torch.float64), False)
+    assert rel_err(xg.grad.cpu(), dx0) <= GRAD_TOL
+    for pname, p in dec.named_parameters():
+        assert rel_err(p.grad.cpu(), go[pname].reshape(p.shape)) <= GRAD_TOL, pname

@@ -467,22 +467,34 @@ def test_config4_reconstruct_full_size_vs_oracle(S):
     z0 = torch.randn(Bz, L, generator=gen) * 0.01
     c = (torch.rand(Bz, 3, generator=gen) - 0.5) * 0.6
     r = 0.3 + 0.3 * torch.rand(Bz, generator=gen)
+    zo = z0.double().clone()
+    mo, vo = torch.zeros_like(zo), torch.zeros_like(zo)
     batches = []
     for it in range(iters):
         xyz = torch.rand(Bz, S, 3, generator=gen) * 2 - 1
         half = S // 2
         d = torch.randn(Bz, half, 3, generator=gen)
         xyz[:, :half] = c[:, None, :] + r[:, None, None] * d / d.norm(dim=2, keepdim=True) + 0.05 * torch.randn(Bz, half, 3, generator=gen)
-        batches.append((xyz, (xyz - c[:, None, :]).norm(dim=2) - r[:, None]))
-    zo = z0.double().clone()
-    mo, vo = torch.zeros_like(zo), torch.zeros_like(zo)
-    losses = []
-    for it, (xyz, sdf) in enumerate(batches):
+        sdf = (xyz - c[:, None, :]).norm(dim=2) - r[:, None]
         for b in range(Bz):
+            # margin-safe points (as _safe_batch: a clamp / sign flip of ONE point moves 1/S = 1.3e-4 of the code's gradient, and
+            # Adam's early steps ~ lr * g / |g| pass that on undamped): re-draw what the float64 oracle calls close
+            for _ in range(12):
+                x0 = torch.cat([zo[b:b + 1].expand(S, -1), xyz[b].double()], 1)
+                y, sv = orc.decoder_forward(net, p64, x0, training=False, track_margin=True)
+                dd = torch.clamp(y, -0.1, 0.1) - torch.clamp(sdf[b].double().reshape(-1, 1), -0.1, 0.1)
+                risky = (((y.abs() - 0.1).abs() < 2e-5) | ((dd != 0) & (dd.abs() < 2e-5))).reshape(-1) | (sv.min_abs_pre < 1e-6)
+                if not bool(risky.any()):
+                    break
+                k = int(risky.sum())
+                xyz[b, risky] = torch.rand(k, 3, generator=gen) * 2 - 1
+                sdf[b, risky] = (torch.rand(k, generator=gen) - 0.5) * 0.4
+            else:
+                raise RuntimeError("could not build a margin-safe batch")
             zb, mb, vb = zo[b:b + 1], mo[b:b + 1], vo[b:b + 1]           # views: latent_step mutates them in place
-            lo, _ = orc.latent_step(net, p64, zb, mb, vb, it + 1, xyz[b].double(), sdf[b].double(), delta=0.1,
-                                    lr=5e-3 * (0.1 if it >= 3 else 1.0), l2reg=1e-4)
-        losses.append(lo)
+            orc.latent_step(net, p64, zb, mb, vb, it + 1, xyz[b].double(), sdf[b].double(), delta=0.1,
+                            lr=5e-3 * (0.1 if it >= 3 else 1.0), l2reg=1e-4)
+        batches.append((xyz, sdf))
     grads_before = eng.grads.clone()
     zh, loss = reconstruct(eng, batches[0][0].cuda(), batches[0][1].cuda(), num_iterations=iters, clamp_dist=0.1, lr=5e-3,
                            l2reg=1e-4, z0=z0, lr_drop_every=3, callback=lambda it: (batches[it][0].cuda(), batches[it][1].cuda()))

@@ -173,3 +173,95 @@ def test_clip_logs_and_magnitudes():
     ll, lr, tl, lm, pm = train.clip_logs(list(range(12)), [[1, 1]] * 4, [0.1] * 4, [0.5] * 4, {"a": [1, 2, 3, 4]}, 2)
     assert ll == list(range(6)) and len(lr) == 2 and pm == {"a": [1, 2]}
     assert train.get_spec_with_default({"a": 1}, "b", 5) == 5
+
+
+def test_checkpoint_written_by_the_reference_trainer_loads(tmp_path):
+    """Golden G10 = the tensors of an experiment directory the REFERENCE's own main_function wrote (3 epochs, CPU).  The
+    drop-in loaders (deepsdf_amd.workspace / train: train_deep_sdf.py:116-131,146-176,202-218, workspace.py:38-51) must
+    restore exactly that state, and the oracle's eval forward on the trained weights must reproduce the reference's."""
+    from deepsdf_amd import train, workspace as ws
+    from deepsdf_amd.decoder import Decoder
+    from oracle import deepsdf_oracle as orc
+    from tests.golden_io import write_reference_experiment, rel_err
+    exp, _, g = write_reference_experiment(str(tmp_path))
+    m = g.meta
+    specs = ws.load_experiment_specifications(exp)
+    L = specs["CodeLength"]
+    dec = Decoder(L, **specs["NetworkSpecs"])
+    assert ws.load_model_parameters(exp, "latest", torch.nn.DataParallel(dec)) == 3
+    sd = dec.state_dict()
+    assert ["module." + k for k in sd.keys()] == m["model_keys"]
+    for k in sd:
+        assert torch.equal(sd[k], g.get("model/module." + k)), k
+    lat = torch.zeros(4, L)
+    assert train.load_latent_vectors(exp, "latest.pth", lat) == 3 and torch.equal(lat, g.get("latent/weight"))
+    eng = _FakeEngine(dec.spec)
+    eng.exp_avg.zero_(); eng.exp_avg_sq.zero_(); eng.step = 0
+    lm, lv = torch.zeros(4, L), torch.zeros(4, L)
+    bridge = train.AdamStateBridge(dec, eng, torch.nn.Parameter(lat.clone()), lm, lv, 0.0, 0.0)
+    assert train.load_optimizer(exp, "latest.pth", bridge) == 3
+    assert eng.step == 6 == int(g.get("opt0/step"))                      # 2 steps per epoch x 3 epochs
+    for i, p in enumerate(dec.spec.params):
+        assert torch.equal(eng.view(eng.exp_avg, p), g.get(f"opt{i}/exp_avg")), p.name
+        assert torch.equal(eng.view(eng.exp_avg_sq, p), g.get(f"opt{i}/exp_avg_sq")), p.name
+    n = len(dec.spec.params)
+    assert m["param_groups"][1]["params"] == [n] and torch.equal(lm, g.get(f"opt{n}/exp_avg")) and torch.equal(lv, g.get(f"opt{n}/exp_avg_sq"))
+    # and the bridge writes the same layout back: keys, shapes, dtypes, the step's dtype/shape, the group options
+    out = bridge.state_dict()
+    assert [{k: (list(v) if isinstance(v, (tuple, list)) else v) for k, v in pg.items() if k != "lr"} for pg in out["param_groups"]] \
+        == [{k: v for k, v in pg.items() if k != "lr"} for pg in m["param_groups"]]
+    assert sorted(out["state"].keys()) == m["opt_state_ids"]
+    for i in m["opt_state_ids"]:
+        for k in ("step", "exp_avg", "exp_avg_sq"):
+            ref = g.get(f"opt{i}/{k}")
+            assert out["state"][i][k].dtype == ref.dtype and tuple(out["state"][i][k].shape) == tuple(ref.shape), (i, k)
+    assert str(out["state"][0]["step"].dtype) == m["step_dtype"] and list(out["state"][0]["step"].shape) == m["step_shape"]
+    ll, lr, tl, lmag, pm, ep = train.load_logs(exp)
+    assert ep == 3 and len(ll) == m["n_loss"] == 6 and len(lr) == 3 and list(pm.keys()) == m["param_magnitude_keys"]
+    for k in pm:                                                          # the logged magnitudes are the norms of these tensors
+        assert abs(pm[k][-1] - float(sd[k].norm())) <= 1e-5 * float(sd[k].norm()), k
+    assert lr[2] == [5e-4 * 0.5, 1e-3 * 0.5]
+    net = orc.make_net(L, **specs["NetworkSpecs"])
+    y = orc.decoder_forward(net, {k: v for k, v in sd.items()}, g.get("eval/x"), training=False)[0].reshape(-1)
+    assert rel_err(y, g.get("eval/y")) <= 1e-6
+
+
+def test_torchscript_export_matches_reference_outputs(tmp_path):
+    """SURVEY 8f row f4, export half (create_libtorch_executable.py:4-24): the TorchScript module exported from the HIP
+    Decoder's parameters reproduces the reference's eval forward on (a) the REAL trained weights the reference ships as
+    cpp_model.pt (golden g6, f(0) = -0.1340, last layer weight-normed + tanh o tanh), (b) the 8x512 architecture (g8),
+    (c) the net the reference trainer itself trained (g10); it keeps the reference's state-dict keys and survives
+    save -> torch.jit.load, and the root script writes <experiment>/cpp_model.pt from a reference-written checkpoint."""
+    import subprocess
+    import sys
+    from deepsdf_amd.decoder import Decoder
+    from deepsdf_amd.export import to_stock_torch
+    from oracle import deepsdf_oracle as orc
+    from tests.golden_io import write_reference_experiment, rel_err
+    g = Golden("g6_real_weights")
+    dec = Decoder(g.meta["L"], **g.meta["net_specs"])
+    dec.load_state_dict(g.group("params"))
+    path = os.path.join(str(tmp_path), "cpp_model.pt")
+    sm = dec.export_torchscript(torch.zeros(1, g.meta["L"] + 3), path)
+    assert abs(float(sm(torch.zeros(1, g.meta["L"] + 3))) - g.meta["f0_survey"]) < 5e-5
+    assert list(sm.state_dict().keys()) == list(dec.state_dict().keys())
+    loaded = torch.jit.load(path)
+    x = torch.rand(37, g.meta["L"] + 3) * 2 - 1                           # the trace is not specialised to the example's batch size
+    assert torch.equal(loaded(x), sm(x)) and loaded(x).shape == (37, 1)
+    twin = to_stock_torch(dec)
+    with pytest.raises(RuntimeError, match="not a CPU training path"):
+        twin.train()
+    for name in ("g8_eval_8x512", "g8_eval_6x128"):
+        e = Golden(name)
+        net = orc.make_net(e.meta["L"], **e.meta["net_specs"])
+        d2 = Decoder(e.meta["L"], **e.meta["net_specs"])
+        d2.load_state_dict(orc.init_params(net, e.meta["seed"]))
+        y = d2.export_torchscript(e.get("in/x")[:1])(e.get("in/x"))
+        assert rel_err(y.reshape(-1), e.get("out/y")) <= 1e-6, name
+    exp, _, g10 = write_reference_experiment(str(tmp_path / "ref"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "create_libtorch_executable.py"), "-e", exp, "-c", "latest"],
+                       capture_output=True, text=True, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m = torch.jit.load(os.path.join(exp, "cpp_model.pt"))
+    assert rel_err(m(g10.get("eval/x")).reshape(-1), g10.get("eval/y")) <= 1e-6
