@@ -3,42 +3,54 @@
 
 One "step" = one full optimiser step of the hot path over one synthetic batch resident in HBM:
 latent renorm + gather + concat -> 8x512 decoder forward (weight-norm, skip@4, dropout 0.2) -> clamped-L1 + code
-regulariser -> backward -> [N>1: RCCL all-reduce of decoder grads] -> Adam on decoder + latent table -> weight
-re-materialisation.  Workload at N=1 = BASELINE.json configs[1]; N>1 = configs[2] (512 scenes sharded, weak scaling).
+regulariser -> backward -> [N>1: RCCL all-reduce of decoder grads, latent Adam under it] -> Adam on decoder + latent table
+-> weight re-materialisation.  The step object is the PRODUCT's (deepsdf_amd.train.FusedTrainStep: what train_deep_sdf.py
+runs).  Workload at N=1 = BASELINE.json configs[1]; N>1 = configs[2] (512 scenes sharded, weak scaling).
 
   python bench.py --gpus 1 --steps 50 --warmup 10
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Beside the contract's line (value / ms_per_step over the barrier-bracketed timed region) rank 0 reports, at N=1:
+  step_time_ms    median / p10 / p90 of single steps (device time between per-step events on the compute stream)
+  roofline        dominant kernel: algorithmic FLOP / HIP-event time; `traffic` (HBM bytes per launch) and `executed_frac`
+                  (MFMA FLOPs actually issued, from SQ counters) measured by rocprofv3 --pmc child passes of THIS command
+  cpu_baseline    the step in stock torch ops (oracle/torch_native.py) on this host: all cores and one core
+  config.one_scene_ms_per_step   the locality extreme B=1 x S=16384
 """
 import argparse
 import ctypes as C
 import json
 import math
 import os
+import statistics
+import subprocess
 import sys
+import threading
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+from deepsdf_amd import dist  # noqa: E402  (first: HSA_*/NCCL_* defaults must be in the environment before any GPU call)
+
+import torch  # noqa: E402
 
 PEAK_TFLOPS = 157.3          # fp32 MFMA dense peak, MI355X_MICROARCH.md "Peak FP32 (matrix)"
 NET = dict(dims=[512] * 8, dropout=list(range(8)), dropout_prob=0.2, norm_layers=list(range(8)), latent_in=[4],
            xyz_in_all=False, use_tanh=False, latent_dropout=False, weight_norm=True, geom_dimension=3)
-L, SCENES_PER_BATCH, SAMPLES = 256, 64, 256   # 64 x 256 = 16384 pts/step (SURVEY 8d config 2)
+L = 256                      # 64 scenes x 256 samples = 16384 pts/step (SURVEY 8d config 2)
 
 
-def synth_batches(n_batches, scene_lo, scene_hi, device, seed):
-    """Seeded sphere-SDF batches: every batch = SCENES_PER_BATCH scenes x SAMPLES points, staged on device."""
+def synth_batches(n_batches, scene_lo, scene_hi, device, seed, scenes_per_batch, samples):
+    """Seeded sphere-SDF batches: every batch = scenes_per_batch scenes x samples points, staged on device."""
     gen = torch.Generator().manual_seed(seed)
     n_scenes = scene_hi - scene_lo
     c = (torch.rand(n_scenes, 3, generator=gen) - 0.5) * 0.6
     r = 0.3 + 0.3 * torch.rand(n_scenes, 1, generator=gen)
     out = []
     for b in range(n_batches):
-        scenes = (torch.randperm(n_scenes, generator=gen)[:SCENES_PER_BATCH]).sort().values if n_scenes > SCENES_PER_BATCH \
+        scenes = (torch.randperm(n_scenes, generator=gen)[:scenes_per_batch]).sort().values if n_scenes > scenes_per_batch \
             else torch.arange(n_scenes)
-        idx = scenes.repeat_interleave(SAMPLES)
+        idx = scenes.repeat_interleave(samples)
         half = idx.numel() // 2
         xyz = torch.rand(idx.numel(), 3, generator=gen) * 2 - 1
         d = torch.randn(idx.numel() - half, 3, generator=gen)
@@ -46,36 +58,84 @@ def synth_batches(n_batches, scene_lo, scene_hi, device, seed):
         sel = torch.randperm(idx.numel(), generator=gen)[:idx.numel() - half]
         xyz[sel] = c[idx[sel]] + r[idx[sel]] * d + 0.05 * torch.randn(sel.numel(), 3, generator=gen)
         gt = (xyz - c[idx]).norm(dim=1, keepdim=True) - r[idx]
-        seg_off = torch.arange(0, idx.numel() + 1, SAMPLES, dtype=torch.int64)
-        out.append(dict(idx=idx, seg_scene=scenes.to(torch.int64).to(device), seg_offset=seg_off.to(device),
-                        xyz=xyz.to(device).contiguous(), gt=gt.reshape(-1).to(device).contiguous(),
-                        xyz_cpu=xyz, gt_cpu=gt))
+        out.append(dict(idx=idx, scenes=scenes.to(torch.int64).to(device), xyz=xyz.to(device).contiguous(),
+                        gt=gt.reshape(-1).to(device).contiguous(), xyz_cpu=xyz, gt_cpu=gt))
     return out
 
 
-def cpu_baseline(seconds=20.0):
-    """The oracle (CPU restatement, kind 'port') timed on this host's cores on a bounded sample of the SAME workload:
-    whole optimiser steps of config 2 (16384 pts), as many as fit in ~`seconds`."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline():
+    """The reference's CPU path restated in stock torch ops (oracle/torch_native.py: F.linear + autograd + nn.Embedding(max_norm)
+    + torch.optim.Adam, hash dropout masks injected) timed on this host on a bounded sample of the SAME workload:
+      k = all threads: 3 warm-up + 10 timed full 16384-pt optimiser steps, median;
+      k = 1 thread:    1 warm-up + 3 timed steps of a 4096-pt quarter batch (same scenes / net; per-point cost is what is reported).
+    The explicit-algebra oracle (hand-derived backward; the parity checker) is timed beside it for reference."""
     from oracle import deepsdf_oracle as orc
+    from oracle.torch_native import NativeStep
+    B, S = 64, 256
     net = orc.make_net(L, **NET)
     params = orc.init_params(net, 0)
     gen = torch.Generator().manual_seed(1)
-    lat = torch.randn(SCENES_PER_BATCH, L, generator=gen) / math.sqrt(L)
-    st = orc.TrainState.create(params, lat)
-    b = synth_batches(1, 0, SCENES_PER_BATCH, "cpu", 7)[0]
+    lat = torch.randn(B, L, generator=gen) / math.sqrt(L)
+    b = synth_batches(1, 0, B, "cpu", 7, B, S)[0]
+    n_all = torch.get_num_threads()
+
+    def time_native(idx, xyz, gt, warm, timed):
+        nat = NativeStep(net, params, lat, code_bound=1.0)
+        masks = orc.dropout_masks(net, 0, 0, idx.numel())
+        ts = []
+        for i in range(warm + timed):
+            t0 = time.perf_counter()
+            nat.step(idx, xyz, gt, delta=0.1, epoch=1, masks=masks)
+            if i >= warm:
+                ts.append(time.perf_counter() - t0)
+        return statistics.median(ts)
+
+    t_all = time_native(b["idx"], b["xyz_cpu"], b["gt_cpu"], 3, 10)
+    q = slice(0, 16 * S)                                         # 16 scenes x 256 = 4096 points
+    torch.set_num_threads(1)
+    try:
+        t_one = time_native(b["idx"][q], b["xyz_cpu"][q], b["gt_cpu"][q], 1, 3)
+    finally:
+        torch.set_num_threads(n_all)
+    st = orc.TrainState.create({k: v.clone() for k, v in params.items()}, lat.clone())
     masks = [orc.dropout_masks(net, 0, 0, b["idx"].numel())]
     kw = dict(delta=0.1, code_bound=1.0, epoch=1, masks_per_chunk=masks)
-    orc.train_step(net, st, b["idx"], b["xyz_cpu"], b["gt_cpu"], **kw)   # warm-up (first call pages MKL in)
-    n, t0 = 0, time.perf_counter()
-    while True:
+    orc.train_step(net, st, b["idx"], b["xyz_cpu"], b["gt_cpu"], **kw)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
         orc.train_step(net, st, b["idx"], b["xyz_cpu"], b["gt_cpu"], **kw)
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds or n >= 64:
-            break
-    return dict(value=n * b["idx"].numel() / dt, unit="point-samples/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n} full optimiser steps of the 16384-pt config-2 workload (oracle/deepsdf_oracle.py, torch CPU fp32, "
-                       f"dropout masks precomputed), {dt:.1f} s")
+        ts.append(time.perf_counter() - t0)
+    return dict(value=B * S / t_all, unit="point-samples/s", cores=n_all, kind="port", cpu_model=cpu_model(),
+                sample=f"oracle/torch_native.py (stock torch ops + autograd + torch.optim.Adam = the op sequence the reference runs on "
+                       f"a CPU), fp32, {n_all} threads: median of 10 full 16384-pt config-2 optimiser steps after 3 warm-up "
+                       f"({1e3 * t_all:.0f} ms/step)",
+                k1=dict(value=16 * S / t_one, cores=1, ms_per_step=1e3 * t_one,
+                        sample="same step, 1 thread, 4096-pt quarter batch: median of 3 steps after 1 warm-up"),
+                oracle_explicit=dict(value=B * S / statistics.median(ts), cores=n_all,
+                                     sample="oracle/deepsdf_oracle.py train_step (hand-derived backward, the parity checker), "
+                                            "median of 3 full steps"))
+
+
+def pmc_children(result, bench_extra):
+    """rocprofv3 --pmc passes over this very command as child processes (tools/pmc.py); fills `result` in place."""
+    try:
+        from tools import pmc
+        args = pmc.CHILD_ARGS + bench_extra
+        result["mfma"] = pmc.mfma(args)
+        result["traffic"] = pmc.traffic(args)
+    except Exception as e:                                    # no rocprofv3, refused counters, ...: report, never fail the bench
+        result["error"] = f"{type(e).__name__}: {e}"
 
 
 def main():
@@ -84,17 +144,21 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--scenes-per-batch", type=int, default=64,
-                    help="NOT the headline config: scale the batch (x 256 samples) to see large-batch behaviour")
+                    help="NOT the headline config: scale the batch (x --samples) to see other batch shapes")
+    ap.add_argument("--samples", type=int, default=256, help="samples per scene (headline: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event instrumented pass")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (HBM traffic, MFMA counters)")
+    ap.add_argument("--no-extras", action="store_true", help="skip per-step percentiles and the one-scene extreme")
     args = ap.parse_args()
 
-    global SCENES_PER_BATCH
-    SCENES_PER_BATCH = args.scenes_per_batch
-    from deepsdf_amd import _lib, dist
+    from deepsdf_amd import _lib
     from deepsdf_amd.engine import Engine
     from deepsdf_amd.net import NetSpec
+    from deepsdf_amd.train import FusedTrainStep
 
+    B, S = args.scenes_per_batch, args.samples
+    headline = (B, S) == (64, 256)
     # rehearsal knobs (1-GPU box): DSDF_DIST_BACKEND=gloo + DSDF_SINGLE_DEVICE=1 run several ranks on ONE card to exercise
     # the multi-process logic; the driver's real multi-GPU runs use neither (backend nccl = RCCL, one rank per GPU)
     rank, local, world = dist.init(backend=os.environ.get("DSDF_DIST_BACKEND"))
@@ -105,30 +169,27 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
+    # the PMC child passes start NOW (rank 0, N = 1): they share the card with the first seconds of this process's own
+    # initialisation only through the driver's queue, and finish while the CPU baseline runs; they never overlap the timed region
+    pmc_res, pmc_thread = {}, None
+    want_pmc = rank == 0 and world == 1 and not args.no_pmc and "ROCPROFILER" not in " ".join(os.environ.keys()).upper()
+
     spec = NetSpec(L, **NET)
     eng = Engine(spec, dev)
     eng.init_like_reference(torch.Generator().manual_seed(0))      # identical on every rank (replicated decoder)
-    total_scenes = SCENES_PER_BATCH if world == 1 else max(512, SCENES_PER_BATCH * world)   # configs[1] / configs[2]
+    total_scenes = B if world == 1 else max(512, B * world)        # configs[1] / configs[2]
     lo, hi = dist.owned_scenes(total_scenes, rank, world)
     gen = torch.Generator().manual_seed(100 + rank)
     lat = (torch.randn(hi - lo, L, generator=gen) / math.sqrt(L)).to(dev)
-    dlat, lat_m, lat_v = torch.zeros_like(lat), torch.zeros_like(lat), torch.zeros_like(lat)
-    batches = synth_batches(8, lo, hi, dev, 1000 + rank)
-    n_local = SCENES_PER_BATCH * SAMPLES
+    fused = FusedTrainStep(eng, lat, clamp_dist=0.1, code_reg=True, code_reg_lambda=1e-4, code_bound=1.0, grad_clip=None, seed=rank)
+    batches = synth_batches(8, lo, hi, dev, 1000 + rank, B, S)
+    n_local = B * S
     n_global = n_local * world
 
-    def step(i):
-        b = batches[i % len(batches)]
-        if world == 1:     # the trainer's single-GPU path: one library call (FusedTrainStep in deepsdf_amd/train.py)
-            eng.train_step(lat, dlat, lat_m, lat_v, b["seg_scene"], b["seg_offset"], b["xyz"], b["gt"], n_norm=n_global,
-                           clamp_dist=0.1, reg_coef=1e-4 * min(1, 1 / 100), code_bound=1.0, lr_decoder=5e-4, lr_latent=1e-3,
-                           training=True, seed=rank, seg_len=SAMPLES)
-            return
-        eng.train_forward_backward(lat, dlat, b["seg_scene"], b["seg_offset"], b["xyz"], b["gt"], n_norm=n_global,
-                                   clamp_dist=0.1, reg_coef=1e-4 * min(1, 1 / 100), code_bound=1.0, training=True,
-                                   seed=rank, row_offset=0, seg_len=SAMPLES)
-        dist.allreduce_sum_(eng.grads)
-        eng.adam_step(lat, dlat, lat_m, lat_v, 5e-4, 1e-3)
+    def step(i, bs=batches, s=S, n_norm=n_global):
+        b = bs[i % len(bs)]
+        # epoch 1 of the reference's schedules: lr 5e-4 / 1e-3, regulariser ramp min(1, 1/100)  (examples/sofas/specs.json)
+        fused(b["scenes"], s, b["xyz"], b["gt"], 1, 5e-4, 1e-3, batch_split=1, n_norm=n_norm)
 
     # initialisation, not part of the contract's W warm-up steps: the first ~100 launches of a process load the code objects
     # and grow the runtime's kernarg / signal pools (one-off stalls of 80-90 ms were observed as late as the 4th step)
@@ -159,6 +220,20 @@ def main():
     flop_per_pt = 6 * spec.w_mac
     step_tflops = flop_per_pt * (value / world) / 1e12
 
+    # ---- single-step distribution: events on the compute stream around every step (separate pass: outside the timed region) ----
+    step_stats = None
+    if not args.no_extras:
+        k = min(args.steps, 200)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(k + 1)]
+        evs[0].record()
+        for i in range(k):
+            step(args.warmup + i)
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        ts = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(k))
+        step_stats = dict(median=ts[k // 2], p10=ts[k // 10], p90=ts[(9 * k) // 10], n=k,
+                          note="device time between per-step events on the compute stream; includes the event records")
+
     # ---- instrumented pass: HIP events around every launch of each kernel class, same steps, same stream ----
     roofline = None
     if not args.no_profile:
@@ -177,38 +252,79 @@ def main():
                                   ms_per_step=prof.ms[c] / args.steps,
                                   tflops=prof.flops[c] / (prof.ms[c] * 1e-3) / 1e12 if prof.ms[c] > 0 else None)
         dom = max(kern, key=lambda k: kern[k]["ms_per_step"])
-        # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process; the value is
-        # taken from the committed rocprofv3 --pmc summary (tools/pmc_traffic.sh -> profiles/) when present, else null
-        traffic, traffic_src = None, None
-        tfile = os.path.join(ROOT, "profiles", "r01_seg_pmc_traffic.json")
-        if os.path.exists(tfile):
-            tj = json.load(open(tfile))
-            if dom in tj:
-                traffic, traffic_src = tj[dom]["hbm_bytes_per_launch"], "profiles/r01_seg_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2)"
         roofline = dict(bound="mfma", kernel=dom, achieved=kern[dom]["tflops"], peak=PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=kern[dom]["tflops"] / PEAK_TFLOPS, traffic=traffic, traffic_source=traffic_src,
+                        frac=kern[dom]["tflops"] / PEAK_TFLOPS, traffic=None, executed_frac=None,
                         avg_launch_us=kern[dom]["avg_us"], launches_per_step=kern[dom]["launches_per_step"],
                         step_achieved=step_tflops, step_frac=step_tflops / PEAK_TFLOPS, kernels=kern,
                         note="achieved = ALGORITHMIC 2*pts*sum(in*out) of the hidden layers the kernel covers (the reference's "
                              "dense formulation, SURVEY 8d) / HIP-event time around its launches; segment mode executes fewer MFMA "
-                             "FLOPs than that (per-scene latent products are hoisted, DESIGN.md 4); "
+                             "FLOPs than that (per-scene latent products are hoisted, DESIGN.md 4): executed_frac = MFMA FLOPs "
+                             "issued (SQ_INSTS_VALU_MFMA_MOPS_F32 x 512) / the same HIP-event time / peak; "
                              "step_* = 6*W_mac*pts/s over the un-instrumented timed region")
 
+    # ---- the locality extreme of config 2: ONE scene x 16384 samples per step ----
+    one_scene = None
+    if rank == 0 and world == 1 and headline and not args.no_extras:
+        ob = synth_batches(2, 0, 1, dev, 77, 1, 16384)
+        olat = (torch.randn(1, L, generator=torch.Generator().manual_seed(5)) / math.sqrt(L)).to(dev)
+        ofused = FusedTrainStep(eng, olat, clamp_dist=0.1, code_reg=True, code_reg_lambda=1e-4, code_bound=1.0, grad_clip=None, seed=3)
+        ostep = lambda i: ofused(ob[i % 2]["scenes"], 16384, ob[i % 2]["xyz"], ob[i % 2]["gt"], 1, 5e-4, 1e-3, n_norm=16384)  # noqa: E731
+        for i in range(20):
+            ostep(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(100):
+            ostep(i)
+        torch.cuda.synchronize()
+        one_scene = 1e3 * (time.perf_counter() - t1) / 100
+
+    # ---- PMC child passes (GPU, child processes) run WHILE the CPU baseline runs (host cores); both after all GPU timing ----
+    if want_pmc:
+        extra = ["--scenes-per-batch", str(B), "--samples", str(S)]
+        pmc_thread = threading.Thread(target=pmc_children, args=(pmc_res, extra), daemon=True)
+        pmc_thread.start()
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
+    if pmc_thread is not None:
+        pmc_thread.join(timeout=600)
+    if roofline is not None:
+        dom = roofline["kernel"]
+        if "traffic" in pmc_res and dom in pmc_res["traffic"]:
+            roofline["traffic"] = pmc_res["traffic"][dom]["hbm_bytes_per_launch"]
+            roofline["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this command "
+                                          "(separate passes, FETCH_SIZE x2 on gfx950), per launch")
+            roofline["traffic_per_kernel_MB"] = {k: v["hbm_bytes_per_launch"] / 1e6 for k, v in pmc_res["traffic"].items()}
+        else:
+            tfile = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+            if os.path.exists(tfile) and dom in json.load(open(tfile)):
+                roofline["traffic"] = json.load(open(tfile))[dom]["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = "NOT measured in this run (" + pmc_res.get("error", "--no-pmc") + "): profiles/r02_pmc_traffic.json"
+        if "mfma" in pmc_res and dom in pmc_res["mfma"]:
+            m = pmc_res["mfma"][dom]
+            t = roofline["avg_launch_us"] * 1e-6
+            roofline["executed_frac"] = m["exec_mfma_flop"] / t / (PEAK_TFLOPS * 1e12)
+            roofline["executed"] = {k: dict(exec_mfma_gflop=v["exec_mfma_flop"] / 1e9, mfma_busy_frac=v.get("mfma_busy_frac"),
+                                            clock_ghz_profiled=v.get("clock_ghz"), profiled_us=v.get("duration_us"),
+                                            mops_per_mfma_inst=v.get("mops_per_mfma_inst"))
+                                    for k, v in pmc_res["mfma"].items() if v.get("exec_mfma_flop", 0) > 0}
+        if "error" in pmc_res:
+            roofline["pmc_error"] = pmc_res["error"]
 
     if rank == 0:
+        cfg = {"workload": (f"configs[1]: {B} synthetic sphere-SDF scenes, latent_dim=256, 8x512 decoder + layer-4 skip, "
+                            f"weight-norm, dropout 0.2, {n_local} pts/step ({B} scenes x {S} samples), fp32" if world == 1 else
+                            f"configs[2]: {total_scenes} scenes sharded over {world} ranks, {n_local} pts/step/rank, RCCL all-reduce of "
+                            "decoder grads (asynchronous, latent Adam under it)"),
+               "points_per_step_per_gpu": n_local, "headline_config": headline, "parallelism": f"dp{world}", "final_loss": loss}
+        if one_scene is not None:
+            cfg["one_scene_ms_per_step"] = one_scene
+            cfg["one_scene_value"] = 16384 / (one_scene * 1e-3)
         print(json.dumps({
             "metric": "SDF point-samples/sec per training step (8x512 decoder, 16384 pts)", "value": value,
             "unit": "point-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("configs[1]: 64 synthetic sphere-SDF scenes, latent_dim=256, 8x512 decoder + layer-4 skip, "
-                                    "weight-norm, dropout 0.2, 16384 pts/step, fp32" if world == 1 else
-                                    f"configs[2]: 512 scenes sharded over {world} ranks, 16384 pts/step/rank, RCCL all-reduce of "
-                                    "decoder grads"),
-                       "points_per_step_per_gpu": n_local, "headline_config": SCENES_PER_BATCH == 64, "parallelism": f"dp{world}", "final_loss": loss},
+            "dtype": "f32", "data": "synthetic", "config": cfg, "step_time_ms": step_stats,
             "roofline": roofline, "cpu_baseline": cpu}))
 
 

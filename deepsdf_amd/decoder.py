@@ -83,10 +83,14 @@ class _DecoderFn(torch.autograd.Function):
         y = eng.module_forward(x, training, seed=dec.dropout_seed, step=dec._fwd_calls)
         ctx.dec, ctx.n, ctx.training, ctx.token = dec, x.shape[0], training, dec._fwd_calls
         ctx.need_x = x.requires_grad
+        ctx.n_params = len(params)
+        ctx.set_materialize_grads(False)      # forward-mode: parameters without a tangent arrive as None, not as zeros
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            return (None,) * (2 + ctx.n_params)
         out = _DecoderBwdFn.apply(ctx.dec, dy, ctx.token, ctx.n, ctx.training, ctx.need_x)
         return (None, out[0] if ctx.need_x else None) + tuple(out[1:])
 

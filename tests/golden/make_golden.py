@@ -511,6 +511,7 @@ if __name__ == "__main__":
     if "--layout-only" in sys.argv:
         case_checkpoint_layout(ref_decoder_cls(), "g9_checkpoint_layout")
     elif "--reference-trainer-only" in sys.argv:      # the two cases that import the reference's train_deep_sdf.py
+        torch.set_num_threads(4)                      # as main(): the run is bit-reproducible for a fixed thread count
         case_lr("g5_lr_schedules")
         case_reference_run("g10_reference_run")
     else:

@@ -164,3 +164,29 @@ def test_dropout_hash_properties():
     other = orc.dropout_keep(orc.dropout_layer_key(1234, 6, 3), 4096, 512, 0.2)
     assert abs((keep == other).mean() - (0.8 * 0.8 + 0.2 * 0.2)) < 5e-3
     assert orc.dropout_threshold16(0.2) == 13107
+
+
+def test_torch_native_restatement_agrees_with_oracle_and_golden():
+    """oracle/torch_native.py (stock torch ops + autograd + torch.optim.Adam: the op sequence bench.py times as the CPU baseline)
+    reproduces the reference-generated golden g3a (dropout-injected training, 2 steps incl. renorm + dense Adam) and the
+    explicit-algebra oracle."""
+    from oracle.torch_native import NativeStep
+    g = Golden("g3a_dropout_tiny")
+    m = g.meta
+    net = orc.make_net(m["L"], **m["net_specs"])
+    params = g.group("params0")
+    st = orc.TrainState.create({k: v.clone() for k, v in params.items()}, g.get("lat0/w").clone())
+    nat = NativeStep(net, params, g.get("lat0/w"), code_bound=m["code_bound"], lr_decoder=m["lr"][0], lr_latent=m["lr"][1])
+    for si in range(m["n_steps"]):
+        i = g.group(f"step{si}/in")
+        loss = nat.step(i["idx"], i["xyz"], i["gt"], delta=m["delta"], code_reg=m["code_reg"], code_reg_lambda=m["lam"],
+                        epoch=m["epoch"], seed=m["drop_seed"])
+        ro = orc.train_step(net, st, i["idx"], i["xyz"], i["gt"], delta=m["delta"], code_bound=m["code_bound"],
+                            code_reg=m["code_reg"], code_reg_lambda=m["lam"], epoch=m["epoch"], lr_decoder=m["lr"][0],
+                            lr_latent=m["lr"][1], seed=m["drop_seed"])
+        assert abs(loss - float(g.group(f"step{si}/out")["loss"])) <= 1e-6 * abs(loss)
+        assert abs(loss - ro["loss"]) <= 1e-6 * abs(loss)
+        for k, ref in g.group(f"step{si}/params_after").items():
+            assert rel_err(nat.params[k].detach(), ref) <= 1e-6, (si, k)
+            assert rel_err(nat.params[k].detach(), st.params[k]) <= 1e-6, (si, k)
+        assert rel_err(nat.lat.weight.detach(), g.get(f"step{si}/lat_after/w")) <= 1e-6
