@@ -146,6 +146,9 @@ def main():
     ap.add_argument("--scenes-per-batch", type=int, default=64,
                     help="NOT the headline config: scale the batch (x --samples) to see other batch shapes")
     ap.add_argument("--samples", type=int, default=256, help="samples per scene (headline: 256)")
+    ap.add_argument("--config", choices=["fp32", "bf16"], default="fp32",
+                    help="fp32 = BASELINE configs[1] (the headline); bf16 = configs[4]: the same workload with the hidden-layer forward "
+                         "GEMMs on bf16 inputs / fp32 accumulate (v_mfma_f32_32x32x16_bf16), backward, dW and Adam in fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event instrumented pass")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (HBM traffic, MFMA counters)")
@@ -174,7 +177,8 @@ def main():
     pmc_res, pmc_thread = {}, None
     want_pmc = rank == 0 and world == 1 and not args.no_pmc and "ROCPROFILER" not in " ".join(os.environ.keys()).upper()
 
-    spec = NetSpec(L, **NET)
+    bf16 = args.config == "bf16"
+    spec = NetSpec(L, forward_bf16=bf16, **NET)
     eng = Engine(spec, dev)
     eng.init_like_reference(torch.Generator().manual_seed(0))      # identical on every rank (replicated decoder)
     total_scenes = B if world == 1 else max(512, B * world)        # configs[1] / configs[2]
@@ -280,11 +284,11 @@ def main():
 
     # ---- PMC child passes (GPU, child processes) run WHILE the CPU baseline runs (host cores); both after all GPU timing ----
     if want_pmc:
-        extra = ["--scenes-per-batch", str(B), "--samples", str(S)]
+        extra = ["--scenes-per-batch", str(B), "--samples", str(S), "--config", args.config]
         pmc_thread = threading.Thread(target=pmc_children, args=(pmc_res, extra), daemon=True)
         pmc_thread.start()
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not bf16:
         cpu = cpu_baseline()
     if pmc_thread is not None:
         pmc_thread.join(timeout=600)
@@ -312,8 +316,10 @@ def main():
             roofline["pmc_error"] = pmc_res["error"]
 
     if rank == 0:
-        cfg = {"workload": (f"configs[1]: {B} synthetic sphere-SDF scenes, latent_dim=256, 8x512 decoder + layer-4 skip, "
-                            f"weight-norm, dropout 0.2, {n_local} pts/step ({B} scenes x {S} samples), fp32" if world == 1 else
+        cfg = {"workload": ((f"configs[4]: configs[1] with the hidden-layer FORWARD GEMMs on bf16 inputs / fp32 accumulate; backward, dW, "
+                             f"Adam fp32; {n_local} pts/step ({B} scenes x {S} samples)" if bf16 else
+                             f"configs[1]: {B} synthetic sphere-SDF scenes, latent_dim=256, 8x512 decoder + layer-4 skip, "
+                             f"weight-norm, dropout 0.2, {n_local} pts/step ({B} scenes x {S} samples), fp32") if world == 1 else
                             f"configs[2]: {total_scenes} scenes sharded over {world} ranks, {n_local} pts/step/rank, RCCL all-reduce of "
                             "decoder grads (asynchronous, latent Adam under it)"),
                "points_per_step_per_gpu": n_local, "headline_config": headline, "parallelism": f"dp{world}", "final_loss": loss}
@@ -324,7 +330,7 @@ def main():
             "metric": "SDF point-samples/sec per training step (8x512 decoder, 16384 pts)", "value": value,
             "unit": "point-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic", "config": cfg, "step_time_ms": step_stats,
+            "dtype": "bf16-fwd/f32" if bf16 else "f32", "data": "synthetic", "config": cfg, "step_time_ms": step_stats,
             "roofline": roofline, "cpu_baseline": cpu}))
 
 

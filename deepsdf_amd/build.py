@@ -31,6 +31,7 @@ def build_library(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB, SRC]
+    cmd += os.environ.get("DSDF_HIPCC_FLAGS", "").split()      # lab builds only (-D switches of tools/lab_*.sh)
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)

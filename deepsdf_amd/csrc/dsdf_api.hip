@@ -475,6 +475,7 @@ int run_hoist(const DsdfNet* net, const Plan& P, void* ws, const float* packed, 
   }
   h.L = net->latent_size; h.seg_scene = b->seg_scene; h.table = table; h.R = (int)b->n_segments;
   h.U = at<float>(ws, P.hoistU_off); h.ldu = P.ldu;
+  h.bf16 = net->fwd_bf16 ? 1 : 0;
   const int rows = h.out[0] + (ks > 0 ? h.out[1] : 0);
   hipLaunchKernelGGL(seg_hoist_kernel, dim3((unsigned)((rows + 3) / 4), (unsigned)((h.R + HOIST_SC - 1) / HOIST_SC)), dim3(256), 0, st, h);
   LAUNCH_OK("seg_hoist_kernel");
@@ -718,7 +719,8 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     (void)wmac;
     if (fwd != nullptr) {
       ProfScope ps(DSDF_PROF_FUSED_FWD_BWD, 4.0 * (double)n * amac, st);   // forward + dX chain
-      hipLaunchKernelGGL(fused_fwd_bwd_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
+      if (net->fwd_bf16) hipLaunchKernelGGL(fused_fwd_bf16_bwd_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
+      else hipLaunchKernelGGL(fused_fwd_bwd_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
       LAUNCH_OK("fused_fwd_bwd_kernel");
     } else {
       ProfScope ps(DSDF_PROF_FUSED_BWD, 2.0 * (double)n * amac, st);
@@ -955,9 +957,9 @@ int dsdf_decode_latent(const DsdfNet* net, const float* packed, const float* par
   TRY(check_common(net, packed, params, ws));
   if (n == 0) return 0;
   if (!latent || !xyz || !sdf_out || n < 0) return fail(DSDF_E_INVALID, "bad latent/xyz/sdf_out");
-  if (!fused_enabled() || !fused_eligible(net) || net->fwd_bf16 || net->geom_dim > FGEO || net->latent_size > HOIST_MAXL ||
+  if (!fused_enabled() || !fused_eligible(net) || net->geom_dim > FGEO || net->latent_size > HOIST_MAXL ||
       net->latent_size < 1 || net->n_layers < 3)
-    return fail(DSDF_E_INVALID, "dsdf_decode_latent needs the fp32 fused forward (widths <= 512, geom_dim <= 4): use dsdf_decode");
+    return fail(DSDF_E_INVALID, "dsdf_decode_latent needs the fused forward (widths <= 512, geom_dim <= 4): use dsdf_decode");
   Plan P = make_plan(net, n, 0, true);
   const size_t need = P.total > 16384 ? P.total : 16384;
   if (ws_bytes < need) return fail(DSDF_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, need);
@@ -1122,8 +1124,8 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
   const int skip_l = skip_layer(net);
   const bool segsum = fusedb && b->seg_len > 0 && b->seg_len % FROWS == 0 && b->seg_len * R == n && net->n_layers > 2 &&
                       skip_l != net->n_layers - 2 &&   // the deepest hidden layer's dP column sums live in the head's partials
-                      net->geom_dim <= FGEO && net->latent_size <= HOIST_MAXL &&
-                      !net->fwd_bf16;   // the bf16 forward rounds every Linear input per point: no hoisting
+                      net->geom_dim <= FGEO && net->latent_size <= HOIST_MAXL;   // (config 5 too: bf16 rounding is element-wise
+                                                                                  // on the operands, so the latent products still hoist)
   const Plan P = make_plan(net, n, R, false, segsum);
   if (ws_bytes < P.total) return fail(DSDF_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, P.total);
   hipStream_t st = (hipStream_t)stream;
@@ -1141,7 +1143,7 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
   FusedSeg seg;
   memset(&seg, 0, sizeof(seg));
   FusedFwdArgs fwd_args;                                   // fp32 fused path: forward + backward go out as ONE launch below
-  bool merged = fusedb && !net->fwd_bf16;   // (the bf16 forward is its own kernel)
+  bool merged = fusedb;
 #ifdef DSDF_LAB
   if (getenv("DSDF_LAB_DBG")) merged = false;   // lab builds: per-layer stamps are dumped after a forward launch of its own
 #endif

@@ -31,6 +31,9 @@ namespace dsdf {
 constexpr int FROWS = 64;        // points per workgroup
 constexpr int FLD = 516;         // slab row stride in floats
 constexpr int FMAXW = 512;       // widest layer the fused kernels handle
+#ifndef BF_ABLATE
+#define BF_ABLATE 0      // lab (bf16 forward): 1 = no weight loads inside the k-loop, 2 = no MFMAs, 4 = no A reads inside the k-loop,
+#endif                   //                     8 = no global activation stores in the forward epilogue
 #ifndef FUSED_STORE_AUX
 #define FUSED_STORE_AUX 2          // cache policy of the activation / dP copies (lab: 2 = nt, 16 = sc1 write-through)
 #endif
@@ -127,6 +130,7 @@ __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[2][4], co
       L.out != nullptr ? (void*)(L.out + (size_t)row0 * L.ld_out) : (void*)S, 0,
       L.out != nullptr ? rows_here * L.ld_out * 4 : 0, 0x00020000);
   const int ldb = L.ld_out * 4;   // bytes per global row (wave-uniform)
+  const bool has_out = L.out != nullptr;
   uint32_t mq[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
@@ -168,8 +172,10 @@ __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[2][4], co
             sp[rc * FLD] = v0;
             sp[(rc + 1) * FLD] = v1;
           }
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rsrc, voff, rc * ldb, FUSED_STORE_AUX);
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rsrc, voff, (rc + 1) * ldb, FUSED_STORE_AUX);
+          if (!(BF_ABLATE & 8) && has_out) {   // (inference keeps no copies: 128 dropped stores per lane and layer still cost their issue)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rsrc, voff, rc * ldb, FUSED_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rsrc, voff, (rc + 1) * ldb, FUSED_STORE_AUX);
+          }
           mb[m] |= (v0 > 0.f ? 1u : 0u) << (2 * rp);
           mb[m] |= (v1 > 0.f ? 1u : 0u) << (2 * rp + 1);
         }
@@ -493,73 +499,229 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(const FusedFwdArg
 // by wn_tiles_kernel: fragment order, lane (r, h) holds k = 16u + 8h + j, j = 0..7, in ONE 16-byte load -- exactly the
 // instruction's operand layout); bias, ReLU, dropout, the stored activation copies (fp32, for the fp32 backward and dW
 // GEMMs), the 512->1 output layer and everything after it stay fp32.  Specification: oracle decoder_forward(bf16=True).
-// One k-unit of 16 is ONE MFMA per tile (32 cycles) instead of eight (512): this variant is bound by the weight stream
-// from L2, not by the matrix cores.  General mode only (x0 gathered by gather_concat_kernel).
+//
+// Bound: one k-unit of 16 is ONE MFMA per tile (32 cycles) instead of eight fp32 ones (512), so a wave's 8 tiles consume
+// 4 KiB of weights per 256 cycles: 64 points per CU need the layer's 0.5 MB from L2 in the 3.5 us its MFMAs take --
+// 143 GB/s per CU against the ~70 GB/s an XCD's L2 sustains for rows every workgroup shares (MI355X_MICROARCH.md, L2).
+// The k-loop is therefore L2-BANDWIDTH bound (~7 us per 512x512 layer), and what the kernel has to do is keep that stream
+// saturated: a ring of BF_RING k-units of weights per wave in registers (3 units = 12 KiB per wave in flight, 48 KiB per CU
+// ~ bandwidth x L2 latency), refilled one unit per step, and the NEXT layer's first units requested before the epilogue so
+// the stream does not stop while the VALU works.  (bf16 MFMAs do not block the VALU, unlike the fp32 ones -- tools/lab/
+// mfma_valu.hip -- so nothing here needs the fp32 kernel's scalar-address tricks.)
+// Segment mode works as in the fp32 kernel: rounding is element-wise on the operands, so W[:, lat] latent_s is still one
+// vector per scene (seg_hoist_kernel with bf16-rounded operands), and the xyz product is done on bf16-rounded values.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#ifndef BF_RING_UNITS
+#define BF_RING_UNITS 4
+#endif
+constexpr int BF_RING = BF_RING_UNITS;     // even
 
+__device__ __forceinline__ float bf16_round(float x) { return (float)(__bf16)x; }
+
+// rows of x0 (fp32, global) into bf16 slab columns [col0, col0 + W0) + zero pad up to a multiple of 16.  As in fused_load_x0
+// all loads of a pass are issued back-to-back BEFORE the first LDS write (a load-use loop pays the memory latency per trip:
+// 68 trips for a 259-wide x0 cost ~35 us per call).
 __device__ __forceinline__ void fused_load_x0_h(__bf16* S, const float* x0, int ldx0, int W0, int row0, int N, int col0) {
-  const int zc = (((col0 + W0) + 15) & ~15) - col0;      // columns written incl. the zero pad up to a multiple of 16
-  for (int i = threadIdx.x; i < FROWS * zc; i += 256) {
-    const int r = i / zc, c = i - r * zc;
-    float v = 0.f;
-    if (c < W0 && row0 + r < N) v = x0[(size_t)(row0 + r) * ldx0 + c];
-    S[r * FLDH + col0 + c] = (__bf16)v;
+  constexpr int XCH = 24;
+  const int zc = (((col0 + W0) + 15) & ~15) - col0;      // columns written incl. the zero pad
+  const int total = FROWS * zc;
+  for (int base = 0; base < total; base += 256 * XCH) {
+    float v[XCH];
+#pragma unroll
+    for (int k = 0; k < XCH; ++k) {
+      const int i = base + threadIdx.x + 256 * k;
+      v[k] = 0.f;
+      if (i < total) {
+        const int r = i / zc, c = i - r * zc;
+        if (c < W0 && row0 + r < N) v[k] = x0[(size_t)(row0 + r) * ldx0 + c];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < XCH; ++k) {
+      const int i = base + threadIdx.x + 256 * k;
+      if (i < total) {
+        const int r = i / zc, c = i - r * zc;
+        S[r * FLDH + col0 + c] = (__bf16)v[k];
+      }
+    }
   }
 }
 
-__global__ __launch_bounds__(256, 1) void fused_forward_bf16_kernel(const FusedFwdArgs p) {
-  __shared__ __attribute__((aligned(16))) float S[FROWS * FLD];   // bf16 view for the hidden layers, fp32 for the output layer
+// ONE k-unit of the next layer's weights travels across the epilogue (16 VGPRs); the ring itself lives only inside the
+// k-loop: a ring kept alive across the epilogue made the compiler spill ~600 scratch accesses per layer into it
+// (1.2 GB of scratch traffic per forward: ring 4 ran 30 % SLOWER than ring 2 until the ring became loop-local).
+struct Bf16Pre { bf16x8 b[4]; };
+
+// Every workgroup walks the k-units of a layer in its OWN rotated order (unit (u + rot) mod nu): 32 CUs of an XCD that all
+// stream the same weights in the same order at the same pace keep hitting ONE L2 channel at a time.  A rotation of the
+// contraction order only permutes the fp32 summation; it is a fixed function of the workgroup index, so results stay
+// run-to-run bit-identical.
+#ifndef BF_ROTATE
+#define BF_ROTATE 1
+#endif
+__device__ __forceinline__ int bf16_rot(int nu) {
+#if BF_ROTATE
+  return nu > 0 ? (int)(((blockIdx.x >> 3) * (unsigned)nu) >> 5) % nu : 0;   // blocks b, b+8, ... share an XCD (common.hpp)
+#else
+  return 0;
+#endif
+}
+__device__ __forceinline__ int bf16_unit(int u, int rot, int nu) { const int v = u + rot; return v >= nu ? v - nu : v; }
+
+// weights of k-unit u for this wave's NACT n-tiles
+template <int NACT>
+__device__ __forceinline__ void bf16_load_unit(bf16x8 (&dst)[4], const __bf16* wfb, int U, int w, int lane, int u) {
+#pragma unroll
+  for (int ni = 0; ni < NACT; ++ni)
+    dst[ni] = *reinterpret_cast<const bf16x8*>(wfb + ((size_t)(w + 4 * ni) * U + u) * 512 + lane * 8);
+}
+// the FIRST k-unit (of this workgroup's order) of a layer, requested before the previous layer's epilogue
+__device__ __forceinline__ void bf16_prefetch(Bf16Pre& P, const __bf16* wfb, int U, int w, int lane, int nact, int nu) {
+  if (nu <= 0) return;
+  const int u = bf16_unit(0, bf16_rot(nu), nu);
+  switch (nact) {
+    case 4: bf16_load_unit<4>(P.b, wfb, U, w, lane, u); break;
+    case 3: bf16_load_unit<3>(P.b, wfb, U, w, lane, u); break;
+    case 2: bf16_load_unit<2>(P.b, wfb, U, w, lane, u); break;
+    case 1: bf16_load_unit<1>(P.b, wfb, U, w, lane, u); break;
+    default: break;
+  }
+}
+
+// acc[m][ni] += S[64 rows][16 nu] * Wfb; P holds the first unit (bf16_prefetch)
+template <int NACT>
+__device__ __forceinline__ void bf16_kloop(f32x16 (&acc)[2][4], const __bf16* ap, const __bf16* wfb, int U, int w, int lane,
+                                           int nu, const Bf16Pre& P) {
+  bf16x8 ring[BF_RING][4];
+  bf16x8 a0[2], a1[2];
+  const int rot = bf16_rot(nu), ulast = nu - 1;
+  auto readA = [&](bf16x8 (&a)[2], int q) {          // q = position in this workgroup's unit order
+    if ((BF_ABLATE & 4) && q > 0) return;
+    const int u = bf16_unit(q, rot, nu);
+    a[0] = *reinterpret_cast<const bf16x8*>(ap + 16 * u);
+    a[1] = *reinterpret_cast<const bf16x8*>(ap + 32 * FLDH + 16 * u);
+  };
+  auto loadB = [&](bf16x8 (&dst)[4], int q) {
+    if (!(BF_ABLATE & 1)) bf16_load_unit<NACT>(dst, wfb, U, w, lane, bf16_unit(q, rot, nu));
+  };
+  auto mma = [&](const bf16x8 (&a)[2], const bf16x8 (&b)[4]) {
+    if (BF_ABLATE & 2) return;
+#pragma unroll
+    for (int ni = 0; ni < NACT; ++ni) {
+      acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[ni], acc[0][ni], 0, 0, 0);
+      acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[ni], acc[1][ni], 0, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int ni = 0; ni < NACT; ++ni) ring[0][ni] = P.b[ni];
+#pragma unroll
+  for (int q = 1; q < BF_RING - 1; ++q) loadB(ring[q], min(q, ulast));   // unconditional (clamped): every slot is defined here
+  readA(a0, 0);
+  int s = 0;
+  for (; s + BF_RING <= nu; s += BF_RING) {   // static ring slots; one unit refilled per step, BF_RING - 1 steps ahead
+#pragma unroll
+    for (int q = 0; q < BF_RING; q += 2) {
+      loadB(ring[(q + BF_RING - 1) % BF_RING], min(s + q + BF_RING - 1, ulast));
+      readA(a1, min(s + q + 1, ulast));
+      mma(a0, ring[q]);
+      loadB(ring[q % BF_RING], min(s + q + BF_RING, ulast));
+      readA(a0, min(s + q + 2, ulast));
+      mma(a1, ring[q + 1]);
+    }
+  }
+  // tail: the remaining (< BF_RING) units sit in ring slots 0 .. rem-1; a0 holds the rows of position s
+#pragma unroll
+  for (int q = 0; q < BF_RING - 1; ++q) {
+    if (s + q < nu) {
+      if (q & 1) { readA(a0, min(s + q + 1, ulast)); mma(a1, ring[q]); }
+      else { readA(a1, min(s + q + 1, ulast)); mma(a0, ring[q]); }
+    }
+  }
+}
+
+__device__ __forceinline__ void bf16_kloop_dispatch(f32x16 (&acc)[2][4], const __bf16* ap, const __bf16* wfb, int U, int w,
+                                                    int lane, int nu, int nact, const Bf16Pre& P) {
+  switch (nact) {
+    case 4: bf16_kloop<4>(acc, ap, wfb, U, w, lane, nu, P); break;
+    case 3: bf16_kloop<3>(acc, ap, wfb, U, w, lane, nu, P); break;
+    case 2: bf16_kloop<2>(acc, ap, wfb, U, w, lane, nu, P); break;
+    case 1: bf16_kloop<1>(acc, ap, wfb, U, w, lane, nu, P); break;
+    default: break;
+  }
+}
+
+// S: the slab (bf16 view for the hidden layers; the LAST hidden activation is written as fp32, row stride FLD, for the fp32
+// output layer / backward head).  Segment mode: xs / hu / hwx as in fused_forward_body, all values rounded to bf16.
+__device__ __forceinline__ void fused_forward_bf16_body(const FusedFwdArgs& p, float* S, float4* xs, float (*hu)[FMAXW],
+                                                        float4 (*hwx)[FMAXW]) {
   __bf16* SH = reinterpret_cast<__bf16*>(S);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int row0 = blockIdx.x * FROWS;
-  fused_load_x0_h(SH, p.x0, p.ldx0, p.W0, row0, p.N, 0);
+  const bool segm = p.seg.wg_per_seg > 0;
+  Bf16Pre R;
+  const int lfirst = (segm && p.n_hidden > 1) ? 1 : 0;
+  bf16_prefetch(R, reinterpret_cast<const __bf16*>(p.ly[lfirst].wf), p.ly[lfirst].U, w, lane,
+                fused_nact(p.ly[lfirst].out_dim, w), (p.ly[lfirst].in + 15) >> 4);
+  if (segm) {
+    if (tid < FROWS) {
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + tid < p.N) {
+        const float* q = p.seg.xyz + (size_t)(row0 + tid) * p.seg.G;
+        x.x = bf16_round(q[0]);
+        if (p.seg.G > 1) x.y = bf16_round(q[1]);
+        if (p.seg.G > 2) x.z = bf16_round(q[2]);
+        if (p.seg.G > 3) x.w = bf16_round(q[3]);
+      }
+      xs[tid] = x;
+    }
+    const int sidx = blockIdx.x / p.seg.wg_per_seg;
+#pragma unroll
+    for (int t = 0; t < FHOIST; ++t) {
+      const FusedHoist& H = p.seg.h[t];
+      if (H.layer < 0) continue;
+      const int od = p.ly[H.layer].out_dim;
+      for (int c = tid; c < od; c += 256) {
+        hu[t][c] = p.seg.U[((size_t)sidx * FHOIST + t) * p.seg.ldu + c];
+        const float* q = H.wx + (size_t)c * H.ldw;
+        float4 x = make_float4(bf16_round(q[0]), 0.f, 0.f, 0.f);
+        if (p.seg.G > 1) x.y = bf16_round(q[1]);
+        if (p.seg.G > 2) x.z = bf16_round(q[2]);
+        if (p.seg.G > 3) x.w = bf16_round(q[3]);
+        hwx[t][c] = x;
+      }
+    }
+  } else {
+    fused_load_x0_h(SH, p.x0, p.ldx0, p.W0, row0, p.N, 0);
+  }
   __syncthreads();
   for (int l = 0; l < p.n_hidden; ++l) {
     const FusedLayer& L = p.ly[l];
     const int nu = (L.in + 15) >> 4, nact = fused_nact(L.out_dim, w);
-    const __bf16* wfb = reinterpret_cast<const __bf16*>(L.wf);
     f32x16 acc[2][4];
+    int hidx = -1;
+    if (segm) hidx = l == p.seg.h[0].layer ? 0 : (l == p.seg.h[1].layer ? 1 : -1);
+    if (hidx >= 0) {
+      fused_hoist_init(acc, hu[hidx], hwx[hidx], xs, L.out_dim, w, fr, fh);
+    } else {
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
+        for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][ni][r] = 0.f;
+          for (int r = 0; r < 16; ++r) acc[m][ni][r] = 0.f;
+    }
     float biasv[4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int col = 32 * (w + 4 * ni) + fr;
       biasv[ni] = col < L.out_dim ? L.bias[col] : 0.f;
     }
-    const __bf16* ap = SH + fr * FLDH + 8 * fh;
-    auto loadB = [&](bf16x8 (&b)[4], int u) {
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-        if (ni < nact) b[ni] = *reinterpret_cast<const bf16x8*>(wfb + ((size_t)(w + 4 * ni) * L.U + u) * 512 + lane * 8);
-    };
-    bf16x8 b0[4], b1[4];
-    if (nu > 0) loadB(b0, 0);
-    for (int u = 0; u < nu; u += 2) {        // two k-units per trip: the next unit's weights are in flight under the MFMAs
-      if (u + 1 < nu) loadB(b1, u + 1);
-      {
-        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ap + 16 * u), a1 = *reinterpret_cast<const bf16x8*>(ap + 32 * FLDH + 16 * u);
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          if (ni < nact) {
-            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0[ni], acc[0][ni], 0, 0, 0);
-            acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0[ni], acc[1][ni], 0, 0, 0);
-          }
-      }
-      if (u + 2 < nu) loadB(b0, u + 2);
-      if (u + 1 < nu) {
-        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ap + 16 * (u + 1)), a1 = *reinterpret_cast<const bf16x8*>(ap + 32 * FLDH + 16 * (u + 1));
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          if (ni < nact) {
-            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1[ni], acc[0][ni], 0, 0, 0);
-            acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1[ni], acc[1][ni], 0, 0, 0);
-          }
+    if (nu > 0) {
+      bf16_kloop_dispatch(acc, SH + fr * FLDH + 8 * fh, reinterpret_cast<const __bf16*>(L.wf), L.U, w, lane, nu, nact, R);
+      if (l + 1 < p.n_hidden) {   // the next layer's first units travel while this layer's epilogue runs
+        const FusedLayer& Ln = p.ly[l + 1];
+        bf16_prefetch(R, reinterpret_cast<const __bf16*>(Ln.wf), Ln.U, w, lane, fused_nact(Ln.out_dim, w), (Ln.in + 15) >> 4);
       }
     }
     __syncthreads();   // every wave has finished reading the slab: it may be overwritten in place
@@ -568,7 +730,7 @@ __global__ __launch_bounds__(256, 1) void fused_forward_bf16_kernel(const FusedF
     {
       const bool drop = L.drop_thr != 0u;
       const bool even = ((p.row_offset + (uint32_t)row0) & 1u) == 0u;
-      if (last_hidden) {   // the output layer reads fp32: its input goes to the slab as fp32
+      if (last_hidden) {   // the output layer / the backward head read fp32: its input goes to the slab as fp32
         if (!drop) fused_fwd_epilogue<false, true, false>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
         else if (even) fused_fwd_epilogue<true, true, false>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
         else fused_fwd_epilogue<true, false, false>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
@@ -584,7 +746,7 @@ __global__ __launch_bounds__(256, 1) void fused_forward_bf16_kernel(const FusedF
     }
     __syncthreads();
   }
-  if (p.y_out == nullptr && p.u_out == nullptr) return;   // training: the backward kernel's head recomputes it (fp32 copy)
+  if (p.y_out == nullptr && p.u_out == nullptr) return;   // training: the backward head recomputes the output layer from the slab
   float4 qv[2];
 #pragma unroll
   for (int cc = 0; cc < 2; ++cc) {
@@ -610,6 +772,14 @@ __global__ __launch_bounds__(256, 1) void fused_forward_bf16_kernel(const FusedF
       if (p.u_out) p.u_out[row0 + row] = u;
     }
   }
+}
+
+__global__ __launch_bounds__(256, 1) void fused_forward_bf16_kernel(const FusedFwdArgs p) {
+  __shared__ __attribute__((aligned(16))) float S[FROWS * FLD];   // bf16 view for the hidden layers, fp32 for the output layer
+  __shared__ float4 xs[FROWS];
+  __shared__ float hu[FHOIST][FMAXW];
+  __shared__ float4 hwx[FHOIST][FMAXW];
+  fused_forward_bf16_body(p, S, xs, hu, hwx);
 }
 
 // ===================================================================================================================
@@ -870,6 +1040,21 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_bwd_kernel(const FusedFwdArg
   float (*hsc)[2] = reinterpret_cast<float (*)[2]>(scratch + 4 * 2 * FMAXW / 4);
   fused_forward_body(f, S, xs, hu, hwx, 150 * 1024);
   __syncthreads();
+  fused_backward_body(b, S, xs, hred, hsc, true);
+}
+
+// Config 5 training step: bf16 forward and fp32 backward of the same 64 points in one launch (same LDS plan as above).
+__global__ __launch_bounds__(256, 1) void fused_fwd_bf16_bwd_kernel(const FusedFwdArgs f, const FusedBwdArgs b) {
+  __shared__ __attribute__((aligned(16))) float S[FROWS * FLD];
+  __shared__ float4 xs[FROWS];
+  __shared__ float4 scratch[FHOIST * FMAXW + FHOIST * FMAXW / 4];
+  float (*hu)[FMAXW] = reinterpret_cast<float (*)[FMAXW]>(scratch);
+  float4 (*hwx)[FMAXW] = reinterpret_cast<float4 (*)[FMAXW]>(scratch + FHOIST * FMAXW / 4);
+  float (*hred)[2 * FMAXW] = reinterpret_cast<float (*)[2 * FMAXW]>(scratch);
+  float (*hsc)[2] = reinterpret_cast<float (*)[2]>(scratch + 4 * 2 * FMAXW / 4);
+  fused_forward_bf16_body(f, S, xs, hu, hwx);
+  __syncthreads();
+  // (the backward body refills xs with the UNROUNDED xyz: the fp32 backward / dW use the fp32 layer inputs)
   fused_backward_body(b, S, xs, hred, hsc, true);
 }
 

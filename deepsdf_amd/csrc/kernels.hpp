@@ -82,6 +82,7 @@ struct HoistArgs {
   const float* W[2]; int ldw[2]; int c0[2]; int out[2];
   int L; const int64_t* seg_scene; const float* table; int R;
   float* U; int ldu;                       // [R][2][ldu]
+  int bf16;                                // config 5: both operands rounded to bf16 (RNE), fp32 accumulation
 };
 __global__ __launch_bounds__(256) void seg_hoist_kernel(const HoistArgs p) {   // grid (rows / 4, ceil(R / HOIST_SC))
   const int lane = threadIdx.x & 63;
@@ -98,10 +99,15 @@ __global__ __launch_bounds__(256) void seg_hoist_kernel(const HoistArgs p) {   /
 #pragma unroll
   for (int q = 0; q < HOIST_SC; ++q) a[q] = 0.f;
   for (int c = lane; c < p.L; c += 64) {
-    const float wv = wrow[c];
+    float wv = wrow[c];
     float v[HOIST_SC];
 #pragma unroll
     for (int q = 0; q < HOIST_SC; ++q) v[q] = rows[q][c];
+    if (p.bf16) {
+      wv = (float)(__bf16)wv;
+#pragma unroll
+      for (int q = 0; q < HOIST_SC; ++q) v[q] = (float)(__bf16)v[q];
+    }
 #pragma unroll
     for (int q = 0; q < HOIST_SC; ++q) a[q] = fmaf(wv, v[q], a[q]);
   }

@@ -99,3 +99,40 @@ def test_argument_errors_are_reported_before_any_launch(lib):
     assert lib.dsdf_packed_floats(C.byref(wide), C.byref(n)) == -1 and b"fwd_bf16" in lib.dsdf_last_error()
     net = NetSpec(8, [64, 64], 3).c_struct()
     assert lib.dsdf_decode_latent(C.byref(net), None, None, None, None, 10, None, None, 0, None) == -1
+
+
+def test_warm_own_code_bound_is_inside_the_text_section(tmp_path):
+    """common.hpp warm_own_code reads the kernel's own instructions as data, clamped to the address of
+    dsdf_text_end_marker.  Pinned here on the gfx950 code object inside libdsdf_hip.so: the marker lies INSIDE .text (no read
+    can leave the section) and BEHIND every kernel that warms itself (so each of them has room to cover its own code)."""
+    import re
+    import shutil
+    import subprocess
+    from deepsdf_amd.build import LIB
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = {t: os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")}
+    if not all(os.path.exists(p) for p in tools.values()) or not os.path.exists(LIB):
+        pytest.skip("ROCm LLVM tools or the built library are not available")
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "co.elf")
+    subprocess.run([tools["llvm-objcopy"], "-O", "binary", "--only-section=.hip_fatbin", LIB, fat], check=True)
+    subprocess.run([tools["clang-offload-bundler"], "--unbundle", "--type=o", f"--input={fat}",
+                    "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+    sec = subprocess.run([tools["llvm-readelf"], "-SW", co], capture_output=True, text=True, check=True).stdout
+    m = re.search(r"\.text\s+PROGBITS\s+([0-9a-f]+)\s+[0-9a-f]+\s+([0-9a-f]+)", sec)
+    text_lo, text_hi = int(m.group(1), 16), int(m.group(1), 16) + int(m.group(2), 16)
+    syms = subprocess.run([tools["llvm-readelf"], "-sW", co], capture_output=True, text=True, check=True).stdout
+    funcs = {}
+    for line in syms.splitlines():
+        f = line.split()
+        if len(f) >= 8 and f[3] == "FUNC":
+            funcs[f[7]] = (int(f[1], 16), int(f[2]))
+    marker = [v for k, v in funcs.items() if "dsdf_text_end_marker" in k]
+    assert len(marker) == 1
+    mk = marker[0][0]
+    assert text_lo <= mk < text_hi
+    warmers = [k for k in funcs if re.search(r"fused_(forward|backward|fwd_bwd)_kernel", k) and "bf16" not in k]
+    assert len(warmers) == 3
+    for k in warmers:
+        addr, size = funcs[k]
+        assert addr + size <= mk, (k, hex(addr + size), hex(mk))
+    shutil.rmtree(str(tmp_path), ignore_errors=True)
