@@ -188,19 +188,41 @@ __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[2][4], co
     *reinterpret_cast<uint4*>(L.maskbits + ((size_t)blockIdx.x * 256 + threadIdx.x) * 4) = make_uint4(mq[0], mq[1], mq[2], mq[3]);
 }
 
+// Optional (lab: -DFUSED_ROTATE=1): every workgroup walks the k-units of a layer in its own rotated order, so that the CUs
+// of an XCD do not all stream the same weight lines at the same moment (one L2 channel at a time).
+#ifndef FUSED_ROTATE
+#define FUSED_ROTATE 0
+#endif
+__device__ __forceinline__ int fused_rot(int nu) {
+#if FUSED_ROTATE
+  return nu > 0 ? __builtin_amdgcn_readfirstlane((int)(((blockIdx.x >> 3) * (unsigned)nu) >> 5) % nu) : 0;
+#else
+  return 0;
+#endif
+}
+__device__ __forceinline__ int fused_unit(int u, int rot, int nu) {
+#if FUSED_ROTATE
+  const int v = u + rot; return v >= nu ? v - nu : v;
+#else
+  return u;
+#endif
+}
+
 // The shared k-loop: acc[m][ni] += S[64 rows][K] * Bf[n-tiles of this wave][K]; NACT = existing n-tiles of this wave.
 struct FusedBSets { float4 b0[4][2], b1[4][2]; };   // weights of k-units 0 and 1 of the NEXT layer, requested before the epilogue
 
 __device__ __forceinline__ void fused_prefetch_b(FusedBSets& B, const float* wf, int U, int w, int lane, int nact, int nu) {
+  const int rot = fused_rot(nu);
+  const int u0 = fused_unit(0, rot, nu), u1 = fused_unit(nu > 1 ? 1 : 0, rot, nu);
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
     if (ni < nact) {
       const float* q = wf + (size_t)(w + 4 * ni) * U * 512 + lane * 4;
-      B.b0[ni][0] = *reinterpret_cast<const float4*>(q);
-      B.b0[ni][1] = *reinterpret_cast<const float4*>(q + 256);
+      B.b0[ni][0] = *reinterpret_cast<const float4*>(q + 512 * u0);
+      B.b0[ni][1] = *reinterpret_cast<const float4*>(q + 512 * u0 + 256);
       if (nu > 1) {
-        B.b1[ni][0] = *reinterpret_cast<const float4*>(q + 512);
-        B.b1[ni][1] = *reinterpret_cast<const float4*>(q + 768);
+        B.b1[ni][0] = *reinterpret_cast<const float4*>(q + 512 * u1);
+        B.b1[ni][1] = *reinterpret_cast<const float4*>(q + 512 * u1 + 256);
       }
     }
   }
@@ -238,14 +260,17 @@ __device__ __forceinline__ void fused_kloop(f32x16 (&acc)[2][4], const float* ap
     b1[ni][0] = PB.b1[ni][0]; b1[ni][1] = PB.b1[ni][1];
   }
   float4 a0[4], a1[4], a2[4];   // [m-tile + 2 * half]: 4 consecutive k of rows fr and 32 + fr
-  auto loadB = [&](float4 (&b)[NACT][2], int u) {
+  const int rot = fused_rot(nu);
+  auto loadB = [&](float4 (&b)[NACT][2], int q) {
+    const int u = fused_unit(q, rot, nu);
 #pragma unroll
     for (int ni = 0; ni < NACT; ++ni) {
       b[ni][0] = fused_bload(bv, ni, u, 0);
       b[ni][1] = fused_bload(bv, ni, u, 1);
     }
   };
-  auto readA = [&](float4 (&a)[4], int u) {
+  auto readA = [&](float4 (&a)[4], int q) {
+    const int u = fused_unit(q, rot, nu);
     a[0] = *reinterpret_cast<const float4*>(ap + 16 * u);
     a[1] = *reinterpret_cast<const float4*>(ap + 32 * FLD + 16 * u);
     a[2] = *reinterpret_cast<const float4*>(ap + 16 * u + 4);

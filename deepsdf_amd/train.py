@@ -267,7 +267,8 @@ class FusedTrainStep:
                                   torch.chunk(sdf_gt, batch_split)):
                 sc, so = make_segments(ic)
                 chunks.append((sc, so, xc.contiguous(), gc.contiguous()))
-        if batch_split == 1 and self.grad_clip is None and not dist.is_multi():
+        force_dp = os.environ.get("DSDF_FORCE_DP_PATH") == "1"     # measurement knob: the world > 1 call sequence on one process
+        if batch_split == 1 and self.grad_clip is None and not dist.is_multi() and not force_dp:
             # single-GPU fast path: one library call, decoder Adam folded into the finalize pass
             sc, so, xc, gc = chunks[0]
             self.eng.train_step(self.lat, self.dlat, self.lat_m, self.lat_v, sc, so, xc, gc, n_norm=n_norm,
@@ -288,14 +289,16 @@ class FusedTrainStep:
         # update of this rank's latent rows (their gradient is complete and private to the owner rank) and `under_allreduce`
         # (the trainer passes the NEXT batch's sampling kernel).  The decoder's Adam + weight re-materialisation wait for it.
         work = dist.allreduce_sum_async(self.eng.grads)
-        if work is not None:
+        split_adam = work is not None or (force_dp and self.grad_clip is None)
+        if split_adam:
             self.eng.adam_latents(self.lat, self.dlat, self.lat_m, self.lat_v, lr_latent)
             if under_allreduce is not None:
                 under_allreduce()
-            work.wait()                       # nccl: the compute stream waits for RCCL's stream (no host block)
+            if work is not None:
+                work.wait()                   # nccl: the compute stream waits for RCCL's stream (no host block)
         if self.grad_clip is not None:
             self.eng.grad_norm(self.grad_clip)
-        if work is not None:
+        if split_adam:
             self.eng.adam_step(None, None, None, None, lr_decoder, lr_latent, clip=self.grad_clip is not None)
         else:
             self.eng.adam_step(self.lat, self.dlat, self.lat_m, self.lat_v, lr_decoder, lr_latent, clip=self.grad_clip is not None)

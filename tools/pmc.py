@@ -22,8 +22,8 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PEAK_F32 = 157.3e12
-MFMA_COUNTERS = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_MFMA", "SQ_WAVE_CYCLES",
-                 "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]
+MFMA_COUNTERS = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_VALU_MFMA_MOPS_BF16",
+                 "SQ_INSTS_MFMA", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]
 
 
 def short(name):
@@ -96,10 +96,12 @@ def mfma(bench_args, timeout=240):
     for k, e in res.items():
         v = e["counters"]
         mops, busy, cu = v.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0), v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), v.get("SQ_BUSY_CU_CYCLES", 0.0)
+        mops_bf = v.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0)
         if v.get("SQ_INSTS_MFMA", 0.0) > 0:
-            e["mops_per_mfma_inst"] = mops / v["SQ_INSTS_MFMA"]
+            e["mops_per_mfma_inst"] = (mops + mops_bf) / v["SQ_INSTS_MFMA"]
             e["mfma_busy_cycles_per_inst"] = busy / v["SQ_INSTS_MFMA"]
         e["exec_mfma_flop"] = mops * 512.0
+        e["exec_mfma_flop_bf16"] = mops_bf * 512.0     # (one v_mfma_f32_32x32x16_bf16 = 32768 FLOP = 64 MOPS)
         if cu > 0:
             e["mfma_busy_frac"] = busy / (4.0 * cu)
         t = e.get("duration_us", 0.0) * 1e-6
