@@ -97,6 +97,16 @@ def test_decode_latent_single_code(name):
     with torch.no_grad():
         ys = decode_sdf(dec, z.cuda()[None, :], xyz.cuda())
     assert ys.shape == (xyz.shape[0], 1) and rel_err(ys.cpu().reshape(-1), yo) <= FWD_TOL
+    # config 5: the same entry point with the bf16 forward (hoisted products on bf16-rounded operands) against the oracle's
+    # bf16 emulation, and against the materialised-input bf16 path
+    netb = orc.make_net(L, forward_bf16=True, **g.meta["net_specs"])
+    engb = Engine(spec_from_meta(dict(L=L, net_specs=dict(g.meta["net_specs"], forward_bf16=True))))
+    engb.load_params(params)
+    x = torch.cat([z.expand(xyz.shape[0], -1), xyz], 1)
+    yob = orc.decoder_forward(netb, params, x, training=False)[0].reshape(-1)
+    ylb = engb.decode_latent(z.cuda(), xyz.cuda()).cpu().reshape(-1)
+    ydb = engb.decode(x.cuda()).cpu().reshape(-1)
+    assert rel_err(ylb, yob) <= 1e-4 and rel_err(ydb, yob) <= 1e-4 and rel_err(ylb, yo) >= 1e-5      # bf16 really is in the loop
 
 
 def test_real_weights_known_answer():
