@@ -122,7 +122,7 @@ constexpr int FLDH = 520;        // slab row stride in bf16 elements (bf16 forwa
 
 // HS: the slab holds bf16 (row stride FLDH) instead of fp32 (row stride FLD); the global activation copy stays fp32.
 template <bool DROP, bool EVEN, bool HS = false>
-__device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[2][4], const float (&biasv)[4], float* S,
+__device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[2][4], float* S,
                                                    const FusedLayer& L, int w, int fr, int fh, int row0, int N,
                                                    uint32_t row_offset) {
   const int rows_here = min(FROWS, N - row0);
@@ -138,7 +138,6 @@ __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[2][4], co
     const bool cok = col < L.out_dim;
     const uint32_t voff = cok ? (uint32_t)((4 * fh) * ldb + col * 4) : 0x7FFFFFFFu;
     float* sp = S + (4 * fh) * FLD + col;
-    const float bv = biasv[ni];
     uint32_t mb[2] = {0u, 0u};   // this n-tile's keep bits for m = 0, 1
     uint32_t ck = 0, pm = 0;
     if constexpr (DROP) {
@@ -151,7 +150,7 @@ __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[2][4], co
 #pragma unroll
         for (int rp = 0; rp < 8; ++rp) {
           const int rc = 32 * m + crow(2 * rp);    // compile-time local row (without the 4*fh lane term); even
-          float v0 = fmaxf(acc[m][ni][2 * rp] + bv, 0.f), v1 = fmaxf(acc[m][ni][2 * rp + 1] + bv, 0.f);
+          float v0 = fmaxf(acc[m][ni][2 * rp], 0.f), v1 = fmaxf(acc[m][ni][2 * rp + 1], 0.f);   // (the bias is the accumulators' initial value)
           if constexpr (DROP) {
             if constexpr (EVEN) {   // rows rc, rc+1 share one pair hash
               const uint32_t h = lowbias32(ck ^ (pm + (uint32_t)(rc >> 1) * 0x9E3779B1u));
@@ -358,12 +357,12 @@ __device__ __forceinline__ void fused_zero_pad(float* S, int nin) {   // columns
 
 // accumulators of a hoisted layer start at  U_s[col] + <xyz[row], W[col, xyz]>  (all operands staged in LDS)
 __device__ __forceinline__ void fused_hoist_init(f32x16 (&acc)[2][4], const float* hu, const float4* hwx, const float4* xs,
-                                                 int out_dim, int w, int fr, int fh) {
+                                                 const float (&biasv)[4], int out_dim, int w, int fr, int fh) {
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {   // one n-tile at a time (few live registers); the xyz rows are re-read from LDS (broadcast)
     const int col = 32 * (w + 4 * ni) + fr;
     const bool ok = col < out_dim;
-    const float ub = ok ? hu[col] : 0.f;
+    const float ub = ok ? hu[col] + biasv[ni] : 0.f;
     const float4 wq = ok ? hwx[col] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -430,28 +429,28 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
     const FusedLayer& L = p.ly[l];
     const int nu = (L.in + 15) >> 4;   // segment mode: 0 for layer 0, only the previous layer's columns for the skip layer
     f32x16 acc[2][4];
-    int hidx = -1;
-    if (segm) hidx = l == p.seg.h[0].layer ? 0 : (l == p.seg.h[1].layer ? 1 : -1);
-    if (hidx >= 0) {
-      fused_hoist_init(acc, hu[hidx], hwx[hidx], xs, L.out_dim, w, fr, fh);
-    } else {
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[m][ni][r] = 0.f;
-    }
-    const FusedBView bv = fused_bview(L.wf, L.U, w, lane);
-    const float* ap = S + fr * FLD + 8 * fh;
-    // epilogue operands are fetched BEFORE the k-loop: a load issued after the epilogue's global stores would have
-    // to wait for them (vmcnt is in-order and counts stores)
+    // the accumulators START at the bias (one add per element less in the epilogue: with fp32 MFMAs every VALU
+    // instruction is serial time)
     float biasv[4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int col = 32 * (w + 4 * ni) + fr;
       biasv[ni] = col < L.out_dim ? L.bias[col] : 0.f;
     }
+    int hidx = -1;
+    if (segm) hidx = l == p.seg.h[0].layer ? 0 : (l == p.seg.h[1].layer ? 1 : -1);
+    if (hidx >= 0) {
+      fused_hoist_init(acc, hu[hidx], hwx[hidx], xs, biasv, L.out_dim, w, fr, fh);
+    } else {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][ni][r] = biasv[ni];
+    }
+    const FusedBView bv = fused_bview(L.wf, L.U, w, lane);
+    const float* ap = S + fr * FLD + 8 * fh;
     if (nu > 0) {
       fused_kloop_dispatch(acc, ap, bv, nu, fused_nact(L.out_dim, w), PB);
       if (l + 1 < p.n_hidden) {   // next layer's first weights travel while this layer's epilogue runs
@@ -470,9 +469,9 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
     {
       const bool drop = L.drop_thr != 0u;
       const bool even = ((p.row_offset + (uint32_t)row0) & 1u) == 0u;   // 4*fh and crow(2rp) are even
-      if (!drop) fused_fwd_epilogue<false, true>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
-      else if (even) fused_fwd_epilogue<true, true>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
-      else fused_fwd_epilogue<true, false>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+      if (!drop) fused_fwd_epilogue<false, true>(acc, S, L, w, fr, fh, row0, p.N, p.row_offset);
+      else if (even) fused_fwd_epilogue<true, true>(acc, S, L, w, fr, fh, row0, p.N, p.row_offset);
+      else fused_fwd_epilogue<true, false>(acc, S, L, w, fr, fh, row0, p.N, p.row_offset);
     }
     fused_zero_pad(S, L.x0_col >= 0 ? L.x0_col + p.W0 : L.out_dim);
     __syncthreads();
@@ -591,43 +590,64 @@ __device__ __forceinline__ int bf16_rot(int nu) {
   return 0;
 #endif
 }
-__device__ __forceinline__ int bf16_unit(int u, int rot, int nu) { const int v = u + rot; return v >= nu ? v - nu : v; }
 
-// weights of k-unit u for this wave's NACT n-tiles
-template <int NACT>
-__device__ __forceinline__ void bf16_load_unit(bf16x8 (&dst)[4], const __bf16* wfb, int U, int w, int lane, int u) {
+// Weights come through a buffer resource with SCALAR offsets (as in the fp32 kernel's FusedBView): the first version built a
+// 64-bit address per load on the VALU -- 48 vector + 40 scalar instructions per 32 MFMAs, more than fits into the shadow of
+// 32-cycle MFMAs (the MFMA stream alone ran at 1.6x its ideal time).  Unit (n-tile t, k-unit u) = 1 KiB at ((t U + u) << 10).
+struct Bf16BView { __amdgpu_buffer_rsrc_t rsrc; int tb[4]; int voff; };
+__device__ __forceinline__ Bf16BView bf16_bview(const __bf16* wfb, int U, int w, int lane) {
+  Bf16BView v;
+  v.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wfb, 0, 0x7FFFFFFF, 0x00020000);
+  const int ws = __builtin_amdgcn_readfirstlane(w);
 #pragma unroll
-  for (int ni = 0; ni < NACT; ++ni)
-    dst[ni] = *reinterpret_cast<const bf16x8*>(wfb + ((size_t)(w + 4 * ni) * U + u) * 512 + lane * 8);
+  for (int ni = 0; ni < 4; ++ni) v.tb[ni] = (ws + 4 * ni) * U;
+  v.voff = lane * 16;
+  return v;
+}
+template <int NACT>
+__device__ __forceinline__ void bf16_load_unit(bf16x8 (&dst)[4], const Bf16BView& B, int u) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int ni = 0; ni < NACT; ++ni) {
+    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(B.rsrc, B.voff, (B.tb[ni] + u) << 10, 0);
+    dst[ni] = __builtin_bit_cast(bf16x8, r);
+  }
 }
 // the FIRST k-unit (of this workgroup's order) of a layer, requested before the previous layer's epilogue
 __device__ __forceinline__ void bf16_prefetch(Bf16Pre& P, const __bf16* wfb, int U, int w, int lane, int nact, int nu) {
   if (nu <= 0) return;
-  const int u = bf16_unit(0, bf16_rot(nu), nu);
+  const Bf16BView B = bf16_bview(wfb, U, w, lane);
+  const int u = bf16_rot(nu);
   switch (nact) {
-    case 4: bf16_load_unit<4>(P.b, wfb, U, w, lane, u); break;
-    case 3: bf16_load_unit<3>(P.b, wfb, U, w, lane, u); break;
-    case 2: bf16_load_unit<2>(P.b, wfb, U, w, lane, u); break;
-    case 1: bf16_load_unit<1>(P.b, wfb, U, w, lane, u); break;
+    case 4: bf16_load_unit<4>(P.b, B, u); break;
+    case 3: bf16_load_unit<3>(P.b, B, u); break;
+    case 2: bf16_load_unit<2>(P.b, B, u); break;
+    case 1: bf16_load_unit<1>(P.b, B, u); break;
     default: break;
   }
 }
 
-// acc[m][ni] += S[64 rows][16 nu] * Wfb; P holds the first unit (bf16_prefetch)
+// acc[m][ni] += S[64 rows][16 nu] * Wfb; P holds the first unit (bf16_prefetch).  Units are walked in the rotated order
+// rot, rot+1, ..., wrapping at nu; prefetches past the last unit simply wrap too (valid memory, never used), so the loop
+// carries two running SCALAR unit counters and no clamps.
 template <int NACT>
 __device__ __forceinline__ void bf16_kloop(f32x16 (&acc)[2][4], const __bf16* ap, const __bf16* wfb, int U, int w, int lane,
                                            int nu, const Bf16Pre& P) {
   bf16x8 ring[BF_RING][4];
   bf16x8 a0[2], a1[2];
-  const int rot = bf16_rot(nu), ulast = nu - 1;
-  auto readA = [&](bf16x8 (&a)[2], int q) {          // q = position in this workgroup's unit order
-    if ((BF_ABLATE & 4) && q > 0) return;
-    const int u = bf16_unit(q, rot, nu);
-    a[0] = *reinterpret_cast<const bf16x8*>(ap + 16 * u);
-    a[1] = *reinterpret_cast<const bf16x8*>(ap + 32 * FLDH + 16 * u);
+  const Bf16BView B = bf16_bview(wfb, U, w, lane);
+  auto nextu = [&](int u) { return u + 1 == nu ? 0 : u + 1; };
+  int ub = nextu(bf16_rot(nu)), ua = bf16_rot(nu);   // next unit to request / next unit's rows to read
+  auto readA = [&](bf16x8 (&a)[2]) {
+    if (!(BF_ABLATE & 4) || ua == bf16_rot(nu)) {
+      a[0] = *reinterpret_cast<const bf16x8*>(ap + 16 * ua);
+      a[1] = *reinterpret_cast<const bf16x8*>(ap + 32 * FLDH + 16 * ua);
+    }
+    ua = nextu(ua);
   };
-  auto loadB = [&](bf16x8 (&dst)[4], int q) {
-    if (!(BF_ABLATE & 1)) bf16_load_unit<NACT>(dst, wfb, U, w, lane, bf16_unit(q, rot, nu));
+  auto loadB = [&](bf16x8 (&dst)[4]) {
+    if (!(BF_ABLATE & 1)) bf16_load_unit<NACT>(dst, B, ub);
+    ub = nextu(ub);
   };
   auto mma = [&](const bf16x8 (&a)[2], const bf16x8 (&b)[4]) {
     if (BF_ABLATE & 2) return;
@@ -640,17 +660,17 @@ __device__ __forceinline__ void bf16_kloop(f32x16 (&acc)[2][4], const __bf16* ap
 #pragma unroll
   for (int ni = 0; ni < NACT; ++ni) ring[0][ni] = P.b[ni];
 #pragma unroll
-  for (int q = 1; q < BF_RING - 1; ++q) loadB(ring[q], min(q, ulast));   // unconditional (clamped): every slot is defined here
-  readA(a0, 0);
+  for (int q = 1; q < BF_RING - 1; ++q) loadB(ring[q]);   // unconditional: every slot is defined here
+  readA(a0);
   int s = 0;
   for (; s + BF_RING <= nu; s += BF_RING) {   // static ring slots; one unit refilled per step, BF_RING - 1 steps ahead
 #pragma unroll
     for (int q = 0; q < BF_RING; q += 2) {
-      loadB(ring[(q + BF_RING - 1) % BF_RING], min(s + q + BF_RING - 1, ulast));
-      readA(a1, min(s + q + 1, ulast));
+      loadB(ring[(q + BF_RING - 1) % BF_RING]);
+      readA(a1);
       mma(a0, ring[q]);
-      loadB(ring[q % BF_RING], min(s + q + BF_RING, ulast));
-      readA(a0, min(s + q + 2, ulast));
+      loadB(ring[q % BF_RING]);
+      readA(a0);
       mma(a1, ring[q + 1]);
     }
   }
@@ -658,8 +678,8 @@ __device__ __forceinline__ void bf16_kloop(f32x16 (&acc)[2][4], const __bf16* ap
 #pragma unroll
   for (int q = 0; q < BF_RING - 1; ++q) {
     if (s + q < nu) {
-      if (q & 1) { readA(a0, min(s + q + 1, ulast)); mma(a1, ring[q]); }
-      else { readA(a1, min(s + q + 1, ulast)); mma(a0, ring[q]); }
+      if (q & 1) { readA(a0); mma(a1, ring[q]); }
+      else { readA(a1); mma(a0, ring[q]); }
     }
   }
 }
@@ -724,23 +744,23 @@ __device__ __forceinline__ void fused_forward_bf16_body(const FusedFwdArgs& p, f
     const FusedLayer& L = p.ly[l];
     const int nu = (L.in + 15) >> 4, nact = fused_nact(L.out_dim, w);
     f32x16 acc[2][4];
+    float biasv[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int col = 32 * (w + 4 * ni) + fr;
+      biasv[ni] = col < L.out_dim ? L.bias[col] : 0.f;
+    }
     int hidx = -1;
     if (segm) hidx = l == p.seg.h[0].layer ? 0 : (l == p.seg.h[1].layer ? 1 : -1);
     if (hidx >= 0) {
-      fused_hoist_init(acc, hu[hidx], hwx[hidx], xs, L.out_dim, w, fr, fh);
+      fused_hoist_init(acc, hu[hidx], hwx[hidx], xs, biasv, L.out_dim, w, fr, fh);
     } else {
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[m][ni][r] = 0.f;
-    }
-    float biasv[4];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int col = 32 * (w + 4 * ni) + fr;
-      biasv[ni] = col < L.out_dim ? L.bias[col] : 0.f;
+          for (int r = 0; r < 16; ++r) acc[m][ni][r] = biasv[ni];
     }
     if (nu > 0) {
       bf16_kloop_dispatch(acc, SH + fr * FLDH + 8 * fh, reinterpret_cast<const __bf16*>(L.wf), L.U, w, lane, nu, nact, R);
@@ -756,13 +776,13 @@ __device__ __forceinline__ void fused_forward_bf16_body(const FusedFwdArgs& p, f
       const bool drop = L.drop_thr != 0u;
       const bool even = ((p.row_offset + (uint32_t)row0) & 1u) == 0u;
       if (last_hidden) {   // the output layer / the backward head read fp32: its input goes to the slab as fp32
-        if (!drop) fused_fwd_epilogue<false, true, false>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
-        else if (even) fused_fwd_epilogue<true, true, false>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
-        else fused_fwd_epilogue<true, false, false>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+        if (!drop) fused_fwd_epilogue<false, true, false>(acc, S, L, w, fr, fh, row0, p.N, p.row_offset);
+        else if (even) fused_fwd_epilogue<true, true, false>(acc, S, L, w, fr, fh, row0, p.N, p.row_offset);
+        else fused_fwd_epilogue<true, false, false>(acc, S, L, w, fr, fh, row0, p.N, p.row_offset);
       } else {
-        if (!drop) fused_fwd_epilogue<false, true, true>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
-        else if (even) fused_fwd_epilogue<true, true, true>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
-        else fused_fwd_epilogue<true, false, true>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+        if (!drop) fused_fwd_epilogue<false, true, true>(acc, S, L, w, fr, fh, row0, p.N, p.row_offset);
+        else if (even) fused_fwd_epilogue<true, true, true>(acc, S, L, w, fr, fh, row0, p.N, p.row_offset);
+        else fused_fwd_epilogue<true, false, true>(acc, S, L, w, fr, fh, row0, p.N, p.row_offset);
       }
     }
     if (!last_hidden && L.x0_col < 0) {      // zero pad [out_dim, roundup16) of the bf16 slab (the x0 loader pads its own end)

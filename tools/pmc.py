@@ -34,7 +34,7 @@ def rocprof_path():
     return shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
 
 
-def run_pass(counters, bench_args, timeout=240, keep_dir=None):
+def run_pass(counters, bench_args, timeout=240, keep_dir=None, script="bench.py"):
     """One `rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py <bench_args>` run.
     Returns {kernel: {"counters": {name: avg per launch}, "launches": n, "duration_us": median}}."""
     rp = rocprof_path()
@@ -43,7 +43,7 @@ def run_pass(counters, bench_args, timeout=240, keep_dir=None):
     d = keep_dir or tempfile.mkdtemp(prefix="dsdf_pmc_")
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = [rp, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "--", sys.executable,
-           os.path.join(ROOT, "bench.py"), *bench_args]
+           os.path.join(ROOT, script), *bench_args]
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
     if r.returncode != 0:
         raise RuntimeError(f"rocprofv3 pass {counters} failed (rc {r.returncode}): {r.stderr[-400:]}")
@@ -85,14 +85,14 @@ def traffic(bench_args, timeout=240):
     return out
 
 
-def mfma(bench_args, timeout=240):
+def mfma(bench_args, timeout=240, script="bench.py"):
     """Per kernel: executed fp32 MFMA FLOPs and MFMA-pipe busy share from the SQ counters of ONE pass.
       exec_mfma_flop  = SQ_INSTS_VALU_MFMA_MOPS_F32 x 512   (one v_mfma_f32_32x32x2_f32 = 4096 FLOP; mops_per_mfma_inst reports
                                                               the measured MOPS per instruction so the unit can be checked: 8)
       mfma_busy_frac  = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES): MFMA-pipe-busy share of the busy CUs' SIMD cycles
       clock_ghz       = GRBM_GUI_ACTIVE / 8 XCDs / duration
       exec_frac_of_peak = exec_mfma_flop / duration / 157.3 TFLOP/s  (durations of a PROFILED pass run a few % long)"""
-    res = run_pass(MFMA_COUNTERS, bench_args, timeout)
+    res = run_pass(MFMA_COUNTERS, bench_args, timeout, script=script)
     for k, e in res.items():
         v = e["counters"]
         mops, busy, cu = v.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0), v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), v.get("SQ_BUSY_CU_CYCLES", 0.0)
@@ -115,7 +115,12 @@ def mfma(bench_args, timeout=240):
 
 CHILD_ARGS = ["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-profile", "--no-pmc", "--no-extras"]
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[1] == "--script":      # python tools/pmc.py --script tools/x.py [args]
+    m = mfma(sys.argv[3:], script=sys.argv[2])
+    for k, e in sorted(m.items(), key=lambda kv: -kv[1].get("duration_us", 0)):
+        print(f"{k:28s} {e.get('duration_us', 0):8.1f} us  launches {e['launches']}  mfma_busy {100 * e.get('mfma_busy_frac', 0):5.1f} %  clock {e.get('clock_ghz', 0):.2f} GHz"
+              f"  busy cyc/inst {e.get('mfma_busy_cycles_per_inst', 0):.1f}  counters {({c: round(v) for c, v in e['counters'].items()})}", flush=True)
+elif __name__ == "__main__":
     tag = sys.argv[1] if len(sys.argv) > 1 else "pmc"
     extra = sys.argv[2:]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
