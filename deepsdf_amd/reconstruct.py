@@ -21,7 +21,9 @@ from .engine import Engine, _ptr, _stream
 def reconstruct(engine: Engine, samples_xyz, samples_sdf, *, num_iterations=800, clamp_dist=0.1, lr=5e-3,
                 l2reg=1e-4, init_std=0.01, lr_drop_every=None, generator=None, z0=None, callback=None):
     """samples_xyz [B, S, G], samples_sdf [B, S] (device tensors; the SAME S points are used every iteration unless
-    `callback(it)` returns new (xyz, sdf)).  Returns (codes [B, L], last per-step loss as float)."""
+    `callback(it)` returns new (xyz, sdf)).  Returns (codes [B, L], loss): `loss` is the engine's DEVICE scalar tensor (shape
+    [1], the last iteration's sum over the B per-shape mean losses) -- reading it with float() synchronises, so it is left to
+    the caller."""
     B, S, G = samples_xyz.shape
     L = engine.spec.latent_size
     dev = engine.device
