@@ -6,14 +6,15 @@ import os
 from .build import LIB
 
 MAX_LAYERS = 16
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class DsdfNet(C.Structure):
     _fields_ = [("n_layers", C.c_int32), ("latent_size", C.c_int32), ("geom_dim", C.c_int32),
                 ("in_dim", C.c_int32 * MAX_LAYERS), ("out_dim", C.c_int32 * MAX_LAYERS),
                 ("weight_norm_mask", C.c_uint32), ("dropout_mask", C.c_uint32), ("skip_mask", C.c_uint32),
-                ("dropout_p", C.c_float), ("use_tanh", C.c_int32), ("fwd_bf16", C.c_int32)]
+                ("dropout_p", C.c_float), ("use_tanh", C.c_int32), ("fwd_bf16", C.c_int32),
+                ("latent_dropout", C.c_int32), ("xyz_in_all", C.c_int32)]
 
 
 class DsdfParamLayout(C.Structure):
@@ -64,7 +65,7 @@ PROTOTYPES = {
     "dsdf_materialize_weights": [_NET, _P, _P, _P],
     "dsdf_decode": [_NET, _P, _P, _P, _I64, _I64, _P, _P, _SZ, _P],
     "dsdf_module_forward": [_NET, _P, _P, _P, _I64, _I64, _I32, C.POINTER(C.c_uint32), _P, _P, _SZ, _P],
-    "dsdf_module_backward": [_NET, _P, _P, _P, _I64, _I32, _P, _I32, _P, _I64, _P, _SZ, _P],
+    "dsdf_module_backward": [_NET, _P, _P, _P, _I64, _I32, C.POINTER(C.c_uint32), _P, _I32, _P, _I64, _P, _SZ, _P],
     "dsdf_module_jvp": [_NET, _P, _P, _P, _I64, _I64, _I32, _P, _P, _SZ, _P],
     "dsdf_train_forward_backward": [_NET, _P, _P, _P, _I64, C.POINTER(DsdfBatch), C.POINTER(DsdfLossCfg), _P, _P, _P,
                                     _P, _I32, _P, _SZ, _P],

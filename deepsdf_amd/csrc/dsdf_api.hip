@@ -102,10 +102,12 @@ int validate(const DsdfNet* n) {
     if (n->fwd_bf16 && (n->in_dim[l] > 512 || (l < n->n_layers - 1 && n->out_dim[l] > 512)))
       return fail(DSDF_E_INVALID, "fwd_bf16 needs every layer width <= 512 (layer %d: %d -> %d)", l, n->in_dim[l], n->out_dim[l]);
     if (l > 0) {
-      const int expect = n->out_dim[l - 1] + ((n->skip_mask >> l) & 1 ? W0 : 0);
+      const int expect = n->out_dim[l - 1] + ((n->skip_mask >> l) & 1 ? W0 : (n->xyz_in_all ? n->geom_dim : 0));
       if (n->in_dim[l] != expect) return fail(DSDF_E_INVALID, "layer %d: in_dim %d != %d", l, n->in_dim[l], expect);
     }
   }
+  if ((n->latent_dropout || n->xyz_in_all) && n->fwd_bf16)
+    return fail(DSDF_E_INVALID, "fwd_bf16 is not available with latent_dropout / xyz_in_all");
   if (n->in_dim[n->n_layers - 1] % 4 != 0) return fail(DSDF_E_INVALID, "last hidden width must be a multiple of 4");
   if (!(n->dropout_p >= 0.f && n->dropout_p < 1.f)) return fail(DSDF_E_INVALID, "dropout_p must be in [0,1)");
   return 0;
@@ -239,7 +241,7 @@ struct Plan {
   int ld_dp, ldz, ldcs, ld_part, last_blocks, nsplit, kchunk, mt;
   long long slab;
   size_t u_off, y_off, dp_off[2], dzA_off, dzB_off, slab_off, colsum_off, part_off, part2_off, partdb_off,
-      partloss_off, segpart_off, segnorm_off, gnorm_off, total;
+      partloss_off, segpart_off, segnorm_off, gnorm_off, dxz_off[2], total;
   // fused backward: per hidden layer l a global dP_l buffer, the forward's mask bits and per-workgroup column sums
   size_t dpl_off[DSDF_MAX_LAYERS], mask_off[DSDF_MAX_LAYERS], cs_off[DSDF_MAX_LAYERS], dwslab_off[DSDF_MAX_LAYERS];
   int nwg;
@@ -264,7 +266,8 @@ Plan make_plan(const DsdfNet* n, int64_t N, int64_t R, bool inference, bool segm
   if (inference) {
     size_t pp[2] = {take((size_t)N * maxw * 4), take((size_t)N * maxw * 4)};
     for (int l = 0; l < P.nl; ++l) {
-      if (l == 0 || ((n->skip_mask >> l) & 1)) P.in_off[l] = take((size_t)N * P.ld_in[l] * 4);
+      // (xyz_in_all: every layer input carries xyz columns the gather pre-fills, so none of them can share a ping-pong buffer)
+      if (l == 0 || ((n->skip_mask >> l) & 1) || n->xyz_in_all) P.in_off[l] = take((size_t)N * P.ld_in[l] * 4);
       else P.in_off[l] = pp[l & 1];
     }
     P.total = o;
@@ -279,6 +282,7 @@ Plan make_plan(const DsdfNet* n, int64_t N, int64_t R, bool inference, bool segm
   P.ldz = (int)rup(P.W0, 4);
   P.dzA_off = take((size_t)N * P.ldz * 4);
   P.dzB_off = take((size_t)N * P.ldz * 4);
+  for (int t = 0; t < 2; ++t) P.dxz_off[t] = n->xyz_in_all ? take((size_t)N * 4 * 4) : 0;   // [N][4]: one layer's d/d(xyz), running sum
   // split-K of the dW GEMMs: chunks of >= 256 points, at most NSPLIT_MAX slabs
   int ns = (int)((N + 255) / 256);
   if (ns > NSPLIT_MAX) ns = NSPLIT_MAX;
@@ -425,18 +429,29 @@ int materialize(const DsdfNet* net, const float* params, float* packed, hipStrea
   return 0;
 }
 
-// x0 (+ skip copies) from either the latent table + segments or an explicit input
+constexpr float LATENT_DROPOUT_P = 0.2f;          // nn.Dropout(0.2), deep_sdf_decoder.py:36
+constexpr int LATENT_DROPOUT_KEY = DSDF_MAX_LAYERS - 1;   // slot of dropout_key[] (no hidden layer can have this index)
+inline uint32_t latent_drop_thr() { return (uint32_t)lround((double)LATENT_DROPOUT_P * 65536.0); }
+inline bool net_variant(const DsdfNet* n) { return n->latent_dropout || n->xyz_in_all; }
+
+// x0 (+ skip copies, + the xyz columns of every layer of an xyz_in_all net) from either the latent table + segments or an
+// explicit input; keys != nullptr && training: latent_dropout nets drop layer 0's latent columns on the way
 int run_gather(const DsdfNet* net, const Plan& P, void* ws, const float* table, const DsdfBatch* b, const float* input,
-               int64_t ld_in, int64_t n, hipStream_t st) {
+               int64_t ld_in, int64_t n, hipStream_t st, int training = 0, const uint32_t* keys = nullptr, uint32_t row_offset = 0) {
   GatherArgs g;
   memset(&g, 0, sizeof(g));
   g.table = table; g.L = net->latent_size; g.G = net->geom_dim;
   if (b) { g.xyz = b->xyz; g.seg_scene = b->seg_scene; g.seg_offset = b->seg_offset; g.R = (int)b->n_segments; }
   g.input = input; g.ld_in = ld_in; g.n = (int)n;
+  const int W0 = net->latent_size + net->geom_dim;
+  const bool drop = net->latent_dropout && training && keys != nullptr && net->latent_size > 0;
+  if (drop) { g.drop_key = keys[LATENT_DROPOUT_KEY]; g.drop_thr = latent_drop_thr(); g.drop_scale = 1.0f / (1.0f - LATENT_DROPOUT_P); g.row_offset = row_offset; }
   g.ndst = 0;
-  g.dst[g.ndst++] = GatherDst{at<float>(ws, P.in_off[0]), P.ld_in[0], 0};
-  for (int l = 1; l < net->n_layers; ++l)
-    if ((net->skip_mask >> l) & 1) g.dst[g.ndst++] = GatherDst{at<float>(ws, P.in_off[l]), P.ld_in[l], net->out_dim[l - 1]};
+  g.dst[g.ndst++] = GatherDst{at<float>(ws, P.in_off[0]), P.ld_in[0], 0, 0, W0, drop ? 1 : 0};
+  for (int l = 1; l < net->n_layers; ++l) {
+    if ((net->skip_mask >> l) & 1) g.dst[g.ndst++] = GatherDst{at<float>(ws, P.in_off[l]), P.ld_in[l], net->out_dim[l - 1], 0, W0, 0};
+    else if (net->xyz_in_all) g.dst[g.ndst++] = GatherDst{at<float>(ws, P.in_off[l]), P.ld_in[l], net->out_dim[l - 1], net->latent_size, net->geom_dim, 0};
+  }
   hipLaunchKernelGGL(gather_concat_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, g);
   LAUNCH_OK("gather_concat_kernel");
   return 0;
@@ -448,6 +463,7 @@ bool fused_enabled() {
 }
 
 bool fused_eligible(const DsdfNet* net) {
+  if (net_variant(net)) return false;   // latent_dropout / xyz_in_all live on the layer-by-layer kernels only
   if (net->in_dim[0] > FMAXW) return false;
   for (int l = 0; l < net->n_layers - 1; ++l)
     if (net->in_dim[l] > FMAXW || net->out_dim[l] > FMAXW) return false;
@@ -587,8 +603,12 @@ float mask_scale_of(const DsdfNet* net, int layer, int training) {
 
 // shared backward over hidden layers, given dp of layer nl-2 in dp[0] and the last layer's partials.
 // ncols_dz: how many leading x0 columns of d/dx0 are needed (L for training, W0 for the module path).
+// keys / row_offset: latent_dropout nets mask the latent part of layer 0's dX (dzA) with the forward's hash.
+// xyz_acc != nullptr (xyz_in_all, module path with d/d(input)): *xyz_acc = true when dxz_off[1] holds the sum of the xyz_in
+// layers' d/d(xyz) (the caller adds it to the xyz columns of d_input).
 int run_backward(const DsdfNet* net, const Plan& P, void* ws, const float* packed, const float* params, int64_t n,
-                 int training, float* grads, int accumulate, int ncols_dz, bool* used_dzB, hipStream_t st, bool want_dw = true) {
+                 int training, float* grads, int accumulate, int ncols_dz, bool* used_dzB, hipStream_t st, bool want_dw = true,
+                 const uint32_t* keys = nullptr, uint32_t row_offset = 0, bool* xyz_acc = nullptr) {
   DsdfParamLayout L;
   param_layout(net, &L);
   const Packed pk = packed_layout(net);
@@ -650,14 +670,30 @@ int run_backward(const DsdfNet* net, const Plan& P, void* ws, const float* packe
       a.act = at<float>(ws, P.in_off[l]); a.ldact = P.ld_in[l];
       a.mask_cols = net->out_dim[l - 1];
       a.mask_scale = mask_scale_of(net, l - 1, training);
-      a.N = skip ? (ncols_dz > 0 ? a.mask_cols + ncols_dz : a.mask_cols) : net->in_dim[l];
+      const bool xyz_l = !skip && net->xyz_in_all;                 // this layer's input is [a || xyz]
+      const bool want_xyz = xyz_l && xyz_acc != nullptr && ncols_dz > net->latent_size;
+      a.N = skip ? (ncols_dz > 0 ? a.mask_cols + ncols_dz : a.mask_cols) : (xyz_l ? a.mask_cols + (want_xyz ? net->geom_dim : 0) : net->in_dim[l]);
       if (skip && ncols_dz > 0) { a.C2 = at<float>(ws, P.dzB_off); a.ldc2 = P.ldz; a.c2_cols = ncols_dz; *used_dzB = true; }
+      if (want_xyz) { a.C2 = at<float>(ws, P.dxz_off[0]); a.ldc2 = 4; a.c2_cols = net->geom_dim; }
       a.colsum = at<float>(ws, P.colsum_off); a.ldcs = P.ldcs;
       TRY(launch_nt<EPI_BWD>(a, st));
+      if (want_xyz) {
+        const long long tot = (long long)n * net->geom_dim;
+        hipLaunchKernelGGL(acc_cols_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, at<float>(ws, P.dxz_off[0]), 4,
+                           at<float>(ws, P.dxz_off[1]), 4, 0, (int)n, net->geom_dim, *xyz_acc ? 1 : 0);
+        LAUNCH_OK("acc_cols_kernel");
+        *xyz_acc = true;
+      }
       cur ^= 1;
     } else if (ncols_dz > 0) {
       a.C = at<float>(ws, P.dzA_off); a.ldc = P.ldz; a.N = ncols_dz;
       TRY(launch_nt<EPI_PLAIN>(a, st));
+      if (net->latent_dropout && training && keys != nullptr && net->latent_size > 0) {   // layer 0 saw the DROPPED latent
+        const long long tot = (long long)n * net->latent_size;
+        hipLaunchKernelGGL(latent_drop_bwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, at<float>(ws, P.dzA_off), P.ldz,
+                           (int)n, net->latent_size, keys[LATENT_DROPOUT_KEY], latent_drop_thr(), 1.0f / (1.0f - LATENT_DROPOUT_P), row_offset);
+        LAUNCH_OK("latent_drop_bwd_kernel");
+      }
     }
   }
   return 0;
@@ -986,7 +1022,7 @@ int dsdf_module_forward(const DsdfNet* net, const float* packed, const float* pa
   const Plan P = make_plan(net, n, 0, false);
   if (ws_bytes < P.total) return fail(DSDF_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, P.total);
   hipStream_t st = (hipStream_t)stream;
-  TRY(run_gather(net, P, ws, nullptr, nullptr, input, ld_in, n, st));
+  TRY(run_gather(net, P, ws, nullptr, nullptr, input, ld_in, n, st, training, dropout_key, 0));
   if (fused_enabled() && fused_eligible(net))
     return run_fused_forward(net, P, ws, packed, params, n, training, dropout_key, 0, true, sdf_out, at<float>(ws, P.u_off), st);
   TRY(run_hidden_forward(net, P, ws, packed, params, n, training, dropout_key, 0, st));
@@ -1003,12 +1039,14 @@ int dsdf_module_forward(const DsdfNet* net, const float* packed, const float* pa
 }
 
 int dsdf_module_backward(const DsdfNet* net, const float* packed, const float* params, const float* d_sdf, int64_t n,
-                         int32_t training, float* grads, int32_t accumulate, float* d_input, int64_t ld_din, void* ws,
-                         size_t ws_bytes, void* stream) {
+                         int32_t training, const uint32_t* dropout_key, float* grads, int32_t accumulate, float* d_input,
+                         int64_t ld_din, void* ws, size_t ws_bytes, void* stream) {
   TRY(check_common(net, packed, params, ws));
   if (n == 0) return 0;
   if (!d_sdf || !grads || n < 0) return fail(DSDF_E_INVALID, "bad d_sdf/grads");
   if (d_input && ld_din < net->in_dim[0]) return fail(DSDF_E_INVALID, "ld_din too small");
+  if (training && net->latent_dropout && d_input && !dropout_key)
+    return fail(DSDF_E_INVALID, "dropout_key is NULL (latent_dropout needs the forward's key for d/d(input))");
   const Plan P = make_plan(net, n, 0, false);
   if (ws_bytes < P.total) return fail(DSDF_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, P.total);
   hipStream_t st = (hipStream_t)stream;
@@ -1034,7 +1072,30 @@ int dsdf_module_backward(const DsdfNet* net, const float* packed, const float* p
     TRY(run_backward_fused(net, P, ws, packed, params, n, training, grads, accumulate, d_input ? P.W0 : 0, &used_dzB, st, true, h));
   } else {
     TRY(launch_last<LAST_BWD_EXT>(a, P.last_blocks, st));
-    TRY(run_backward(net, P, ws, packed, params, n, training, grads, accumulate, d_input ? P.W0 : 0, &used_dzB, st));
+    bool xyz_acc = false;
+    if (d_input && net->xyz_in_all && last > 0) {   // the last layer's input is [a || xyz] too: its own d/d(xyz) opens the running sum
+      const long long tot = (long long)n * net->geom_dim;
+      hipLaunchKernelGGL(last_xyz_grad_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_sdf, at<float>(ws, P.u_off),
+                         packed + pk.w_off[last] + net->out_dim[last - 1], net->geom_dim, net->use_tanh, at<float>(ws, P.dxz_off[1]), 4, 0,
+                         (int)n, 0);
+      LAUNCH_OK("last_xyz_grad_kernel");
+      xyz_acc = true;
+    }
+    TRY(run_backward(net, P, ws, packed, params, n, training, grads, accumulate, d_input ? P.W0 : 0, &used_dzB, st, true, dropout_key, 0,
+                     (d_input && net->xyz_in_all) ? &xyz_acc : nullptr));
+    if (d_input) {
+      const long long tot = (long long)n * P.W0;
+      hipLaunchKernelGGL(add2_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, at<float>(ws, P.dzA_off), P.ldz,
+                         used_dzB ? at<float>(ws, P.dzB_off) : nullptr, P.ldz, d_input, (long long)ld_din, (int)n, P.W0);
+      LAUNCH_OK("add2_kernel");
+      if (xyz_acc) {
+        const long long tx = (long long)n * net->geom_dim;
+        hipLaunchKernelGGL(acc_cols_kernel, dim3((unsigned)((tx + 255) / 256)), dim3(256), 0, st, at<float>(ws, P.dxz_off[1]), 4, d_input,
+                           (int)ld_din, net->latent_size, (int)n, net->geom_dim, 1);
+        LAUNCH_OK("acc_cols_kernel");
+      }
+    }
+    return 0;
   }
   if (d_input) {
     const long long tot = (long long)n * P.W0;
@@ -1054,6 +1115,7 @@ int dsdf_module_jvp(const DsdfNet* net, const float* packed, const float* params
   TRY(check_common(net, packed, params, ws));
   if (n == 0) return 0;
   if (!tangent || !jvp_out || n < 0 || ld_t < net->in_dim[0]) return fail(DSDF_E_INVALID, "bad tangent/jvp_out/ld_t");
+  if (net_variant(net)) return fail(DSDF_E_INVALID, "dsdf_module_jvp is not implemented for latent_dropout / xyz_in_all nets");
   const Plan P = make_plan(net, n, 0, false);
   if (ws_bytes < P.total) return fail(DSDF_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, P.total);
   hipStream_t st = (hipStream_t)stream;
@@ -1152,7 +1214,7 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
     TRY(run_fused_forward(net, P, ws, packed, params, n, cfg->training, cfg->dropout_key, (uint32_t)b->row_offset, true,
                           nullptr, nullptr, st, &seg, merged ? &fwd_args : nullptr));
   } else {
-    TRY(run_gather(net, P, ws, latent_table, b, nullptr, 0, n, st));
+    TRY(run_gather(net, P, ws, latent_table, b, nullptr, 0, n, st, cfg->training, cfg->dropout_key, (uint32_t)b->row_offset));
     if (fusedb)
       TRY(run_fused_forward(net, P, ws, packed, params, n, cfg->training, cfg->dropout_key, (uint32_t)b->row_offset, true,
                             nullptr, nullptr, st, nullptr, merged ? &fwd_args : nullptr));
@@ -1196,7 +1258,8 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
                            use, segsum ? &sb : nullptr, merged ? &fwd_args : nullptr));
     if (use != nullptr && adam_fused) *adam_fused = 1;
   } else {
-    TRY(run_backward(net, P, ws, packed, params, n, cfg->training, grads, accumulate, Lc, &used_dzB, st, want_dw));
+    TRY(run_backward(net, P, ws, packed, params, n, cfg->training, grads, accumulate, Lc, &used_dzB, st, want_dw, cfg->dropout_key,
+                     (uint32_t)b->row_offset));
   }
 
   SegArgs s;

@@ -41,11 +41,15 @@ __global__ void latent_renorm_kernel(float* __restrict__ table, int L, const int
 
 // K0b: x0[n] = [E[scene(n)] || xyz[n]] written to up to 1 + popcount(skip_mask) destinations
 // (train_deep_sdf.py:509-511; the skip destinations realise deep_sdf_decoder.py:88-89 without a cat).
-struct GatherDst { float* ptr; int ld; int col0; };
+// A destination takes columns [src0, src0 + ncols) of x0 at its column col0: the whole x0 for layer 0 and the skip layer, only
+// the xyz columns for the layers of an xyz_in_all net (deep_sdf_decoder.py:90-91).  drop != 0 (layer 0 of a latent_dropout net
+// in training, :79-82): the latent columns pass through the dropout hash (key drop_key, p = 0.2) on their way.
+struct GatherDst { float* ptr; int ld; int col0; int src0; int ncols; int drop; };
 struct GatherArgs {
   const float* table; int L; const float* xyz; int G;
   const int64_t* seg_scene; const int64_t* seg_offset; int R;
   const float* input; long long ld_in;  // module path: rows come from an explicit [n, L+G] input instead
+  uint32_t drop_key, drop_thr; float drop_scale; uint32_t row_offset;
   int n; int ndst; GatherDst dst[DSDF_MAX_LAYERS + 1];
 };
 __global__ void gather_concat_kernel(const GatherArgs p) {
@@ -64,10 +68,54 @@ __global__ void gather_concat_kernel(const GatherArgs p) {
     src_lat = p.table + (size_t)p.seg_scene[lo] * p.L;
     src_xyz = p.xyz + (size_t)n * p.G;
   }
+  const uint32_t g = p.row_offset + (uint32_t)n;
   for (int c = lane; c < W; c += 64) {
     const float v = c < p.L ? src_lat[c] : src_xyz[c - p.L];
-    for (int d = 0; d < p.ndst; ++d) p.dst[d].ptr[(size_t)n * p.dst[d].ld + p.dst[d].col0 + c] = v;
+    for (int d = 0; d < p.ndst; ++d) {
+      const GatherDst& D = p.dst[d];
+      if (c < D.src0 || c >= D.src0 + D.ncols) continue;
+      float o = v;
+      if (D.drop && c < p.L) o = drop_keep(drop_pair_hash(drop_col_key((uint32_t)c, p.drop_key), g), g, p.drop_thr) ? v * p.drop_scale : 0.f;
+      D.ptr[(size_t)n * D.ld + D.col0 + (c - D.src0)] = o;
+    }
   }
+}
+
+// latent_dropout backward: d/d(latent) that came through layer 0 passes the same mask (in place, columns < L of dz [n][ld])
+__global__ void latent_drop_bwd_kernel(float* dz, int ld, int n, int L, uint32_t key, uint32_t thr, float scale, uint32_t row_offset) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)n * L) return;
+  const int r = (int)(i / L), c = (int)(i % L);
+  const uint32_t g = row_offset + (uint32_t)r;
+  float* q = dz + (size_t)r * ld + c;
+  *q = drop_keep(drop_pair_hash(drop_col_key((uint32_t)c, key), g), g, thr) ? *q * scale : 0.f;
+}
+
+// dst[r][c0 + j] (+)= src[r][j], j < w   (xyz_in_all: d/d(xyz) of one layer added to the running sum)
+__global__ void acc_cols_kernel(const float* src, int lds, float* dst, int ldd, int c0, int n, int w, int accumulate) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)n * w) return;
+  const int r = (int)(i / w), j = (int)(i % w);
+  float* q = dst + (size_t)r * ldd + c0 + j;
+  const float v = src[(size_t)r * lds + j];
+  *q = accumulate ? *q + v : v;
+}
+
+// xyz_in_all, module path: the LAST layer's own d/d(xyz) = du * w_last[out_prev + j] (its input is [a || xyz]); du is rebuilt from
+// the saved pre-activation u and the incoming gradient exactly as last_layer_kernel<LAST_BWD_EXT> does
+__global__ void last_xyz_grad_kernel(const float* d_sdf, const float* u_in, const float* w_xyz, int G, int use_tanh, float* dst,
+                                     int ldd, int c0, int n, int accumulate) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)n * G) return;
+  const int r = (int)(i / G), j = (int)(i % G);
+  const float u = u_in[r];
+  const float t1 = use_tanh ? tanhf(u) : u;
+  const float y = tanhf(t1);
+  float du = d_sdf[r] * (1.f - y * y);
+  if (use_tanh) du *= (1.f - t1 * t1);
+  float* q = dst + (size_t)r * ldd + c0 + j;
+  const float v = du * w_xyz[j];
+  *q = accumulate ? *q + v : v;
 }
 
 // ---------------------------------------------------------------------------------------------------

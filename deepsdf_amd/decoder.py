@@ -6,8 +6,9 @@ Same constructor, same ``.geom_dimension`` attribute, same ``forward(input[N, L+
 so checkpoints move freely between this class and the reference class.  All parameters are views of ONE flat fp32
 arena (the layout the HIP kernels and the fused Adam use); gradients land in a second arena.
 
-There is no CPU fallback: ``forward`` on a non-CUDA tensor raises.  Variants no shipped spec uses (LayerNorm
-without weight_norm, xyz_in_all, latent_dropout) raise NotImplementedError at construction.
+There is no CPU fallback: ``forward`` on a non-CUDA tensor raises.  ``xyz_in_all`` and ``latent_dropout`` (used by no shipped
+spec) run on the layer-by-layer kernels; the LayerNorm variant (norm_layers without weight_norm) raises NotImplementedError
+at construction.
 """
 import torch
 import torch.nn as nn
@@ -117,6 +118,7 @@ class Decoder(nn.Module):
         self.geom_dimension = s.geom_dimension
         self.norm_layers, self.latent_in, self.weight_norm = s.norm_layers, s.latent_in, s.weight_norm
         self.dropout, self.dropout_prob, self.use_tanh = s.dropout, s.dropout_prob, s.use_tanh
+        self.xyz_in_all, self.latent_dropout = s.xyz_in_all, s.latent_dropout
         self.dropout_seed = int(torch.initial_seed() & 0x7FFFFFFFFFFFFFFF)
         self._fwd_calls = 0
         self._engine = None

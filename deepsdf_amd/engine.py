@@ -163,6 +163,7 @@ class Engine:
         ws = self.train_workspace(n, 0)
         out = torch.empty(n, dtype=torch.float32, device=self.device)
         keys = (C.c_uint32 * _lib.MAX_LAYERS)(*[dropout_layer_key(seed, step, l) for l in range(_lib.MAX_LAYERS)])
+        self._module_keys = keys          # module_backward of a latent_dropout net needs the same mask
         _lib.check(self.lib.dsdf_module_forward(C.byref(self.cnet), _ptr(self.packed), _ptr(self.params), _ptr(x),
                                                 x.stride(0), n, int(training), keys, _ptr(out), _ptr(ws), ws.numel(),
                                                 _stream()))
@@ -172,7 +173,8 @@ class Engine:
         ws = self.train_workspace(n, 0)
         d_in = torch.empty(n, self.spec.in_dim[0], dtype=torch.float32, device=self.device) if need_input_grad else None
         _lib.check(self.lib.dsdf_module_backward(C.byref(self.cnet), _ptr(self.packed), _ptr(self.params), _ptr(d_sdf), n,
-                                                 int(training), _ptr(self.grads), int(accumulate), _ptr(d_in),
+                                                 int(training), getattr(self, "_module_keys", None), _ptr(self.grads),
+                                                 int(accumulate), _ptr(d_in),
                                                  self.spec.in_dim[0], _ptr(ws), ws.numel(), _stream()))
         return d_in
 
@@ -192,8 +194,9 @@ class Engine:
     # ---- training --------------------------------------------------------------------------------------------
     def train_forward_backward(self, latents, dlat, seg_scene, seg_offset, xyz, sdf_gt, *, n_norm, clamp_dist,
                                reg_coef, code_bound, training=True, seed=0, row_offset=0, accumulate=False,
-                               sdf_out=None, step=None, seg_len=0, frozen_decoder=False):
-        """One chunk of train_deep_sdf.py:509-533.  Gradients land in self.grads / dlat, loss in self.loss."""
+                               sdf_out=None, step=None, seg_len=0, frozen_decoder=False, loss_out=None):
+        """One chunk of train_deep_sdf.py:509-533.  Gradients land in self.grads / dlat, loss in self.loss (or in the
+        caller's 1-element fp32 device tensor `loss_out`, e.g. a slot of a per-epoch loss buffer: no copy kernel per step)."""
         self._fresh_weights()
         n, R = xyz.shape[0], seg_scene.shape[0]
         ws = self.train_workspace(n, R)
@@ -209,11 +212,12 @@ class Engine:
             cfg.dropout_key[l] = dropout_layer_key(seed, st, l)
         _lib.check(self.lib.dsdf_train_forward_backward(
             C.byref(self.cnet), _ptr(self.packed), _ptr(self.params), _ptr(latents), latents.shape[0], C.byref(b),
-            C.byref(cfg), _ptr(self.grads), _ptr(dlat), _ptr(self.loss), _ptr(sdf_out), int(accumulate), _ptr(ws),
-            ws.numel(), _stream()))
+            C.byref(cfg), _ptr(self.grads), _ptr(dlat), _ptr(self.loss if loss_out is None else loss_out), _ptr(sdf_out),
+            int(accumulate), _ptr(ws), ws.numel(), _stream()))
 
     def train_step(self, latents, dlat, lat_m, lat_v, seg_scene, seg_offset, xyz, sdf_gt, *, n_norm, clamp_dist, reg_coef,
-                   code_bound, lr_decoder, lr_latent, training=True, seed=0, seg_len=0, betas=(0.9, 0.999), eps=1e-8):
+                   code_bound, lr_decoder, lr_latent, training=True, seed=0, seg_len=0, betas=(0.9, 0.999), eps=1e-8,
+                   loss_out=None):
         """Whole optimiser step in ONE library call (single process, no --batch_split, no clipping): forward + backward +
         Adam on both groups + weight re-materialisation, with the decoder's Adam folded into the finalize pass."""
         self._fresh_weights()
@@ -232,7 +236,7 @@ class Engine:
         _lib.check(self.lib.dsdf_train_step(
             C.byref(self.cnet), _ptr(self.packed), _ptr(self.params), _ptr(self.grads), _ptr(self.exp_avg),
             _ptr(self.exp_avg_sq), _ptr(latents), latents.shape[0], _ptr(dlat), _ptr(lat_m), _ptr(lat_v), C.byref(b),
-            C.byref(cfg), C.byref(ad), _ptr(self.loss), None, _ptr(ws), ws.numel(), _stream()))
+            C.byref(cfg), C.byref(ad), _ptr(self.loss if loss_out is None else loss_out), None, _ptr(ws), ws.numel(), _stream()))
         self.weights_dirty = False
 
     def grad_norm(self, max_norm):

@@ -25,6 +25,8 @@ class StockDecoder(nn.Module):
         self.geom_dimension = spec.geom_dimension
         self.n_lin = spec.n_layers
         self.skip = [bool((spec.c_struct().skip_mask >> l) & 1) for l in range(spec.n_layers)]
+        self.xyz_in = [bool(spec.xyz_in_all and l != 0 and not self.skip[l]) for l in range(spec.n_layers)]
+        self.L = spec.latent_size
         self.use_tanh = bool(spec.use_tanh)
         for l in range(spec.n_layers):
             lin = nn.Linear(spec.in_dim[l], spec.out_dim[l])
@@ -44,6 +46,8 @@ class StockDecoder(nn.Module):
         for l in range(self.n_lin):
             if self.skip[l]:
                 x = torch.cat([x, input], 1)
+            elif self.xyz_in[l]:                  # xyz_in_all (latent_dropout is the identity in eval mode)
+                x = torch.cat([x, input[:, self.L:]], 1)
             x = getattr(self, f"lin{l}")(x)
             if l < self.n_lin - 1:
                 x = torch.relu(x)

@@ -28,17 +28,13 @@ class ParamInfo:
 
 
 class NetSpec:
-    """Validated architecture.  Variants the HIP path does not implement raise NotImplementedError here --
-    there is no silent fallback."""
+    """Validated architecture.  The one variant the HIP path does not implement (LayerNorm: norm_layers without
+    weight_norm) raises NotImplementedError here -- there is no silent fallback."""
 
     def __init__(self, latent_size, dims, geom_dimension, dropout=None, dropout_prob=0.0, norm_layers=(),
                  latent_in=(), weight_norm=False, xyz_in_all=None, use_tanh=False, latent_dropout=False, forward_bf16=False):
         """forward_bf16 (not a reference key; BASELINE config 5): hidden-layer forward GEMMs on bf16 MFMA with fp32
         accumulation; backward, master weights and Adam stay fp32."""
-        if xyz_in_all:
-            raise NotImplementedError("xyz_in_all=True is not implemented by the HIP decoder (no shipped spec uses it)")
-        if latent_dropout:
-            raise NotImplementedError("latent_dropout=True is not implemented by the HIP decoder (no shipped spec uses it)")
         norm_layers = tuple(norm_layers or ())
         latent_in = tuple(latent_in or ())
         if (not weight_norm) and len(norm_layers) > 0:
@@ -53,6 +49,11 @@ class NetSpec:
         self.weight_norm = bool(weight_norm)
         self.use_tanh = bool(use_tanh)
         self.forward_bf16 = bool(forward_bf16)
+        # variants no shipped spec uses; they run on the layer-by-layer kernels (general mode), never with forward_bf16
+        self.xyz_in_all = bool(xyz_in_all)
+        self.latent_dropout = bool(latent_dropout)
+        if (self.xyz_in_all or self.latent_dropout) and self.forward_bf16:
+            raise NotImplementedError("forward_bf16 is not available with xyz_in_all / latent_dropout")
         d = [self.latent_size + self.geom_dimension] + self.dims + [1]
         self.n_layers = len(d) - 1
         if self.n_layers > _lib.MAX_LAYERS:
@@ -60,7 +61,10 @@ class NetSpec:
         self.in_dim, self.out_dim = [], []
         for l in range(self.n_layers):
             self.in_dim.append(d[l])
-            self.out_dim.append(d[l + 1] - d[0] if (l + 1) in latent_in else d[l + 1])
+            if (l + 1) in latent_in:
+                self.out_dim.append(d[l + 1] - d[0])
+            else:     # deep_sdf_decoder.py:45-48: xyz_in_all narrows every hidden Linear that is not followed by the skip concat
+                self.out_dim.append(d[l + 1] - (self.geom_dimension if self.xyz_in_all and l != self.n_layers - 1 else 0))
         self.wn = [bool(weight_norm and l in norm_layers) for l in range(self.n_layers)]
         self.skip = [l in latent_in for l in range(self.n_layers)]
         self.drop = [bool(self.dropout is not None and l in self.dropout and l < self.n_layers - 1)
@@ -85,7 +89,8 @@ class NetSpec:
     def kwargs(self):
         return dict(dims=self.dims, geom_dimension=self.geom_dimension, dropout=self.dropout,
                     dropout_prob=self.dropout_prob, norm_layers=self.norm_layers, latent_in=self.latent_in,
-                    weight_norm=self.weight_norm, use_tanh=self.use_tanh, forward_bf16=self.forward_bf16)
+                    weight_norm=self.weight_norm, use_tanh=self.use_tanh, forward_bf16=self.forward_bf16,
+                    xyz_in_all=self.xyz_in_all, latent_dropout=self.latent_dropout)
 
     def c_struct(self) -> "_lib.DsdfNet":
         n = _lib.DsdfNet()
@@ -103,6 +108,8 @@ class NetSpec:
         n.dropout_p = self.dropout_prob
         n.fwd_bf16 = int(self.forward_bf16)
         n.use_tanh = int(self.use_tanh)
+        n.latent_dropout = int(self.latent_dropout)
+        n.xyz_in_all = int(self.xyz_in_all)
         return n
 
     @property

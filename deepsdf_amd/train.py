@@ -241,10 +241,12 @@ class FusedTrainStep:
         self.code_bound, self.grad_clip, self.seed = code_bound, grad_clip, seed
 
     def __call__(self, scene_rows, samples_per_scene, xyz, sdf_gt, epoch, lr_decoder, lr_latent, batch_split=1,
-                 n_norm=None, under_allreduce=None):
+                 n_norm=None, under_allreduce=None, loss_out=None):
         """scene_rows [B] (rows of self.lat), xyz [B*S, G], sdf_gt [B*S]; returns nothing (loss in eng.loss).
         under_allreduce: optional callable that enqueues work independent of this step's decoder gradient (e.g. the next
-        batch's sampling); it runs exactly once per call, under the gradient all-reduce when there is one."""
+        batch's sampling); it runs exactly once per call, under the gradient all-reduce when there is one.
+        loss_out: 1-element fp32 device tensor that receives the step's loss instead of eng.loss (the trainer passes the
+        step's slot of its per-epoch loss buffer: the kernels write it in place, no copy launch per step)."""
         N = xyz.shape[0]
         n_norm = N if n_norm is None else n_norm
         uniform = 0
@@ -273,7 +275,7 @@ class FusedTrainStep:
             sc, so, xc, gc = chunks[0]
             self.eng.train_step(self.lat, self.dlat, self.lat_m, self.lat_v, sc, so, xc, gc, n_norm=n_norm,
                                 clamp_dist=self.clamp_dist, reg_coef=reg, code_bound=self.code_bound, lr_decoder=lr_decoder,
-                                lr_latent=lr_latent, training=True, seed=self.seed, seg_len=uniform)
+                                lr_latent=lr_latent, training=True, seed=self.seed, seg_len=uniform, loss_out=loss_out)
             if under_allreduce is not None:
                 under_allreduce()
             return
@@ -281,7 +283,7 @@ class FusedTrainStep:
         for ci, (sc, so, xc, gc) in enumerate(chunks):
             self.eng.train_forward_backward(self.lat, self.dlat, sc, so, xc, gc, n_norm=n_norm, clamp_dist=self.clamp_dist,
                                             reg_coef=reg, code_bound=self.code_bound, training=True, seed=self.seed,
-                                            row_offset=row0, accumulate=ci > 0, seg_len=uniform)
+                                            row_offset=row0, accumulate=ci > 0, seg_len=uniform, loss_out=loss_out)
             row0 += xc.shape[0]
         # Data parallel (train_deep_sdf.py:353 replaced): ONE sum all-reduce of the decoder-gradient
         # arena, issued asynchronously (RCCL runs it on its own stream, ordered after the finalize launch that wrote the
@@ -487,8 +489,7 @@ def main_function(experiment_directory, continue_from, batch_split):
                     nxt[0] = draw(it + 1)
 
             fused(scenes_dev, 2 * int(num_samp_per_scene / 2), xyz, sdf_gt, epoch, lr0, lr1,
-                  batch_split=batch_split, n_norm=n_norm, under_allreduce=prefetch)
-            loss_buf[it:it + 1].copy_(eng.loss)
+                  batch_split=batch_split, n_norm=n_norm, under_allreduce=prefetch, loss_out=loss_buf[it:it + 1])
         if world > 1:
             torch.distributed.all_reduce(loss_buf)           # per-rank partial losses share the global normaliser
         stats.pop(loss_log, lat_mag_log, param_mag_log)      # the PREVIOUS epoch's values (its copy finished long ago)

@@ -39,7 +39,8 @@ def decode_sdf(decoder, latent_vector, queries):
                                         or any(p.requires_grad for p in dec.parameters()))
     spec = getattr(dec, "spec", None)
     if (spec is not None and not grad and not dec.training and latent_vector.numel() == spec.latent_size and queries.is_cuda
-            and not spec.forward_bf16 and spec.geom_dimension <= 4 and max(spec.dims) <= 512 and len(spec.dims) >= 2):
+            and spec.geom_dimension <= 4 and max(spec.dims) <= 512 and len(spec.dims) >= 2
+            and not spec.xyz_in_all and not spec.latent_dropout):
         eng = dec._engine_for(queries.device)
         eng.weights_dirty = True   # parameters may have been changed by any optimizer since the last call
         return eng.decode_latent(latent_vector, queries)

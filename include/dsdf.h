@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define DSDF_MAX_LAYERS 16
-#define DSDF_ABI_VERSION 9
+#define DSDF_ABI_VERSION 10
 
 enum {
   DSDF_OK = 0,
@@ -53,6 +53,11 @@ typedef struct DsdfNet {
   int32_t fwd_bf16;                 /* BASELINE config 5: hidden-layer forward GEMMs take bf16 inputs (weights and layer inputs
                                        rounded to nearest-even), fp32 accumulate on v_mfma_f32_32x32x16_bf16; the output layer,
                                        the backward pass, master weights and Adam stay fp32.  Needs every width <= 512. */
+  /* Decoder variants no shipped spec uses (layer-by-layer kernels, general mode; not with fwd_bf16): */
+  int32_t latent_dropout;           /* deep_sdf_decoder.py:79-82: in training, layer 0 sees F.dropout(latent, 0.2) (the skip layer
+                                       still concatenates the original input); mask = the dropout hash under dropout_key[15] */
+  int32_t xyz_in_all;               /* :90-91: every layer l >= 1 that is not a latent_in layer takes [x || xyz]
+                                       (in_dim[l] = out_dim[l-1] + geom_dim) */
 } DsdfNet;
 
 /* Offsets (in floats) of every parameter tensor inside the decoder arena, named_parameters() order:
@@ -133,7 +138,9 @@ int dsdf_module_forward(const DsdfNet* net, const float* packed, const float* pa
                         int64_t ld_in, int64_t n, int32_t training, const uint32_t* dropout_key /*[host]*/,
                         float* sdf_out, void* ws, size_t ws_bytes, void* stream);
 int dsdf_module_backward(const DsdfNet* net, const float* packed, const float* params, const float* d_sdf,
-                         int64_t n, int32_t training, float* grads /*arena, overwritten or accumulated*/,
+                         int64_t n, int32_t training, const uint32_t* dropout_key /*[host] the forward's keys; only
+                         latent_dropout nets read it (slot 15), may be NULL otherwise*/,
+                         float* grads /*arena, overwritten or accumulated*/,
                          int32_t accumulate, float* d_input /*[n, ld_din] or NULL*/, int64_t ld_din,
                          void* ws, size_t ws_bytes, void* stream);
 /* Forward-mode tangent (Jacobian-vector product) of Decoder.forward at the point of the LAST dsdf_module_forward on this

@@ -50,6 +50,9 @@ class Layer:
     weight_norm: bool
     skip_in: bool  # input of this layer is [x || x0]   (deep_sdf_decoder.py:88-89)
     dropout: bool  # dropout applied to this layer's activated output (deep_sdf_decoder.py:105-106)
+    xyz_in: bool = False      # input of this layer is [x || xyz]  (xyz_in_all, deep_sdf_decoder.py:90-91)
+    layer_norm: bool = False  # nn.LayerNorm(out_dim) between the Linear and the ReLU (deep_sdf_decoder.py:60-65,97-103)
+    has_ln_params: bool = False   # a bn{l} module exists (it does for every l in norm_layers, even where forward never calls it)
 
 
 @dataclass
@@ -60,6 +63,7 @@ class Net:
     dropout_prob: float
     use_tanh: bool
     forward_bf16: bool = False     # BASELINE config 5 (not a reference option): see decoder_forward
+    latent_dropout: bool = False   # F.dropout(latent, 0.2) on layer 0's input only (deep_sdf_decoder.py:79-82)
 
     @property
     def n_lin(self) -> int:
@@ -70,24 +74,28 @@ def make_net(latent_size, dims, geom_dimension, dropout=None, dropout_prob=0.0, 
              latent_in=(), weight_norm=False, xyz_in_all=None, use_tanh=False,
              latent_dropout=False, forward_bf16=False) -> Net:
     """Same constructor signature as the reference Decoder (deep_sdf_decoder.py:10-23) (+ forward_bf16, config 5)."""
-    if xyz_in_all:
-        raise NotImplementedError("xyz_in_all is False in every shipped spec; not restated")
-    if latent_dropout:
-        raise NotImplementedError("latent_dropout is False in every shipped spec; not restated")
-    if (not weight_norm) and norm_layers:
-        raise NotImplementedError("LayerNorm variant (weight_norm=False with norm_layers) not restated")
     d = [latent_size + geom_dimension] + list(dims) + [1]
     n_lin = len(d) - 1
+    norm_layers = tuple(norm_layers or ())
+    latent_in = tuple(latent_in or ())
     layers = []
     for l in range(n_lin):
-        out_dim = d[l + 1] - d[0] if (l + 1) in latent_in else d[l + 1]
+        if (l + 1) in latent_in:
+            out_dim = d[l + 1] - d[0]
+        else:
+            out_dim = d[l + 1]
+            if xyz_in_all and l != n_lin - 1:          # deep_sdf_decoder.py:45-48 (the last Linear keeps its width 1)
+                out_dim -= geom_dimension
+        ln_mod = bool((not weight_norm) and l in norm_layers)
         layers.append(Layer(
             in_dim=d[l], out_dim=out_dim,
             weight_norm=bool(weight_norm and l in norm_layers),
             skip_in=l in latent_in,
             dropout=bool(dropout is not None and l in dropout and l < n_lin - 1),
+            xyz_in=bool(xyz_in_all and l != 0 and l not in latent_in),
+            layer_norm=bool(ln_mod and l < n_lin - 1), has_ln_params=ln_mod,
         ))
-    return Net(latent_size, geom_dimension, layers, float(dropout_prob), bool(use_tanh), bool(forward_bf16))
+    return Net(latent_size, geom_dimension, layers, float(dropout_prob), bool(use_tanh), bool(forward_bf16), bool(latent_dropout))
 
 
 def param_names(net: Net) -> List[str]:
@@ -99,6 +107,8 @@ def param_names(net: Net) -> List[str]:
                       f"lin{l}.parametrizations.weight.original1"]
         else:
             names += [f"lin{l}.weight", f"lin{l}.bias"]
+        if ly.has_ln_params:
+            names += [f"bn{l}.weight", f"bn{l}.bias"]
     return names
 
 
@@ -117,6 +127,9 @@ def init_params(net: Net, seed: int, dtype=torch.float32) -> Dict[str, torch.Ten
         else:
             p[f"lin{l}.weight"] = w.to(dtype)
             p[f"lin{l}.bias"] = b.to(dtype)
+        if ly.has_ln_params:      # nn.LayerNorm starts at weight 1, bias 0; perturbed here so the tests see the affine part
+            p[f"bn{l}.weight"] = (1.0 + 0.2 * (torch.rand(ly.out_dim, generator=gen, dtype=torch.float64) - 0.5)).to(dtype)
+            p[f"bn{l}.bias"] = (0.1 * (torch.rand(ly.out_dim, generator=gen, dtype=torch.float64) - 0.5)).to(dtype)
     return p
 
 
@@ -241,19 +254,43 @@ class Saved:
     t1: Optional[torch.Tensor] = None                          # tanh(u) if use_tanh
     y: Optional[torch.Tensor] = None                           # network output [N,1]
     min_abs_pre: Optional[torch.Tensor] = None                 # [N] min |hidden pre-activation| (margin checks in tests)
+    latent_mask: Optional[torch.Tensor] = None                 # [N, L] keep mask of latent_dropout (training), else None
+    xhat: List[Optional[torch.Tensor]] = field(default_factory=list)   # per layer: LayerNorm's normalised pre-activation, or None
+    rstd: List[Optional[torch.Tensor]] = field(default_factory=list)
+
+
+LATENT_DROPOUT_P = 0.2      # nn.Dropout(0.2), deep_sdf_decoder.py:36
+LATENT_DROPOUT_LAYER = 15   # dropout_layer_key slot of the latent mask (no Linear layer can have this index: at most 16 layers)
+LN_EPS = 1e-5               # nn.LayerNorm default
+
+
+def latent_dropout_mask(net: Net, seed: int, step: int, n_rows: int, row_offset: int = 0):
+    """Keep mask [n_rows, L] of latent_dropout, from the same integer hash as the hidden-layer masks."""
+    k = dropout_layer_key(seed, step, LATENT_DROPOUT_LAYER)
+    return torch.from_numpy(dropout_keep(k, n_rows, net.latent_size, LATENT_DROPOUT_P, row_offset))
 
 
 def decoder_forward(net: Net, params, x0: torch.Tensor, training: bool = False,
-                    masks: Optional[Sequence[Optional[torch.Tensor]]] = None, track_margin: bool = False):
+                    masks: Optional[Sequence[Optional[torch.Tensor]]] = None, track_margin: bool = False,
+                    latent_mask: Optional[torch.Tensor] = None):
     """x0: [N, L+G] (latent first, coordinates last).  Returns (y [N,1], Saved)."""
     Wb = effective_weights(net, params)
     sv = Saved(x0=x0)
+    L, G = net.latent_size, net.geom_dimension
+    xyz = x0[:, L:]
     x = x0
+    if net.latent_dropout and training and L > 0:            # deep_sdf_decoder.py:79-82: layer 0 sees the dropped latent,
+        if latent_mask is None:                              # the skip layer still concatenates the ORIGINAL input
+            raise ValueError("training-mode forward with latent_dropout needs an explicit latent mask")
+        sv.latent_mask = latent_mask
+        x = torch.cat([x0[:, :L] * latent_mask.to(x0.dtype) * (1.0 / (1.0 - LATENT_DROPOUT_P)), xyz], dim=1)
     n_lin = net.n_lin
     scale = 1.0 / (1.0 - net.dropout_prob) if net.dropout_prob < 1.0 else 0.0
     for l, ly in enumerate(net.layers):
         if ly.skip_in:
             x = torch.cat([x, x0], dim=1)
+        elif ly.xyz_in:
+            x = torch.cat([x, xyz], dim=1)
         sv.inputs.append(x)
         W, b = Wb[l]
         if net.forward_bf16 and l < n_lin - 1:
@@ -263,6 +300,14 @@ def decoder_forward(net: Net, params, x0: torch.Tensor, training: bool = False,
             x = rb(x) @ rb(W).t() + b
         else:
             x = x @ W.t() + b
+        xh = rs = None
+        if ly.layer_norm:                                    # nn.LayerNorm(out_dim): biased variance, eps 1e-5, affine
+            mu = x.mean(dim=1, keepdim=True)
+            rs = torch.rsqrt(((x - mu) ** 2).mean(dim=1, keepdim=True) + LN_EPS)
+            xh = (x - mu) * rs
+            x = xh * params[f"bn{l}.weight"] + params[f"bn{l}.bias"]
+        sv.xhat.append(xh)
+        sv.rstd.append(rs)
         if l < n_lin - 1:
             if track_margin:
                 mn = x.abs().amin(dim=1)
@@ -296,11 +341,21 @@ def decoder_backward(net: Net, params, sv: Saved, dy: torch.Tensor, training: bo
     if net.use_tanh:
         d = d * (1.0 - sv.t1 * sv.t1)
     dx0 = torch.zeros_like(sv.x0)
-    dp = d  # gradient w.r.t. the linear output of the current layer
+    L = net.latent_size
+    dp = d  # gradient w.r.t. the current layer's output BEFORE the ReLU (= after LayerNorm where there is one)
     for l in range(n_lin - 1, -1, -1):
         ly = net.layers[l]
         W, _ = Wb[l]
         inp = sv.inputs[l]
+        if ly.layer_norm:                                    # LayerNorm backward: dp is d/dz, z = xhat * gamma + beta
+            xh, rs = sv.xhat[l], sv.rstd[l]
+            grads[f"bn{l}.weight"] = (dp * xh).sum(dim=0)
+            grads[f"bn{l}.bias"] = dp.sum(dim=0)
+            dxh = dp * params[f"bn{l}.weight"]
+            dp = rs * (dxh - dxh.mean(dim=1, keepdim=True) - xh * (dxh * xh).mean(dim=1, keepdim=True))
+        elif ly.has_ln_params:                               # a bn module forward never calls (the last Linear): zero gradient
+            grads[f"bn{l}.weight"] = torch.zeros_like(params[f"bn{l}.weight"])
+            grads[f"bn{l}.bias"] = torch.zeros_like(params[f"bn{l}.bias"])
         grads[f"lin{l}.bias"] = dp.sum(dim=0)
         dW = dp.t() @ inp
         if ly.weight_norm:
@@ -315,7 +370,13 @@ def decoder_backward(net: Net, params, sv: Saved, dy: torch.Tensor, training: bo
             k = ly.in_dim - sv.x0.shape[1]
             dx0 = dx0 + din[:, k:]
             din = din[:, :k]
+        elif ly.xyz_in:
+            k = ly.in_dim - net.geom_dimension
+            dx0[:, L:] = dx0[:, L:] + din[:, k:]
+            din = din[:, :k]
         if l == 0:
+            if sv.latent_mask is not None:                   # layer 0 saw the dropped latent
+                din = torch.cat([din[:, :L] * sv.latent_mask.to(din.dtype) * (1.0 / (1.0 - LATENT_DROPOUT_P)), din[:, L:]], dim=1)
             dx0 = dx0 + din
             break
         a = sv.acts[l - 1]           # output of layer l-1 after relu (+dropout)
@@ -418,7 +479,7 @@ class TrainState:
 
 
 def step_gradients(net: Net, params, latents, indices, xyz, sdf_gt, *, delta, code_bound,
-                   code_reg, code_reg_lambda, epoch, n_norm=None, training=True, masks=None):
+                   code_reg, code_reg_lambda, epoch, n_norm=None, training=True, masks=None, latent_mask=None):
     """One chunk's forward+backward.  ``indices`` [N] int64 (scene of every point).  Mutates ``latents``
     (renorm) like the reference.  Returns dict(loss, y, grads, dlat [S_tot, L], dx0)."""
     N = xyz.shape[0]
@@ -426,7 +487,7 @@ def step_gradients(net: Net, params, latents, indices, xyz, sdf_gt, *, delta, co
     renorm_rows_(latents, indices, code_bound)
     z = latents[indices]
     x0 = torch.cat([z, xyz], dim=1)
-    y, sv = decoder_forward(net, params, x0, training=training, masks=masks)
+    y, sv = decoder_forward(net, params, x0, training=training, masks=masks, latent_mask=latent_mask)
     loss, dy = clamped_l1(y, sdf_gt.reshape(-1, 1), delta, n_norm)
     grads, dx0 = decoder_backward(net, params, sv, dy, training)
     L = net.latent_size
@@ -458,9 +519,10 @@ def train_step(net: Net, st: TrainState, indices, xyz, sdf_gt, *, delta, code_bo
             masks = dropout_masks(net, seed, st.step, n, row_offset=row0)
         else:
             masks = None
+        lmask = latent_dropout_mask(net, seed, st.step, n, row_offset=row0) if (training and net.latent_dropout) else None
         r = step_gradients(net, st.params, st.latents, is_[ci], xs[ci], ts[ci], delta=delta,
                            code_bound=code_bound, code_reg=code_reg, code_reg_lambda=code_reg_lambda,
-                           epoch=epoch, n_norm=N, training=training, masks=masks)
+                           epoch=epoch, n_norm=N, training=training, masks=masks, latent_mask=lmask)
         loss += float(r["loss"])
         tot_dlat += r["dlat"]
         if tot_g is None:

@@ -102,12 +102,13 @@ def ref_step(dec, lat, opt, batches, *, delta, lam, epoch, code_reg, masks_per_c
             chunk_loss = chunk_loss + (lam * min(1, epoch / 100) * l2) / n_total
         chunk_loss.backward()
         batch_loss += chunk_loss.item()
-    grads = {k: p.grad.detach().clone() for k, p in dec.named_parameters()}
+    # (a parameter forward never touches -- the bn module of the LAST Linear in the LayerNorm variant -- has grad None)
+    grads = {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for k, p in dec.named_parameters()}
     dlat = lat.weight.grad.detach().clone()
     gn = None
     if grad_clip is not None:
         gn = torch.nn.utils.clip_grad_norm_(dec.parameters(), grad_clip)
-        grads_clipped = {k: p.grad.detach().clone() for k, p in dec.named_parameters()}
+        grads_clipped = {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for k, p in dec.named_parameters()}
     else:
         grads_clipped = None
     opt.step()
@@ -137,10 +138,11 @@ def synth_batch(gen, scenes, S, G=3):
     return torch.cat(idx), torch.cat(xyz).float(), torch.cat(gt).float()
 
 
-def margins_ok(dec_net, params, x0, gt, delta, masks=None, training=False, tol=2e-5):
+def margins_ok(dec_net, params, x0, gt, delta, masks=None, training=False, tol=2e-5, latent_mask=None):
     """Reject batches where a ReLU pre-activation or |y|-delta sits within tol of its threshold."""
     p64 = {k: v.double() for k, v in params.items()}
-    _, sv = orc.decoder_forward(dec_net, p64, x0.double(), training=training, masks=masks)
+    _, sv = orc.decoder_forward(dec_net, p64, x0.double(), training=training, masks=masks, track_margin=True,
+                                latent_mask=latent_mask)
     # clamp boundary and sign(pred - gt) flips switch a whole point's gradient: keep a hard margin there
     if ((sv.y.abs() - delta).abs() < tol).any():
         return False
@@ -150,12 +152,8 @@ def margins_ok(dec_net, params, x0, gt, delta, masks=None, training=False, tol=2
             return False
     # a ReLU flip only moves one unit of one point (forward is continuous): checked on small nets only
     n_pre = sum(ly.out_dim for ly in dec_net.layers[:-1]) * x0.shape[0]
-    if n_pre <= 50000:
-        Wb = orc.effective_weights(dec_net, p64)
-        for l in range(dec_net.n_lin - 1):
-            pre = sv.inputs[l] @ Wb[l][0].t() + Wb[l][1]
-            if (pre.abs() < 1e-6).any():
-                return False
+    if n_pre <= 50000 and sv.min_abs_pre is not None and (sv.min_abs_pre < 1e-6).any():
+        return False
     return True
 
 
@@ -186,20 +184,25 @@ def case_train(Decoder, name, *, L, net_specs, S_tot, scenes_steps, S, seed, del
             idx, xyz, gt = synth_batch(gen, scenes, S)
             chunks = list(zip(torch.chunk(idx, batch_split), torch.chunk(xyz, batch_split), torch.chunk(gt, batch_split)))
             masks_pc, row0 = None, 0
+            lat_drop = dropout_train and net.latent_dropout
             if dropout_train:
                 masks_pc = []
                 for (ci, xc, gc) in chunks:
-                    masks_pc.append(orc.dropout_masks(net, drop_seed, si, xc.shape[0], row_offset=row0))
+                    ms = orc.dropout_masks(net, drop_seed, si, xc.shape[0], row_offset=row0)
+                    if lat_drop:   # the reference's FIRST F.dropout call of a forward is the latent one (deep_sdf_decoder.py:81)
+                        ms = [orc.latent_dropout_mask(net, drop_seed, si, xc.shape[0], row_offset=row0)] + ms
+                    masks_pc.append(ms)
                     row0 += xc.shape[0]
             # margin check on the concatenated batch with the CURRENT reference params
             cur = {k: v.detach().clone() for k, v in dec.state_dict().items()}
             lat_probe = lat.weight.detach().clone()
             orc.renorm_rows_(lat_probe, idx, code_bound)
             x0 = torch.cat([lat_probe[idx], xyz], 1)
-            mm = None
+            mm, lm = None, None
             if dropout_train:  # chunk masks continue the row counter, so their concatenation is this
                 mm = orc.dropout_masks(net, drop_seed, si, xyz.shape[0], row_offset=0)
-            if margins_ok(net, cur, x0, gt, delta, masks=mm, training=dropout_train):
+                lm = orc.latent_dropout_mask(net, drop_seed, si, xyz.shape[0]) if lat_drop else None
+            if margins_ok(net, cur, x0, gt, delta, masks=mm, training=dropout_train, latent_mask=lm):
                 break
         else:
             raise RuntimeError("could not draw a batch with safe margins")
@@ -218,9 +221,10 @@ def case_train(Decoder, name, *, L, net_specs, S_tot, scenes_steps, S, seed, del
             out.update(pack(pre + "/params_after", dict(dec.state_dict())))
             st = opt.state_dict()["state"]
             names = list(dict(dec.named_parameters()).keys()) + ["latent"]
-            for i, nme in enumerate(names):
-                out.update(pack(f"{pre}/adam_m", {nme: st[i]["exp_avg"]}))
-                out.update(pack(f"{pre}/adam_v", {nme: st[i]["exp_avg_sq"]}))
+            shapes = [p_.shape for p_ in dec.parameters()] + [lat.weight.shape]
+            for i, nme in enumerate(names):   # (torch.optim.Adam keeps no state for a parameter that never had a gradient)
+                out.update(pack(f"{pre}/adam_m", {nme: st[i]["exp_avg"] if i in st else torch.zeros(shapes[i])}))
+                out.update(pack(f"{pre}/adam_v", {nme: st[i]["exp_avg_sq"] if i in st else torch.zeros(shapes[i])}))
         else:  # "slice": small tensors in full, big ones as corner + Frobenius norm
             for k, g in grads.items():
                 if g.numel() <= 4096:
@@ -496,6 +500,13 @@ def main():
     # G4: batch_split=2 (chunk boundary inside a scene: 3 scenes x 32 pts -> chunks of 48)
     case_train(Decoder, "g4_batch_split2", L=4, net_specs=wn4d, S_tot=3, scenes_steps=[[0, 1, 2]], S=32, seed=41,
                batch_split=2, dropout_train=True, drop_seed=7)
+    # G11: the Decoder variants no shipped spec uses (deep_sdf_decoder.py:79-82, 90-91, 60-65/97-103)
+    case_train(Decoder, "g11a_xyz_in_all", L=5, net_specs=dict(wn4d, xyz_in_all=True, dims=[48] * 4), S_tot=3,
+               scenes_steps=[[0, 1, 2], [1, 2, 0]], S=32, seed=111, dropout_train=True, drop_seed=21)
+    case_train(Decoder, "g11b_latent_dropout", L=6, net_specs=dict(wn4d, latent_dropout=True, dims=[40] * 4), S_tot=3,
+               scenes_steps=[[0, 1, 2], [2, 1, 0]], S=32, seed=112, dropout_train=True, drop_seed=22, batch_split=2)
+    case_train(Decoder, "g11c_layer_norm", L=4, net_specs=dict(wn4d, weight_norm=False, norm_layers=[0, 1, 2, 3, 4], dims=[56] * 4),
+               S_tot=3, scenes_steps=[[0, 1, 2], [0, 2, 1]], S=32, seed=113, dropout_train=True, drop_seed=23)
     case_lr("g5_lr_schedules")
     case_real_weights("g6_real_weights")
     case_latent_only(Decoder, "g7_latent_only", L=8, net_specs=dict(wn4, latent_in=[2]), N=96, iters=5, seed=71)
@@ -510,6 +521,17 @@ def main():
 if __name__ == "__main__":
     if "--layout-only" in sys.argv:
         case_checkpoint_layout(ref_decoder_cls(), "g9_checkpoint_layout")
+    elif "--variants-only" in sys.argv:
+        torch.set_num_threads(4)
+        D = ref_decoder_cls()
+        wn4d = dict(dims=[64] * 4, dropout=[0, 1, 2, 3], dropout_prob=0.2, norm_layers=[0, 1, 2, 3], latent_in=[2],
+                    xyz_in_all=False, use_tanh=False, latent_dropout=False, weight_norm=True, geom_dimension=3)
+        case_train(D, "g11a_xyz_in_all", L=5, net_specs=dict(wn4d, xyz_in_all=True, dims=[48] * 4), S_tot=3,
+                   scenes_steps=[[0, 1, 2], [1, 2, 0]], S=32, seed=111, dropout_train=True, drop_seed=21)
+        case_train(D, "g11b_latent_dropout", L=6, net_specs=dict(wn4d, latent_dropout=True, dims=[40] * 4), S_tot=3,
+                   scenes_steps=[[0, 1, 2], [2, 1, 0]], S=32, seed=112, dropout_train=True, drop_seed=22, batch_split=2)
+        case_train(D, "g11c_layer_norm", L=4, net_specs=dict(wn4d, weight_norm=False, norm_layers=[0, 1, 2, 3, 4], dims=[56] * 4),
+                   S_tot=3, scenes_steps=[[0, 1, 2], [0, 2, 1]], S=32, seed=113, dropout_train=True, drop_seed=23)
     elif "--reference-trainer-only" in sys.argv:      # the two cases that import the reference's train_deep_sdf.py
         torch.set_num_threads(4)                      # as main(): the run is bit-reproducible for a fixed thread count
         case_lr("g5_lr_schedules")

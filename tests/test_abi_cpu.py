@@ -51,9 +51,15 @@ def test_layout_and_sizes(lib):
 def test_invalid_nets_rejected(lib):
     from deepsdf_amd.net import NetSpec
     with pytest.raises(NotImplementedError):
-        NetSpec(4, [32] * 2, 3, xyz_in_all=True)
-    with pytest.raises(NotImplementedError):
         NetSpec(4, [32] * 2, 3, norm_layers=[0], weight_norm=False)
+    with pytest.raises(NotImplementedError):
+        NetSpec(4, [32] * 2, 3, xyz_in_all=True, forward_bf16=True)
+    x = NetSpec(4, [32] * 3, 3, xyz_in_all=True, latent_in=[2])           # deep_sdf_decoder.py:42-48 layer arithmetic
+    assert x.out_dim == [29, 25, 29, 1] and x.in_dim == [7, 32, 32, 32]
+    bad = x.c_struct()
+    bad.xyz_in_all = 0                                                    # widths no longer add up without the xyz columns
+    b0 = C.c_size_t()
+    assert lib.dsdf_workspace_bytes(C.byref(bad), 8, 1, C.byref(b0)) == -1 and b"in_dim" in lib.dsdf_last_error()
     spec = NetSpec(4, [32, 32, 32], 3, latent_in=[1, 2])
     b = C.c_size_t()
     net = spec.c_struct()

@@ -316,3 +316,47 @@ def test_decoder_jvp_vs_oracle(name):
     assert rel_err(xg.grad.cpu(), dx0) <= GRAD_TOL
     for pname, p in dec.named_parameters():
         assert rel_err(p.grad.cpu(), go[pname].reshape(p.shape)) <= GRAD_TOL, pname
+
+
+@pytest.mark.parametrize("name", ["g11a_xyz_in_all", "g11b_latent_dropout"])
+def test_decoder_variants_module_path_vs_oracle(name):
+    """xyz_in_all / latent_dropout through the nn.Module seam (Decoder.forward + autograd) against the oracle: eval and train
+    forward, parameter gradients, and d/d(input) -- which for xyz_in_all collects a d/d(xyz) term from EVERY layer and for
+    latent_dropout passes the latent part of layer 0's gradient through the forward's mask."""
+    from deepsdf_amd.decoder import Decoder
+    g = Golden(name)
+    m = g.meta
+    L = m["L"]
+    net = orc.make_net(L, **m["net_specs"])
+    params = g.group("params0")
+    p64 = {k: v.double() for k, v in params.items()}
+    dec = Decoder(L, **m["net_specs"]).cuda()
+    dec.load_state_dict(params)
+    gen = torch.Generator().manual_seed(5)
+    N = 150
+    x = torch.cat([torch.randn(N, L, generator=gen) * 0.3, torch.rand(N, 3, generator=gen) * 2 - 1], 1)
+    dy = torch.randn(N, 1, generator=gen)
+    for training in (False, True):
+        dec.train(training)
+        xg = x.cuda().requires_grad_(True)
+        for p in dec.parameters():
+            p.grad = None
+        y = dec(xg)
+        masks = orc.dropout_masks(net, dec.dropout_seed, dec._fwd_calls, N) if training else None
+        lmask = orc.latent_dropout_mask(net, dec.dropout_seed, dec._fwd_calls, N) if (training and net.latent_dropout) else None
+        yo, sv = orc.decoder_forward(net, p64, x.double(), training=training, masks=masks, latent_mask=lmask)
+        assert rel_err(y.detach().cpu(), yo) <= FWD_TOL, training
+        y.backward(dy.cuda())
+        go, dx0 = orc.decoder_backward(net, p64, sv, dy.double(), training)
+        for pname, p in dec.named_parameters():
+            assert rel_err(p.grad.cpu(), go[pname].reshape(p.shape)) <= GRAD_TOL, (training, pname)
+        assert rel_err(xg.grad.cpu()[:, :L], dx0[:, :L]) <= GRAD_TOL, training
+        assert rel_err(xg.grad.cpu()[:, L:], dx0[:, L:]) <= GRAD_TOL, training
+    dec.eval()
+    with torch.no_grad():
+        y2 = dec(x.cuda())
+    assert rel_err(y2.cpu(), orc.decoder_forward(net, p64, x.double(), training=False)[0]) <= FWD_TOL
+    with pytest.raises(Exception, match="not implemented for latent_dropout / xyz_in_all"):
+        dec.jvp(x.cuda(), x.cuda())
+    # export twin (eval) agrees too
+    assert rel_err(dec.export_torchscript(x[:1])(x).detach(), y2.cpu()) <= 1e-5

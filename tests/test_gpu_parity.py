@@ -14,7 +14,9 @@ pytestmark = pytest.mark.gpu
 FWD_TOL, GRAD_TOL, PARAM_TOL = 1e-5, 1e-4, 1e-5
 
 TRAIN_CASES = ["g1a_tiny_full", "g1b_lastnorm_tanh", "g1c_plain_clip", "g2_8x512_slice", "g3a_dropout_tiny",
-               "g3b_dropout_8x512", "g4_batch_split2"]
+               "g3b_dropout_8x512", "g4_batch_split2",
+               # Decoder variants no shipped spec uses (deep_sdf_decoder.py:90-91, 79-82): reference-generated goldens
+               "g11a_xyz_in_all", "g11b_latent_dropout"]
 
 
 @pytest.mark.parametrize("name", TRAIN_CASES)

@@ -15,7 +15,10 @@ from tests.golden_io import GOLDEN, Golden, rel_err
 FWD_TOL, GRAD_TOL, PARAM_TOL = 1e-5, 1e-4, 1e-5
 
 TRAIN_CASES = ["g1a_tiny_full", "g1b_lastnorm_tanh", "g1c_plain_clip", "g2_8x512_slice", "g3a_dropout_tiny",
-               "g3b_dropout_8x512", "g4_batch_split2"]
+               "g3b_dropout_8x512", "g4_batch_split2",
+               # the Decoder variants no shipped spec uses: xyz_in_all, latent_dropout (+ batch_split 2), LayerNorm (incl. the
+               # bn module of the last Linear, which forward never calls: zero gradient, no Adam movement)
+               "g11a_xyz_in_all", "g11b_latent_dropout", "g11c_layer_norm"]
 
 
 def run_case(name):
