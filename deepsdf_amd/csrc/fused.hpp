@@ -122,7 +122,7 @@ constexpr int FLDH = 520;        // slab row stride in bf16 elements (bf16 forwa
 
 // HS: the slab holds bf16 (row stride FLDH) instead of fp32 (row stride FLD); the global activation copy stays fp32.
 template <bool DROP, bool EVEN, bool HS = false>
-__device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[2][4], float* S,
+__device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[2][4], const float (&biasv)[4], float* S,
                                                    const FusedLayer& L, int w, int fr, int fh, int row0, int N,
                                                    uint32_t row_offset) {
   const int rows_here = min(FROWS, N - row0);
@@ -138,6 +138,7 @@ __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[2][4], fl
     const bool cok = col < L.out_dim;
     const uint32_t voff = cok ? (uint32_t)((4 * fh) * ldb + col * 4) : 0x7FFFFFFFu;
     float* sp = S + (4 * fh) * FLD + col;
+    const float bv = biasv[ni];
     uint32_t mb[2] = {0u, 0u};   // this n-tile's keep bits for m = 0, 1
     uint32_t ck = 0, pm = 0;
     if constexpr (DROP) {
@@ -150,7 +151,7 @@ __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[2][4], fl
 #pragma unroll
         for (int rp = 0; rp < 8; ++rp) {
           const int rc = 32 * m + crow(2 * rp);    // compile-time local row (without the 4*fh lane term); even
-          float v0 = fmaxf(acc[m][ni][2 * rp], 0.f), v1 = fmaxf(acc[m][ni][2 * rp + 1], 0.f);   // (the bias is the accumulators' initial value)
+          float v0 = fmaxf(acc[m][ni][2 * rp] + bv, 0.f), v1 = fmaxf(acc[m][ni][2 * rp + 1] + bv, 0.f);
           if constexpr (DROP) {
             if constexpr (EVEN) {   // rows rc, rc+1 share one pair hash
               const uint32_t h = lowbias32(ck ^ (pm + (uint32_t)(rc >> 1) * 0x9E3779B1u));
@@ -357,12 +358,12 @@ __device__ __forceinline__ void fused_zero_pad(float* S, int nin) {   // columns
 
 // accumulators of a hoisted layer start at  U_s[col] + <xyz[row], W[col, xyz]>  (all operands staged in LDS)
 __device__ __forceinline__ void fused_hoist_init(f32x16 (&acc)[2][4], const float* hu, const float4* hwx, const float4* xs,
-                                                 const float (&biasv)[4], int out_dim, int w, int fr, int fh) {
+                                                 int out_dim, int w, int fr, int fh) {
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {   // one n-tile at a time (few live registers); the xyz rows are re-read from LDS (broadcast)
     const int col = 32 * (w + 4 * ni) + fr;
     const bool ok = col < out_dim;
-    const float ub = ok ? hu[col] + biasv[ni] : 0.f;
+    const float ub = ok ? hu[col] : 0.f;
     const float4 wq = ok ? hwx[col] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -429,8 +430,8 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
     const FusedLayer& L = p.ly[l];
     const int nu = (L.in + 15) >> 4;   // segment mode: 0 for layer 0, only the previous layer's columns for the skip layer
     f32x16 acc[2][4];
-    // the accumulators START at the bias (one add per element less in the epilogue: with fp32 MFMAs every VALU
-    // instruction is serial time)
+    // epilogue operands are fetched BEFORE the k-loop: a load issued after the epilogue's global stores would have
+    // to wait for them (vmcnt is in-order and counts stores)
     float biasv[4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
@@ -440,14 +441,14 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
     int hidx = -1;
     if (segm) hidx = l == p.seg.h[0].layer ? 0 : (l == p.seg.h[1].layer ? 1 : -1);
     if (hidx >= 0) {
-      fused_hoist_init(acc, hu[hidx], hwx[hidx], xs, biasv, L.out_dim, w, fr, fh);
+      fused_hoist_init(acc, hu[hidx], hwx[hidx], xs, L.out_dim, w, fr, fh);
     } else {
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[m][ni][r] = biasv[ni];
+          for (int r = 0; r < 16; ++r) acc[m][ni][r] = 0.f;
     }
     const FusedBView bv = fused_bview(L.wf, L.U, w, lane);
     const float* ap = S + fr * FLD + 8 * fh;
@@ -469,9 +470,9 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
     {
       const bool drop = L.drop_thr != 0u;
       const bool even = ((p.row_offset + (uint32_t)row0) & 1u) == 0u;   // 4*fh and crow(2rp) are even
-      if (!drop) fused_fwd_epilogue<false, true>(acc, S, L, w, fr, fh, row0, p.N, p.row_offset);
-      else if (even) fused_fwd_epilogue<true, true>(acc, S, L, w, fr, fh, row0, p.N, p.row_offset);
-      else fused_fwd_epilogue<true, false>(acc, S, L, w, fr, fh, row0, p.N, p.row_offset);
+      if (!drop) fused_fwd_epilogue<false, true>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+      else if (even) fused_fwd_epilogue<true, true>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+      else fused_fwd_epilogue<true, false>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
     }
     fused_zero_pad(S, L.x0_col >= 0 ? L.x0_col + p.W0 : L.out_dim);
     __syncthreads();
@@ -753,14 +754,14 @@ __device__ __forceinline__ void fused_forward_bf16_body(const FusedFwdArgs& p, f
     int hidx = -1;
     if (segm) hidx = l == p.seg.h[0].layer ? 0 : (l == p.seg.h[1].layer ? 1 : -1);
     if (hidx >= 0) {
-      fused_hoist_init(acc, hu[hidx], hwx[hidx], xs, biasv, L.out_dim, w, fr, fh);
+      fused_hoist_init(acc, hu[hidx], hwx[hidx], xs, L.out_dim, w, fr, fh);
     } else {
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[m][ni][r] = biasv[ni];
+          for (int r = 0; r < 16; ++r) acc[m][ni][r] = 0.f;
     }
     if (nu > 0) {
       bf16_kloop_dispatch(acc, SH + fr * FLDH + 8 * fh, reinterpret_cast<const __bf16*>(L.wf), L.U, w, lane, nu, nact, R);
@@ -776,13 +777,13 @@ __device__ __forceinline__ void fused_forward_bf16_body(const FusedFwdArgs& p, f
       const bool drop = L.drop_thr != 0u;
       const bool even = ((p.row_offset + (uint32_t)row0) & 1u) == 0u;
       if (last_hidden) {   // the output layer / the backward head read fp32: its input goes to the slab as fp32
-        if (!drop) fused_fwd_epilogue<false, true, false>(acc, S, L, w, fr, fh, row0, p.N, p.row_offset);
-        else if (even) fused_fwd_epilogue<true, true, false>(acc, S, L, w, fr, fh, row0, p.N, p.row_offset);
-        else fused_fwd_epilogue<true, false, false>(acc, S, L, w, fr, fh, row0, p.N, p.row_offset);
+        if (!drop) fused_fwd_epilogue<false, true, false>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+        else if (even) fused_fwd_epilogue<true, true, false>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+        else fused_fwd_epilogue<true, false, false>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
       } else {
-        if (!drop) fused_fwd_epilogue<false, true, true>(acc, S, L, w, fr, fh, row0, p.N, p.row_offset);
-        else if (even) fused_fwd_epilogue<true, true, true>(acc, S, L, w, fr, fh, row0, p.N, p.row_offset);
-        else fused_fwd_epilogue<true, false, true>(acc, S, L, w, fr, fh, row0, p.N, p.row_offset);
+        if (!drop) fused_fwd_epilogue<false, true, true>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+        else if (even) fused_fwd_epilogue<true, true, true>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+        else fused_fwd_epilogue<true, false, true>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
       }
     }
     if (!last_hidden && L.x0_col < 0) {      // zero pad [out_dim, roundup16) of the bf16 slab (the x0 loader pads its own end)
