@@ -14,12 +14,12 @@ class DsdfNet(C.Structure):
                 ("in_dim", C.c_int32 * MAX_LAYERS), ("out_dim", C.c_int32 * MAX_LAYERS),
                 ("weight_norm_mask", C.c_uint32), ("dropout_mask", C.c_uint32), ("skip_mask", C.c_uint32),
                 ("dropout_p", C.c_float), ("use_tanh", C.c_int32), ("fwd_bf16", C.c_int32),
-                ("latent_dropout", C.c_int32), ("xyz_in_all", C.c_int32)]
+                ("latent_dropout", C.c_int32), ("xyz_in_all", C.c_int32), ("ln_param_mask", C.c_uint32)]
 
 
 class DsdfParamLayout(C.Structure):
     _fields_ = [("total", C.c_int64), ("bias_off", C.c_int64 * MAX_LAYERS), ("g_off", C.c_int64 * MAX_LAYERS),
-                ("v_off", C.c_int64 * MAX_LAYERS)]
+                ("v_off", C.c_int64 * MAX_LAYERS), ("ln_w_off", C.c_int64 * MAX_LAYERS), ("ln_b_off", C.c_int64 * MAX_LAYERS)]
 
 
 class DsdfBatch(C.Structure):

@@ -85,6 +85,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 constexpr int NSPLIT_MAX = 32;     // split-K factor of the dW GEMMs
 constexpr int LAST_BLOCKS_MAX = 1024;
 constexpr int LAST_GROUPS = 16;    // second-stage partial groups of the last-layer reduction
+constexpr int LN_BLOCKS = 256;     // LayerNorm backward: fixed grid = fixed summation order of its column partials
 
 int validate(const DsdfNet* n) {
   if (!n) return fail(DSDF_E_INVALID, "net is NULL");
@@ -106,8 +107,14 @@ int validate(const DsdfNet* n) {
       if (n->in_dim[l] != expect) return fail(DSDF_E_INVALID, "layer %d: in_dim %d != %d", l, n->in_dim[l], expect);
     }
   }
-  if ((n->latent_dropout || n->xyz_in_all) && n->fwd_bf16)
-    return fail(DSDF_E_INVALID, "fwd_bf16 is not available with latent_dropout / xyz_in_all");
+  if ((n->latent_dropout || n->xyz_in_all || n->ln_param_mask) && n->fwd_bf16)
+    return fail(DSDF_E_INVALID, "fwd_bf16 is not available with latent_dropout / xyz_in_all / LayerNorm");
+  if (n->ln_param_mask) {
+    if (n->weight_norm_mask) return fail(DSDF_E_INVALID, "LayerNorm (ln_param_mask) and weight norm exclude each other");
+    if (n->ln_param_mask >> n->n_layers) return fail(DSDF_E_INVALID, "ln_param_mask names a layer >= n_layers");
+    for (int l = 0; l < n->n_layers; ++l)
+      if (((n->ln_param_mask >> l) & 1) && n->out_dim[l] > 2048) return fail(DSDF_E_INVALID, "LayerNorm width %d > 2048", n->out_dim[l]);
+  }
   if (n->in_dim[n->n_layers - 1] % 4 != 0) return fail(DSDF_E_INVALID, "last hidden width must be a multiple of 4");
   if (!(n->dropout_p >= 0.f && n->dropout_p < 1.f)) return fail(DSDF_E_INVALID, "dropout_p must be in [0,1)");
   return 0;
@@ -149,7 +156,7 @@ Packed packed_layout(const DsdfNet* n) {
 
 void param_layout(const DsdfNet* n, DsdfParamLayout* L) {
   int64_t o = 0;
-  for (int l = 0; l < DSDF_MAX_LAYERS; ++l) L->bias_off[l] = L->g_off[l] = L->v_off[l] = -1;
+  for (int l = 0; l < DSDF_MAX_LAYERS; ++l) L->bias_off[l] = L->g_off[l] = L->v_off[l] = L->ln_w_off[l] = L->ln_b_off[l] = -1;
   for (int l = 0; l < n->n_layers; ++l) {
     const int64_t out = n->out_dim[l], in = n->in_dim[l];
     if ((n->weight_norm_mask >> l) & 1) {
@@ -159,6 +166,10 @@ void param_layout(const DsdfNet* n, DsdfParamLayout* L) {
     } else {
       L->v_off[l] = o;    o += out * in;
       L->bias_off[l] = o; o += out;
+    }
+    if ((n->ln_param_mask >> l) & 1) {   // bn{l}.weight, bn{l}.bias follow lin{l}'s parameters (module registration order)
+      L->ln_w_off[l] = o; o += out;
+      L->ln_b_off[l] = o; o += out;
     }
   }
   L->total = o;
@@ -241,7 +252,8 @@ struct Plan {
   int ld_dp, ldz, ldcs, ld_part, last_blocks, nsplit, kchunk, mt;
   long long slab;
   size_t u_off, y_off, dp_off[2], dzA_off, dzB_off, slab_off, colsum_off, part_off, part2_off, partdb_off,
-      partloss_off, segpart_off, segnorm_off, gnorm_off, dxz_off[2], total;
+      partloss_off, segpart_off, segnorm_off, gnorm_off, dxz_off[2], lnpg_off, lnpb_off, total;
+  size_t lnx_off[DSDF_MAX_LAYERS], lnr_off[DSDF_MAX_LAYERS];   // LayerNorm: xhat [N][ld_in[l+1]] (the Linear's output in place), rstd [N]
   // fused backward: per hidden layer l a global dP_l buffer, the forward's mask bits and per-workgroup column sums
   size_t dpl_off[DSDF_MAX_LAYERS], mask_off[DSDF_MAX_LAYERS], cs_off[DSDF_MAX_LAYERS], dwslab_off[DSDF_MAX_LAYERS];
   int nwg;
@@ -270,6 +282,10 @@ Plan make_plan(const DsdfNet* n, int64_t N, int64_t R, bool inference, bool segm
       if (l == 0 || ((n->skip_mask >> l) & 1) || n->xyz_in_all) P.in_off[l] = take((size_t)N * P.ld_in[l] * 4);
       else P.in_off[l] = pp[l & 1];
     }
+    if (n->ln_param_mask) {   // one scratch row block for the Linear's output before LayerNorm (nothing is kept in inference)
+      const size_t t = take((size_t)N * maxw * 4);
+      for (int l = 0; l < P.nl; ++l) P.lnx_off[l] = t;
+    }
     P.total = o;
     return P;
   }
@@ -283,6 +299,8 @@ Plan make_plan(const DsdfNet* n, int64_t N, int64_t R, bool inference, bool segm
   P.dzA_off = take((size_t)N * P.ldz * 4);
   P.dzB_off = take((size_t)N * P.ldz * 4);
   for (int t = 0; t < 2; ++t) P.dxz_off[t] = n->xyz_in_all ? take((size_t)N * 4 * 4) : 0;   // [N][4]: one layer's d/d(xyz), running sum
+  for (int l = 0; l + 1 < P.nl; ++l)
+    if ((n->ln_param_mask >> l) & 1) { P.lnx_off[l] = take((size_t)N * P.ld_in[l + 1] * 4); P.lnr_off[l] = take((size_t)N * 4); }
   // split-K of the dW GEMMs: chunks of >= 256 points, at most NSPLIT_MAX slabs
   int ns = (int)((N + 255) / 256);
   if (ns > NSPLIT_MAX) ns = NSPLIT_MAX;
@@ -303,6 +321,7 @@ Plan make_plan(const DsdfNet* n, int64_t N, int64_t R, bool inference, bool segm
   P.mt = (int)((N + BM - 1) / BM);
   P.ldcs = (int)rup(maxout, 4);
   P.colsum_off = take((size_t)P.mt * P.ldcs * 4);
+  if (n->ln_param_mask) { P.lnpg_off = take((size_t)LN_BLOCKS * P.ldcs * 4); P.lnpb_off = take((size_t)LN_BLOCKS * P.ldcs * 4); }
   P.last_blocks = (int)((N + 15) / 16);
   if (P.last_blocks > LAST_BLOCKS_MAX) P.last_blocks = LAST_BLOCKS_MAX;
   if (P.last_blocks < 1) P.last_blocks = 1;
@@ -432,7 +451,9 @@ int materialize(const DsdfNet* net, const float* params, float* packed, hipStrea
 constexpr float LATENT_DROPOUT_P = 0.2f;          // nn.Dropout(0.2), deep_sdf_decoder.py:36
 constexpr int LATENT_DROPOUT_KEY = DSDF_MAX_LAYERS - 1;   // slot of dropout_key[] (no hidden layer can have this index)
 inline uint32_t latent_drop_thr() { return (uint32_t)lround((double)LATENT_DROPOUT_P * 65536.0); }
-inline bool net_variant(const DsdfNet* n) { return n->latent_dropout || n->xyz_in_all; }
+inline bool net_variant(const DsdfNet* n) { return n->latent_dropout || n->xyz_in_all || n->ln_param_mask != 0; }
+inline bool ln_applied(const DsdfNet* n, int l) { return ((n->ln_param_mask >> l) & 1) && l < n->n_layers - 1; }   // hidden layers only
+
 
 // x0 (+ skip copies, + the xyz columns of every layer of an xyz_in_all net) from either the latent table + segments or an
 // explicit input; keys != nullptr && training: latent_dropout nets drop layer 0's latent columns on the way
@@ -567,9 +588,10 @@ int run_fused_forward(const DsdfNet* net, const Plan& P, void* ws, const float* 
   return 0;
 }
 
-// hidden layers 0..nl-2: in[l+1][:, :out_l] = dropout(relu(in[l] W_l^T + b_l))
+// hidden layers 0..nl-2: in[l+1][:, :out_l] = dropout(relu(in[l] W_l^T + b_l)); LayerNorm layers: Linear (bias) into the xhat
+// buffer, then ln_fwd_kernel normalises in place (kept for the backward when save_ln) and writes the activated output
 int run_hidden_forward(const DsdfNet* net, const Plan& P, void* ws, const float* packed, const float* params, int64_t n,
-                       int training, const uint32_t* keys, uint32_t row_offset, hipStream_t st) {
+                       int training, const uint32_t* keys, uint32_t row_offset, hipStream_t st, bool save_ln = true) {
   DsdfParamLayout L;
   param_layout(net, &L);
   const Packed pk = packed_layout(net);
@@ -583,10 +605,27 @@ int run_hidden_forward(const DsdfNet* net, const Plan& P, void* ws, const float*
     a.bias = params + L.bias_off[l];
     a.relu = 1;
     const bool drop = training && ((net->dropout_mask >> l) & 1) && net->dropout_p > 0.f;
+    uint32_t thr = 0;
     if (drop) {
-      long thr = lround((double)net->dropout_p * 65536.0);
-      if (thr > 65535) thr = 65535;
-      a.drop_thr = (uint32_t)thr;
+      long t = lround((double)net->dropout_p * 65536.0);
+      if (t > 65535) t = 65535;
+      thr = (uint32_t)t;
+    }
+    if (ln_applied(net, l)) {
+      a.C = at<float>(ws, P.lnx_off[l]);
+      TRY(launch_nt<EPI_PLAIN>(a, st));
+      LnFwdArgs f;
+      memset(&f, 0, sizeof(f));
+      f.y = a.C; f.ldy = a.ldc; f.gamma = params + L.ln_w_off[l]; f.beta = params + L.ln_b_off[l];
+      f.out = at<float>(ws, P.in_off[l + 1]); f.ldo = P.ld_in[l + 1]; f.n = (int)n; f.width = net->out_dim[l];
+      f.save = save_ln ? 1 : 0; f.rstd = save_ln ? at<float>(ws, P.lnr_off[l]) : nullptr;
+      if (drop) { f.drop_thr = thr; f.drop_key = keys[l]; f.drop_scale = 1.0f / (1.0f - net->dropout_p); f.row_offset = row_offset; }
+      hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, f);
+      LAUNCH_OK("ln_fwd_kernel");
+      continue;
+    }
+    if (drop) {
+      a.drop_thr = thr;
       a.drop_key = keys[l];
       a.drop_scale = 1.0f / (1.0f - net->dropout_p);
       a.row_offset = row_offset;
@@ -632,11 +671,42 @@ int run_backward(const DsdfNet* net, const Plan& P, void* ws, const float* packe
     f.out = 1; f.in = net->in_dim[last]; f.accumulate = accumulate;
     hipLaunchKernelGGL(finalize_layer_kernel, dim3(1), dim3(256), 0, st, f);
     LAUNCH_OK("finalize_layer_kernel(last)");
+    if ((net->ln_param_mask >> last) & 1) {   // bn module of the last Linear: created by the reference, never called: zero gradient
+      LnGradArgs z;
+      memset(&z, 0, sizeof(z));
+      z.dgamma = grads + L.ln_w_off[last]; z.dbeta = grads + L.ln_b_off[last]; z.width = net->out_dim[last]; z.accumulate = accumulate; z.zero = 1;
+      hipLaunchKernelGGL(ln_param_grad_kernel, dim3(1), dim3(64), 0, st, z);
+      LAUNCH_OK("ln_param_grad_kernel(last)");
+    }
   }
   *used_dzB = false;
   int cur = 0;
   for (int l = last - 1; l >= 0; --l) {
     float* dp = at<float>(ws, P.dp_off[cur]);
+    // column-sum partials of dp as it arrives (from the output layer's kernel or the next layer's dX epilogue)
+    const float* cs_ptr = l == last - 1 ? at<float>(ws, P.part2_off) + P.ld_in[last] : at<float>(ws, P.colsum_off);
+    int cs_n = l == last - 1 ? LAST_GROUPS : P.mt, cs_ld = l == last - 1 ? P.ld_part : P.ldcs;
+    const bool ln = ln_applied(net, l);
+    if (ln) {   // dp is d/dz (after LayerNorm): turn it into d/d(Linear output) in place; gamma / beta / bias partials
+      LnBwdArgs b;
+      memset(&b, 0, sizeof(b));
+      b.dz = dp; b.ldz = P.ld_dp; b.xhat = at<float>(ws, P.lnx_off[l]); b.ldx = P.ld_in[l + 1]; b.rstd = at<float>(ws, P.lnr_off[l]);
+      b.gamma = params + L.ln_w_off[l]; b.n = (int)n; b.width = net->out_dim[l];
+      b.part_dgamma = at<float>(ws, P.lnpg_off); b.part_db = at<float>(ws, P.lnpb_off); b.ldp = P.ldcs;
+      int blocks = (int)((n + 3) / 4);
+      if (blocks > LN_BLOCKS) blocks = LN_BLOCKS;
+      hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, st, b);
+      LAUNCH_OK("ln_bwd_kernel");
+      if (want_dw) {
+        LnGradArgs g;
+        memset(&g, 0, sizeof(g));
+        g.part_dgamma = b.part_dgamma; g.nblk = blocks; g.ldp = b.ldp; g.cs = cs_ptr; g.ncs = cs_n; g.ldcs = cs_ld;
+        g.dgamma = grads + L.ln_w_off[l]; g.dbeta = grads + L.ln_b_off[l]; g.width = net->out_dim[l]; g.accumulate = accumulate;
+        hipLaunchKernelGGL(ln_param_grad_kernel, dim3((g.width + 255) / 256), dim3(256), 0, st, g);
+        LAUNCH_OK("ln_param_grad_kernel");
+      }
+      cs_ptr = b.part_db; cs_n = blocks; cs_ld = b.ldp;     // the Linear's bias gradient = column sums of dy
+    }
     // dW_l = dp^T in_l  (split-K slabs)
     if (want_dw) {
     TnArgs t;
@@ -648,8 +718,7 @@ int run_backward(const DsdfNet* net, const Plan& P, void* ws, const float* packe
     FinArgs f;
     memset(&f, 0, sizeof(f));
     f.slabs = t.C; f.nsplit = P.nsplit; f.slab = P.slab; f.ldc = t.ldc;
-    if (l == last - 1) { f.colsum = at<float>(ws, P.part2_off) + P.ld_in[last]; f.npart = LAST_GROUPS; f.ldcs = P.ld_part; }
-    else { f.colsum = at<float>(ws, P.colsum_off); f.npart = P.mt; f.ldcs = P.ldcs; }
+    f.colsum = cs_ptr; f.npart = cs_n; f.ldcs = cs_ld;
     f.g = L.g_off[l] >= 0 ? params + L.g_off[l] : nullptr;
     f.v = params + L.v_off[l];
     f.dg = L.g_off[l] >= 0 ? grads + L.g_off[l] : nullptr;
@@ -973,7 +1042,7 @@ int dsdf_decode(const DsdfNet* net, const float* packed, const float* params, co
   TRY(run_gather(net, P, ws, nullptr, nullptr, input, ld_in, n, st));
   if (fused_enabled() && fused_eligible(net))
     return run_fused_forward(net, P, ws, packed, params, n, 0, nullptr, 0, false, sdf_out, nullptr, st);
-  TRY(run_hidden_forward(net, P, ws, packed, params, n, 0, nullptr, 0, st));
+  TRY(run_hidden_forward(net, P, ws, packed, params, n, 0, nullptr, 0, st, false));
   DsdfParamLayout L;
   param_layout(net, &L);
   const Packed pk = packed_layout(net);
@@ -1115,7 +1184,7 @@ int dsdf_module_jvp(const DsdfNet* net, const float* packed, const float* params
   TRY(check_common(net, packed, params, ws));
   if (n == 0) return 0;
   if (!tangent || !jvp_out || n < 0 || ld_t < net->in_dim[0]) return fail(DSDF_E_INVALID, "bad tangent/jvp_out/ld_t");
-  if (net_variant(net)) return fail(DSDF_E_INVALID, "dsdf_module_jvp is not implemented for latent_dropout / xyz_in_all nets");
+  if (net_variant(net)) return fail(DSDF_E_INVALID, "dsdf_module_jvp is not implemented for latent_dropout / xyz_in_all / LayerNorm nets");
   const Plan P = make_plan(net, n, 0, false);
   if (ws_bytes < P.total) return fail(DSDF_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, P.total);
   hipStream_t st = (hipStream_t)stream;
@@ -1343,6 +1412,10 @@ int dsdf_adam_step(const DsdfNet* net, float* params, const float* grads, float*
     a.total_rows = rows;
     hipLaunchKernelGGL(adam_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a);
     LAUNCH_OK("adam_rows_kernel");
+    for (int l = 0; l < net->n_layers; ++l)     // LayerNorm variant: bn{l}.weight | bn{l}.bias are adjacent in the arena
+      if (L.ln_w_off[l] >= 0)
+        TRY(adam_launch(params + L.ln_w_off[l], grads + L.ln_w_off[l], exp_avg + L.ln_w_off[l], exp_avg_sq + L.ln_w_off[l],
+                        2 * (int64_t)net->out_dim[l], cfg->lr_decoder, cfg, cfg->grad_scale, st));
   }
   if (n_latent_floats > 0) {
     if (!latent_table || !dlat || !lat_exp_avg || !lat_exp_avg_sq) return fail(DSDF_E_INVALID, "NULL latent argument");

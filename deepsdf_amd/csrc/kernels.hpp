@@ -916,6 +916,94 @@ __global__ void jvp_tail_kernel(const float* du, const float* u, float* out, int
   out[i] = d;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm variant (deep_sdf_decoder.py:60-65, 97-103: norm_layers WITHOUT weight_norm): nn.LayerNorm(out_dim) between a hidden
+// Linear and its ReLU.  Layer-by-layer path only.  One wave per row; biased variance, eps 1e-5, affine (bn{l}.weight / .bias).
+//   forward:  y = Linear(x) (gemm_nt, bias) -> xhat = (y - mean) rstd ; z = xhat gamma + beta ; a = dropout(relu(z))
+//             xhat replaces y in place and rstd is kept when `save` (training / module path)
+//   backward: dz (= d/da masked by [a > 0] * scale, from the next layer's dX epilogue) -> in place
+//             dy = rstd (dz gamma - mean(dz gamma) - xhat mean(dz gamma xhat))       (gradient w.r.t. the Linear's output)
+//             + per-block column partials of  sum_n dz xhat  (= d gamma)  and  sum_n dy  (= the Linear's bias gradient);
+//             d beta = sum_n dz are the column sums the dX epilogue / the output layer already produced.
+constexpr float LN_EPS = 1e-5f;
+constexpr int LN_MAXW = 2048;
+struct LnFwdArgs {
+  float* y; int ldy; const float* gamma; const float* beta; float* out; int ldo; int n; int width;
+  float* rstd; int save;
+  uint32_t drop_key, drop_thr; float drop_scale; uint32_t row_offset;
+};
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.n) return;
+  float* y = p.y + (size_t)row * p.ldy;
+  float s = 0.f;
+  for (int c = lane; c < p.width; c += 64) s += y[c];
+  const float mean = wave_sum(s) / (float)p.width;
+  float q = 0.f;
+  for (int c = lane; c < p.width; c += 64) { const float d = y[c] - mean; q += d * d; }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)p.width + LN_EPS);
+  const uint32_t g = p.row_offset + (uint32_t)row;
+  for (int c = lane; c < p.width; c += 64) {
+    const float xh = (y[c] - mean) * rstd;
+    float a = fmaxf(fmaf(xh, p.gamma[c], p.beta[c]), 0.f);
+    if (p.drop_thr != 0u) a = drop_keep(drop_pair_hash(drop_col_key((uint32_t)c, p.drop_key), g), g, p.drop_thr) ? a * p.drop_scale : 0.f;
+    p.out[(size_t)row * p.ldo + c] = a;
+    if (p.save) y[c] = xh;
+  }
+  if (p.save && lane == 0) p.rstd[row] = rstd;
+}
+
+struct LnBwdArgs {
+  float* dz; int ldz; const float* xhat; int ldx; const float* rstd; const float* gamma; int n; int width;
+  float* part_dgamma; float* part_db; int ldp;    // [gridDim.x][ldp]
+};
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
+  __shared__ float acc_g[4][LN_MAXW];
+  __shared__ float acc_b[4][LN_MAXW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = lane; c < p.width; c += 64) { acc_g[wave][c] = 0.f; acc_b[wave][c] = 0.f; }
+  for (int row = blockIdx.x * 4 + wave; row < p.n; row += gridDim.x * 4) {   // fixed grid: fixed summation order
+    float* dz = p.dz + (size_t)row * p.ldz;
+    const float* xh = p.xhat + (size_t)row * p.ldx;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < p.width; c += 64) { const float d = dz[c] * p.gamma[c]; s1 += d; s2 += d * xh[c]; }
+    s1 = wave_sum(s1) / (float)p.width;
+    s2 = wave_sum(s2) / (float)p.width;
+    const float rs = p.rstd[row];
+    for (int c = lane; c < p.width; c += 64) {
+      const float z = dz[c], x = xh[c];
+      const float dy = rs * (z * p.gamma[c] - s1 - x * s2);
+      acc_g[wave][c] += z * x;
+      acc_b[wave][c] += dy;
+      dz[c] = dy;
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < p.width; c += 256) {
+    p.part_dgamma[(size_t)blockIdx.x * p.ldp + c] = (acc_g[0][c] + acc_g[1][c]) + (acc_g[2][c] + acc_g[3][c]);
+    p.part_db[(size_t)blockIdx.x * p.ldp + c] = (acc_b[0][c] + acc_b[1][c]) + (acc_b[2][c] + acc_b[3][c]);
+  }
+}
+
+// d gamma[c] = sum of ln_bwd's block partials; d beta[c] = sum of the column-sum partials of dz (cs, ncs rows of ldcs);
+// zero != 0: a bn module forward never calls (the LAST Linear's, :60-65 creates it anyway): zero gradient
+struct LnGradArgs {
+  const float* part_dgamma; int nblk; int ldp; const float* cs; int ncs; int ldcs;
+  float* dgamma; float* dbeta; int width; int accumulate; int zero;
+};
+__global__ void ln_param_grad_kernel(const LnGradArgs p) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= p.width) return;
+  float g = 0.f, b = 0.f;
+  if (!p.zero) {
+    for (int k = 0; k < p.nblk; ++k) g += p.part_dgamma[(size_t)k * p.ldp + c];
+    for (int k = 0; k < p.ncs; ++k) b += p.cs[(size_t)k * p.ldcs + c];
+  }
+  p.dgamma[c] = p.accumulate ? p.dgamma[c] + g : g;
+  p.dbeta[c] = p.accumulate ? p.dbeta[c] + b : b;
+}
+
 __global__ void dropout_mask_kernel(uint32_t key, uint32_t thr, int rows, int cols, uint32_t row_offset, uint8_t* out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)rows * cols) return;

@@ -6,9 +6,8 @@ Same constructor, same ``.geom_dimension`` attribute, same ``forward(input[N, L+
 so checkpoints move freely between this class and the reference class.  All parameters are views of ONE flat fp32
 arena (the layout the HIP kernels and the fused Adam use); gradients land in a second arena.
 
-There is no CPU fallback: ``forward`` on a non-CUDA tensor raises.  ``xyz_in_all`` and ``latent_dropout`` (used by no shipped
-spec) run on the layer-by-layer kernels; the LayerNorm variant (norm_layers without weight_norm) raises NotImplementedError
-at construction.
+There is no CPU fallback: ``forward`` on a non-CUDA tensor raises.  ``xyz_in_all``, ``latent_dropout`` and the LayerNorm
+variant (norm_layers without weight_norm: modules ``bn{i}``) -- used by no shipped spec -- run on the layer-by-layer kernels.
 """
 import torch
 import torch.nn as nn
@@ -42,6 +41,15 @@ def _check_token(dec, token, what):
     if token != dec._fwd_calls:
         raise RuntimeError(f"deepsdf_amd.Decoder: {what} after a newer forward(): activations live in one "
                            "workspace per module; call it before the next forward")
+
+
+class _LayerNormParams(nn.Module):
+    """Holds bn{l}.weight / bn{l}.bias (the reference's nn.LayerNorm(out_dim), deep_sdf_decoder.py:60-65)."""
+
+    def __init__(self):
+        super().__init__()
+        self.register_parameter("weight", None)
+        self.register_parameter("bias", None)
 
 
 class _DecoderBwdFn(torch.autograd.Function):
@@ -124,6 +132,8 @@ class Decoder(nn.Module):
         self._engine = None
         for l in range(s.n_layers):
             setattr(self, f"lin{l}", _Linear(s.wn[l]))
+            if s.ln[l]:
+                setattr(self, f"bn{l}", _LayerNormParams())
         arena = torch.zeros(s.n_params, dtype=torch.float32)
         self._bind(arena)
         self._init_parameters()
@@ -135,6 +145,8 @@ class Decoder(nn.Module):
             return lin.parametrizations["weight"], "original0"
         if p.kind == "v":
             return lin.parametrizations["weight"], "original1"
+        if p.kind in ("ln_w", "ln_b"):
+            return getattr(self, f"bn{p.layer}"), "weight" if p.kind == "ln_w" else "bias"
         return lin, p.kind
 
     def _bind(self, arena):
@@ -162,7 +174,8 @@ class Decoder(nn.Module):
                 b = torch.empty(o).uniform_(-1 / math.sqrt(i), 1 / math.sqrt(i))
                 for p in self.spec.params:
                     if p.layer == l:
-                        src = {"bias": b, "v": w, "weight": w, "g": w.norm(dim=1, keepdim=True)}[p.kind]
+                        src = {"bias": b, "v": w, "weight": w, "g": w.norm(dim=1, keepdim=True), "ln_w": torch.ones(o),
+                               "ln_b": torch.zeros(o)}[p.kind]                     # nn.LayerNorm: weight 1, bias 0
                         self._arena[p.offset:p.offset + p.numel].view(p.shape).copy_(src)
 
     def _apply(self, fn, recurse=True):

@@ -38,7 +38,8 @@ class Engine:
         if lay.total != spec.n_params:
             raise _lib.DsdfError(f"param layout mismatch: C {lay.total} vs host {spec.n_params}")
         for p in spec.params:
-            off = {"bias": lay.bias_off, "g": lay.g_off, "v": lay.v_off, "weight": lay.v_off}[p.kind][p.layer]
+            off = {"bias": lay.bias_off, "g": lay.g_off, "v": lay.v_off, "weight": lay.v_off, "ln_w": lay.ln_w_off,
+                   "ln_b": lay.ln_b_off}[p.kind][p.layer]
             if off != p.offset:
                 raise _lib.DsdfError(f"param layout mismatch at {p.name}: C {off} vs host {p.offset}")
         n = C.c_int64()
@@ -89,7 +90,8 @@ class Engine:
             for p in self.spec.params:
                 if p.layer != l:
                     continue
-                src = {"bias": b, "v": w, "weight": w, "g": w.norm(dim=1, keepdim=True)}[p.kind]
+                src = {"bias": b, "v": w, "weight": w, "g": w.norm(dim=1, keepdim=True), "ln_w": torch.ones(o),
+                       "ln_b": torch.zeros(o)}[p.kind]
                 self.view(self.params, p).copy_(src.to(self.device))
         self.weights_dirty = True
 

@@ -33,6 +33,9 @@ class StockDecoder(nn.Module):
             if spec.wn[l]:
                 lin = nn.utils.parametrizations.weight_norm(lin)      # keys: parametrizations.weight.original0 / original1
             setattr(self, f"lin{l}", lin)
+            if spec.ln[l]:
+                setattr(self, f"bn{l}", nn.LayerNorm(spec.out_dim[l]))
+        self.ln = [bool(spec.ln[l] and l < spec.n_layers - 1) for l in range(spec.n_layers)]   # applied to hidden layers only
         self.th = nn.Tanh()
         super().train(False)
 
@@ -50,6 +53,8 @@ class StockDecoder(nn.Module):
                 x = torch.cat([x, input[:, self.L:]], 1)
             x = getattr(self, f"lin{l}")(x)
             if l < self.n_lin - 1:
+                if self.ln[l]:
+                    x = getattr(self, f"bn{l}")(x)
                 x = torch.relu(x)
             elif self.use_tanh:
                 x = torch.tanh(x)

@@ -17,7 +17,7 @@ class ParamInfo:
     shape: Tuple[int, ...]
     offset: int          # floats from the start of the decoder arena
     layer: int
-    kind: str            # "bias" | "g" | "v" | "weight"
+    kind: str            # "bias" | "g" | "v" | "weight" | "ln_w" | "ln_b"
 
     @property
     def numel(self):
@@ -28,8 +28,8 @@ class ParamInfo:
 
 
 class NetSpec:
-    """Validated architecture.  The one variant the HIP path does not implement (LayerNorm: norm_layers without
-    weight_norm) raises NotImplementedError here -- there is no silent fallback."""
+    """Validated architecture: every constructor variant of the reference Decoder.  xyz_in_all, latent_dropout and
+    LayerNorm (norm_layers without weight_norm) -- used by no shipped spec -- run on the layer-by-layer kernels."""
 
     def __init__(self, latent_size, dims, geom_dimension, dropout=None, dropout_prob=0.0, norm_layers=(),
                  latent_in=(), weight_norm=False, xyz_in_all=None, use_tanh=False, latent_dropout=False, forward_bf16=False):
@@ -37,8 +37,6 @@ class NetSpec:
         accumulation; backward, master weights and Adam stay fp32."""
         norm_layers = tuple(norm_layers or ())
         latent_in = tuple(latent_in or ())
-        if (not weight_norm) and len(norm_layers) > 0:
-            raise NotImplementedError("LayerNorm variant (norm_layers without weight_norm) is not implemented by the HIP decoder")
         self.latent_size = int(latent_size)
         self.geom_dimension = int(geom_dimension)
         self.dims = [int(d) for d in dims]
@@ -52,8 +50,9 @@ class NetSpec:
         # variants no shipped spec uses; they run on the layer-by-layer kernels (general mode), never with forward_bf16
         self.xyz_in_all = bool(xyz_in_all)
         self.latent_dropout = bool(latent_dropout)
-        if (self.xyz_in_all or self.latent_dropout) and self.forward_bf16:
-            raise NotImplementedError("forward_bf16 is not available with xyz_in_all / latent_dropout")
+        layer_norm = (not self.weight_norm) and len(norm_layers) > 0        # deep_sdf_decoder.py:60-65
+        if (self.xyz_in_all or self.latent_dropout or layer_norm) and self.forward_bf16:
+            raise NotImplementedError("forward_bf16 is not available with xyz_in_all / latent_dropout / LayerNorm")
         d = [self.latent_size + self.geom_dimension] + self.dims + [1]
         self.n_layers = len(d) - 1
         if self.n_layers > _lib.MAX_LAYERS:
@@ -66,6 +65,11 @@ class NetSpec:
             else:     # deep_sdf_decoder.py:45-48: xyz_in_all narrows every hidden Linear that is not followed by the skip concat
                 self.out_dim.append(d[l + 1] - (self.geom_dimension if self.xyz_in_all and l != self.n_layers - 1 else 0))
         self.wn = [bool(weight_norm and l in norm_layers) for l in range(self.n_layers)]
+        # a bn{l} = nn.LayerNorm(out_dim) module exists for EVERY l in norm_layers when there is no weight norm -- the last
+        # Linear's too, which forward never calls (:97-103 is inside `layer < num_layers - 2`)
+        self.ln = [bool(layer_norm and l in norm_layers) for l in range(self.n_layers)]
+        if any(self.ln[l] and self.out_dim[l] > 2048 for l in range(self.n_layers)):
+            raise NotImplementedError("LayerNorm wider than 2048")
         self.skip = [l in latent_in for l in range(self.n_layers)]
         self.drop = [bool(self.dropout is not None and l in self.dropout and l < self.n_layers - 1)
                      for l in range(self.n_layers)]
@@ -80,6 +84,8 @@ class NetSpec:
                            (f"lin{l}.parametrizations.weight.original1", (o, i), "v")]
             else:
                 entries = [(f"lin{l}.weight", (o, i), "weight"), (f"lin{l}.bias", (o,), "bias")]
+            if self.ln[l]:
+                entries += [(f"bn{l}.weight", (o,), "ln_w"), (f"bn{l}.bias", (o,), "ln_b")]
             for name, shape, kind in entries:
                 p = ParamInfo(name, shape, off, l, kind)
                 self.params.append(p)
@@ -97,14 +103,15 @@ class NetSpec:
         n.n_layers = self.n_layers
         n.latent_size = self.latent_size
         n.geom_dim = self.geom_dimension
-        wm = dm = sm = 0
+        wm = dm = sm = lm = 0
         for l in range(self.n_layers):
             n.in_dim[l] = self.in_dim[l]
             n.out_dim[l] = self.out_dim[l]
             wm |= int(self.wn[l]) << l
             dm |= int(self.drop[l]) << l
             sm |= int(self.skip[l]) << l
-        n.weight_norm_mask, n.dropout_mask, n.skip_mask = wm, dm, sm
+            lm |= int(self.ln[l]) << l
+        n.weight_norm_mask, n.dropout_mask, n.skip_mask, n.ln_param_mask = wm, dm, sm, lm
         n.dropout_p = self.dropout_prob
         n.fwd_bf16 = int(self.forward_bf16)
         n.use_tanh = int(self.use_tanh)

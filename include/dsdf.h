@@ -58,6 +58,9 @@ typedef struct DsdfNet {
                                        still concatenates the original input); mask = the dropout hash under dropout_key[15] */
   int32_t xyz_in_all;               /* :90-91: every layer l >= 1 that is not a latent_in layer takes [x || xyz]
                                        (in_dim[l] = out_dim[l-1] + geom_dim) */
+  uint32_t ln_param_mask;           /* :60-65 (norm_layers WITHOUT weight_norm): bit l: a bn{l} = nn.LayerNorm(out_dim[l]) module exists
+                                       (parameters bn{l}.weight, bn{l}.bias right after lin{l}.weight, lin{l}.bias); forward applies it
+                                       between the Linear and the ReLU of every HIDDEN layer that has one (:97-103) */
 } DsdfNet;
 
 /* Offsets (in floats) of every parameter tensor inside the decoder arena, named_parameters() order:
@@ -67,6 +70,8 @@ typedef struct DsdfParamLayout {
   int64_t bias_off[DSDF_MAX_LAYERS];
   int64_t g_off[DSDF_MAX_LAYERS];   /* -1 for plain layers */
   int64_t v_off[DSDF_MAX_LAYERS];   /* v (weight-normed) or weight (plain) */
+  int64_t ln_w_off[DSDF_MAX_LAYERS]; /* bn{l}.weight (LayerNorm gamma), -1 if layer l has no bn module */
+  int64_t ln_b_off[DSDF_MAX_LAYERS]; /* bn{l}.bias   (LayerNorm beta) */
 } DsdfParamLayout;
 
 /* Batch of one optimiser (sub-)step, train_deep_sdf.py:483-501.  Points are grouped in R contiguous

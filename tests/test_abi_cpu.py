@@ -51,9 +51,14 @@ def test_layout_and_sizes(lib):
 def test_invalid_nets_rejected(lib):
     from deepsdf_amd.net import NetSpec
     with pytest.raises(NotImplementedError):
-        NetSpec(4, [32] * 2, 3, norm_layers=[0], weight_norm=False)
-    with pytest.raises(NotImplementedError):
         NetSpec(4, [32] * 2, 3, xyz_in_all=True, forward_bf16=True)
+    ln = NetSpec(4, [32] * 2, 3, norm_layers=[0, 2], weight_norm=False)    # LayerNorm variant: bn modules, also the unused last one
+    assert [p.name for p in ln.params] == ["lin0.weight", "lin0.bias", "bn0.weight", "bn0.bias", "lin1.weight", "lin1.bias",
+                                           "lin2.weight", "lin2.bias", "bn2.weight", "bn2.bias"]
+    both = ln.c_struct()
+    both.weight_norm_mask = 1
+    b1 = C.c_size_t()
+    assert lib.dsdf_workspace_bytes(C.byref(both), 8, 1, C.byref(b1)) == -1 and b"exclude" in lib.dsdf_last_error()
     x = NetSpec(4, [32] * 3, 3, xyz_in_all=True, latent_in=[2])           # deep_sdf_decoder.py:42-48 layer arithmetic
     assert x.out_dim == [29, 25, 29, 1] and x.in_dim == [7, 32, 32, 32]
     bad = x.c_struct()

@@ -318,9 +318,9 @@ def test_decoder_jvp_vs_oracle(name):
         assert rel_err(p.grad.cpu(), go[pname].reshape(p.shape)) <= GRAD_TOL, pname
 
 
-@pytest.mark.parametrize("name", ["g11a_xyz_in_all", "g11b_latent_dropout"])
+@pytest.mark.parametrize("name", ["g11a_xyz_in_all", "g11b_latent_dropout", "g11c_layer_norm"])
 def test_decoder_variants_module_path_vs_oracle(name):
-    """xyz_in_all / latent_dropout through the nn.Module seam (Decoder.forward + autograd) against the oracle: eval and train
+    """xyz_in_all / latent_dropout / LayerNorm through the nn.Module seam (Decoder.forward + autograd) against the oracle: eval and train
     forward, parameter gradients, and d/d(input) -- which for xyz_in_all collects a d/d(xyz) term from EVERY layer and for
     latent_dropout passes the latent part of layer 0's gradient through the forward's mask."""
     from deepsdf_amd.decoder import Decoder
@@ -356,7 +356,36 @@ def test_decoder_variants_module_path_vs_oracle(name):
     with torch.no_grad():
         y2 = dec(x.cuda())
     assert rel_err(y2.cpu(), orc.decoder_forward(net, p64, x.double(), training=False)[0]) <= FWD_TOL
-    with pytest.raises(Exception, match="not implemented for latent_dropout / xyz_in_all"):
+    with pytest.raises(Exception, match="not implemented for latent_dropout / xyz_in_all / LayerNorm"):
         dec.jvp(x.cuda(), x.cuda())
     # export twin (eval) agrees too
     assert rel_err(dec.export_torchscript(x[:1])(x).detach(), y2.cpu()) <= 1e-5
+
+
+def test_trainer_runs_a_spec_with_every_decoder_variant(tmp_path):
+    """The drop-in trainer on a specs.json that switches on xyz_in_all, latent_dropout and LayerNorm at once: trains, writes
+    the bn{i} keys into the checkpoint, resumes from it, and the downstream loader + decode_sdf + TorchScript export work."""
+    from deepsdf_amd import train, workspace as ws
+    from deepsdf_amd.utils import decode_sdf
+    ns = {"dims": [64, 64, 64], "dropout": [0, 1, 2], "dropout_prob": 0.2, "norm_layers": [0, 1, 2, 3], "latent_in": [2],
+          "xyz_in_all": True, "use_tanh": False, "latent_dropout": True, "weight_norm": False, "geom_dimension": 3}
+    exp = _make_experiment(str(tmp_path), 4, specs_over={"NetworkSpecs": ns, "NumEpochs": 30, "SnapshotFrequency": 30,
+                                                         "AdditionalSnapshots": [], "LogFrequency": 10})
+    torch.manual_seed(0)
+    train.main_function(exp, None, 1)
+    logs = torch.load(os.path.join(exp, "Logs.pth"), weights_only=True)
+    assert all(math.isfinite(v) for v in logs["loss"]) and sum(logs["loss"][-4:]) < sum(logs["loss"][:4])
+    sd = torch.load(os.path.join(exp, "ModelParameters", "30.pth"), weights_only=True)["model_state_dict"]
+    assert "module.bn0.weight" in sd and "module.bn3.bias" in sd and sd["module.lin0.weight"].shape == (61, 7)
+    specs = json.load(open(os.path.join(exp, "specs.json")))
+    specs["NumEpochs"] = 40
+    json.dump(specs, open(os.path.join(exp, "specs.json"), "w"))
+    train.main_function(exp, "latest", 2)
+    dec = ws.load_trained_model(exp, "latest")
+    dec.eval()
+    lat = ws.load_latent_vectors(exp, "latest").cuda()
+    q = torch.rand(500, 3, device="cuda") * 2 - 1
+    with torch.no_grad():
+        y = decode_sdf(dec, lat[1:2], q)
+    x = torch.cat([lat[1:2].expand(500, -1), q], 1).cpu()
+    assert rel_err(dec.export_torchscript(x[:1])(x).detach(), y.cpu()) <= 1e-5

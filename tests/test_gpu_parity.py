@@ -15,8 +15,8 @@ FWD_TOL, GRAD_TOL, PARAM_TOL = 1e-5, 1e-4, 1e-5
 
 TRAIN_CASES = ["g1a_tiny_full", "g1b_lastnorm_tanh", "g1c_plain_clip", "g2_8x512_slice", "g3a_dropout_tiny",
                "g3b_dropout_8x512", "g4_batch_split2",
-               # Decoder variants no shipped spec uses (deep_sdf_decoder.py:90-91, 79-82): reference-generated goldens
-               "g11a_xyz_in_all", "g11b_latent_dropout"]
+               # Decoder variants no shipped spec uses (deep_sdf_decoder.py:90-91, 79-82, 60-65/97-103): reference-generated goldens
+               "g11a_xyz_in_all", "g11b_latent_dropout", "g11c_layer_norm"]
 
 
 @pytest.mark.parametrize("name", TRAIN_CASES)
@@ -146,9 +146,10 @@ def _safe_batch(net, st64, B, S, seed, delta, code_bound, drop_seed, margin=2e-5
     orc.renorm_rows_(lat, idx, code_bound)
     if masks is None:
         masks = orc.dropout_masks(net, drop_seed, st64.step, xyz.shape[0])
+    lmask = orc.latent_dropout_mask(net, drop_seed, st64.step, xyz.shape[0]) if net.latent_dropout else None
     for _ in range(12):
         x0 = torch.cat([lat[idx], xyz.double()], 1)
-        y, sv = orc.decoder_forward(net, st64.params, x0, training=True, masks=masks, track_margin=True)
+        y, sv = orc.decoder_forward(net, st64.params, x0, training=True, masks=masks, track_margin=True, latent_mask=lmask)
         d = torch.clamp(y, -delta, delta) - torch.clamp(gt.double(), -delta, delta)
         risky = (((y.abs() - delta).abs() < margin) | ((d != 0) & (d.abs() < margin))).reshape(-1)
         risky |= sv.min_abs_pre < relu_margin
@@ -514,3 +515,42 @@ def test_config4_reconstruct_full_size_vs_oracle(S):
     print(f"config 4, S={S}: code rel err vs fp64 oracle after {iters} iterations {e:.2e}")
     assert e <= PARAM_TOL
     assert torch.equal(eng.grads, grads_before)
+
+
+def test_all_decoder_variants_together_vs_oracle():
+    """xyz_in_all + latent_dropout + LayerNorm in ONE net (deep_sdf_decoder.py:79-82, 90-91, 60-65/97-103; each is pinned
+    separately by the reference-generated goldens g11a/b/c), a skip layer, dropout, use_tanh, widths off every tile grid:
+    two optimiser steps against the float64 oracle, unsplit and with --batch_split 3 (ragged chunks)."""
+    kw = dict(dims=[70, 70, 70, 72], dropout=[0, 1, 2, 3], dropout_prob=0.2, norm_layers=[0, 1, 3, 4], latent_in=[2], weight_norm=False,
+              xyz_in_all=True, latent_dropout=True, use_tanh=True, geom_dimension=3)
+    L, B, S = 9, 5, 96
+    net = orc.make_net(L, **kw)
+    spec = spec_from_meta(dict(L=L, net_specs=kw))
+    params = orc.init_params(net, 91)
+    lat0 = torch.randn(B, L, generator=torch.Generator().manual_seed(92)) / math.sqrt(L)
+    lat0[1] *= 1.4 / lat0[1].norm()
+    for split in (1, 3):
+        st64 = orc.TrainState.create({k: v.double() for k, v in params.items()}, lat0.double())
+        tr = HipTrainer(spec, params, lat0)
+        for step in range(2):
+            if split == 1:
+                idx, xyz, gt = _safe_batch(net, st64, B, S, 800 + step, 0.1, 1.0, 55)
+            else:
+                idx, xyz, gt = _big_batch(B, S, 810 + step)          # chunked masks restart per chunk: margins not pre-screened
+            r64 = orc.train_step(net, st64, idx, xyz.double(), gt.double(), delta=0.1, code_bound=1.0, epoch=40, seed=55,
+                                 batch_split=split)
+            rh = tr.step(idx, xyz, gt, delta=0.1, code_bound=1.0, code_reg=True, lam=1e-4, epoch=40, lr=(5e-4, 1e-3), seed=55,
+                         batch_split=split)
+            tol = GRAD_TOL if split == 1 else 5 * GRAD_TOL
+            assert abs(rh["loss"] - r64["loss"]) <= 1e-5 * abs(r64["loss"]), (split, step)
+            for k in r64["grads"]:
+                if float(r64["grads"][k].abs().max()) == 0.0:       # the unused bn module of the last Linear
+                    assert float(rh["grads"][k].abs().max()) == 0.0, k
+                else:
+                    assert rel_err(rh["grads"][k], r64["grads"][k]) <= tol, (split, step, k)
+            assert rel_err(rh["dlat"], r64["dlat"]) <= tol, (split, step)
+            if split == 1:
+                P = tr.params()
+                for k in st64.params:
+                    assert rel_err(P[k], st64.params[k]) <= PARAM_TOL, (step, k)
+                assert rel_err(tr.lat.cpu(), st64.latents) <= PARAM_TOL, step
