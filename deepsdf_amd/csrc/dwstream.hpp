@@ -33,6 +33,9 @@ struct DwLayer {
 struct DwArgs { int n_layers, n_full, n_narrow, N; DwLayer ly[DSDF_MAX_LAYERS]; };
 
 constexpr int DW_RING = 16;
+#ifndef DW_BRANCHLESS
+#define DW_BRANCHLESS 0      // measured: no difference (388 us both ways); the per-step overhead is not the branch
+#endif
 
 template <int NJ> struct DwVec;
 template <> struct DwVec<1> { typedef float type; };
@@ -101,11 +104,17 @@ __device__ __forceinline__ void dw_item(const DwLayer& L, int split, int m0, int
   for (; s + DW_RING <= nsteps; s += DW_RING) {   // steady state: static ring slots, one new step in flight per MMA group
 #pragma unroll
     for (int q = 0; q < DW_RING; ++q) {
+#if DW_BRANCHLESS
+      const int nxt = min(s + q + DW_RING - 1, nsteps - 1);   // past the end: re-request the last step (in bounds, never used) --
+      rga[(q + DW_RING - 1) % DW_RING] = lda(nxt);            // a scalar min instead of a compare + branch per k-step
+      rgb[(q + DW_RING - 1) % DW_RING] = ldbq(nxt);
+#else
       const int nxt = s + q + DW_RING - 1;
       if (nxt < nsteps) {
         rga[(q + DW_RING - 1) % DW_RING] = lda(nxt);
         rgb[(q + DW_RING - 1) % DW_RING] = ldbq(nxt);
       }
+#endif
       mma(rga[q], rgb[q]);
     }
   }

@@ -575,7 +575,11 @@ __device__ __forceinline__ void fused_load_x0_h(__bf16* S, const float* x0, int 
 // ONE k-unit of the next layer's weights travels across the epilogue (16 VGPRs); the ring itself lives only inside the
 // k-loop: a ring kept alive across the epilogue made the compiler spill ~600 scratch accesses per layer into it
 // (1.2 GB of scratch traffic per forward: ring 4 ran 30 % SLOWER than ring 2 until the ring became loop-local).
-struct Bf16Pre { bf16x8 b[4]; };
+#ifndef BF_PRE_UNITS
+#define BF_PRE_UNITS 1      // k-units of the next layer requested before the epilogue (1 .. BF_RING_UNITS - 1)
+#endif
+constexpr int BF_PRE = BF_PRE_UNITS;
+struct Bf16Pre { bf16x8 b[BF_PRE][4]; };
 
 // Every workgroup walks the k-units of a layer in its OWN rotated order (unit (u + rot) mod nu): 32 CUs of an XCD that all
 // stream the same weights in the same order at the same pace keep hitting ONE L2 channel at a time.  A rotation of the
@@ -618,13 +622,17 @@ __device__ __forceinline__ void bf16_load_unit(bf16x8 (&dst)[4], const Bf16BView
 __device__ __forceinline__ void bf16_prefetch(Bf16Pre& P, const __bf16* wfb, int U, int w, int lane, int nact, int nu) {
   if (nu <= 0) return;
   const Bf16BView B = bf16_bview(wfb, U, w, lane);
-  const int u = bf16_rot(nu);
-  switch (nact) {
-    case 4: bf16_load_unit<4>(P.b, B, u); break;
-    case 3: bf16_load_unit<3>(P.b, B, u); break;
-    case 2: bf16_load_unit<2>(P.b, B, u); break;
-    case 1: bf16_load_unit<1>(P.b, B, u); break;
-    default: break;
+  int u = bf16_rot(nu);
+#pragma unroll
+  for (int q = 0; q < BF_PRE; ++q) {          // unconditional (units wrap): every slot is defined, nothing stays live from before
+    switch (nact) {
+      case 4: bf16_load_unit<4>(P.b[q], B, u); break;
+      case 3: bf16_load_unit<3>(P.b[q], B, u); break;
+      case 2: bf16_load_unit<2>(P.b[q], B, u); break;
+      case 1: bf16_load_unit<1>(P.b[q], B, u); break;
+      default: break;
+    }
+    u = u + 1 == nu ? 0 : u + 1;
   }
 }
 
@@ -638,7 +646,9 @@ __device__ __forceinline__ void bf16_kloop(f32x16 (&acc)[2][4], const __bf16* ap
   bf16x8 a0[2], a1[2];
   const Bf16BView B = bf16_bview(wfb, U, w, lane);
   auto nextu = [&](int u) { return u + 1 == nu ? 0 : u + 1; };
-  int ub = nextu(bf16_rot(nu)), ua = bf16_rot(nu);   // next unit to request / next unit's rows to read
+  int ub = bf16_rot(nu), ua = bf16_rot(nu);          // next unit to request / next unit's rows to read
+#pragma unroll
+  for (int q = 0; q < BF_PRE; ++q) ub = nextu(ub);   // (the first BF_PRE units came with P)
   auto readA = [&](bf16x8 (&a)[2]) {
     if (!(BF_ABLATE & 4) || ua == bf16_rot(nu)) {
       a[0] = *reinterpret_cast<const bf16x8*>(ap + 16 * ua);
@@ -659,9 +669,11 @@ __device__ __forceinline__ void bf16_kloop(f32x16 (&acc)[2][4], const __bf16* ap
     }
   };
 #pragma unroll
-  for (int ni = 0; ni < NACT; ++ni) ring[0][ni] = P.b[ni];
+  for (int q = 0; q < BF_PRE; ++q)
 #pragma unroll
-  for (int q = 1; q < BF_RING - 1; ++q) loadB(ring[q]);   // unconditional: every slot is defined here
+    for (int ni = 0; ni < NACT; ++ni) ring[q][ni] = P.b[q][ni];
+#pragma unroll
+  for (int q = BF_PRE; q < BF_RING - 1; ++q) loadB(ring[q]);   // unconditional: every slot is defined here
   readA(a0);
   int s = 0;
   for (; s + BF_RING <= nu; s += BF_RING) {   // static ring slots; one unit refilled per step, BF_RING - 1 steps ahead
