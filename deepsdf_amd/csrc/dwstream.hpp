@@ -32,7 +32,10 @@ struct DwLayer {
 // (round-robin beyond that); the narrow ones are dealt to the waves that got no full item in the last round.
 struct DwArgs { int n_layers, n_full, n_narrow, N; DwLayer ly[DSDF_MAX_LAYERS]; };
 
-constexpr int DW_RING = 16;
+#ifndef DW_RING_STEPS
+#define DW_RING_STEPS 16
+#endif
+constexpr int DW_RING = DW_RING_STEPS;
 #ifndef DW_BRANCHLESS
 #define DW_BRANCHLESS 0      // measured: no difference (388 us both ways); the per-step overhead is not the branch
 #endif
