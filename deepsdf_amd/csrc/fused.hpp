@@ -231,6 +231,26 @@ __device__ __forceinline__ void fused_prefetch_b(FusedBSets& B, const float* wf,
 // Weights come through a buffer resource: the address of k-unit u of n-tile t is scalar ((t U + u) * 2 KiB, an SGPR
 // soffset) plus a per-lane constant, so the loads need NO vector address arithmetic (a lone wave pays for every VALU
 // instruction it issues between its MFMAs).
+#ifndef FUSED_RSRC4
+#define FUSED_RSRC4 0      // lab: 1 = one buffer resource per n-tile, ONE scalar offset per k-unit instead of one per load (measured: no difference -- the scalar instructions are not what the k-loop waits for)
+#endif
+#if FUSED_RSRC4
+struct FusedBView { __amdgpu_buffer_rsrc_t rsrc[4]; int voff; };   // rsrc[ni] based at n-tile (w + 4 ni); voff = lane * 16
+__device__ __forceinline__ FusedBView fused_bview(const float* wf, int U, int w, int lane) {
+  FusedBView v;
+  const int ws = __builtin_amdgcn_readfirstlane(w);
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+    v.rsrc[ni] = __builtin_amdgcn_make_buffer_rsrc((void*)(wf + (size_t)(ws + 4 * ni) * U * 512), 0, 0x7FFFFFFF, 0x00020000);
+  v.voff = lane * 16;
+  return v;
+}
+__device__ __forceinline__ float4 fused_bload(const FusedBView& B, int ni, int u, int half) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(B.rsrc[ni], B.voff + 1024 * half, u * 2048, 0);
+  return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+}
+#else
 struct FusedBView { __amdgpu_buffer_rsrc_t rsrc; int tbase[4]; int voff; };   // tbase[ni] = (w + 4 ni) * U; voff = lane * 16
 __device__ __forceinline__ FusedBView fused_bview(const float* wf, int U, int w, int lane) {
   FusedBView v;
@@ -246,6 +266,7 @@ __device__ __forceinline__ float4 fused_bload(const FusedBView& B, int ni, int u
   const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(B.rsrc, B.voff + 1024 * half, (B.tbase[ni] + u) * 2048, 0);
   return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
 }
+#endif
 
 template <int NACT>
 __device__ __forceinline__ void fused_kloop(f32x16 (&acc)[2][4], const float* ap, const FusedBView& bv, int nu,
