@@ -22,7 +22,7 @@ epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 root = tempfile.mkdtemp()
 d = os.path.join(root, "data", "SdfSamples", "synth", "spheres"); os.makedirs(d)
 names = []
-NSC = 256
+NSC = int(os.environ.get("TB_SCENES", "256"))
 for k in range(NSC):
     pos, neg = sphere_scene(k, 20000)
     np.savez(os.path.join(d, f"s{k}.npz"), pos=pos, neg=neg); names.append(f"s{k}")
