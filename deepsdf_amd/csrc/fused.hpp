@@ -16,11 +16,14 @@
 // k-permutation: within a unit of 16, lane (r, h) holds k = 16u + 8h + j (j = 0..7) for BOTH operands, so MFMA j
 // contracts k in {16u + j, 16u + 8 + j}: a permutation of the sum order only.
 //
-// A lone wave pays for every instruction it issues between its MFMAs, so per-load address arithmetic lives on the scalar
-// unit (FusedBView: buffer resource + SGPR tile/unit offsets; the epilogues' buffer stores with scalar row offsets).
+// A lone wave pays for every instruction it issues between its MFMAs -- and on this chip so would a second wave: an fp32
+// MFMA blocks the SIMD's VALU for its whole 64 cycles (tools/lab/mfma_valu.hip), so no producer/consumer
+// arrangement can hide the epilogues; they can only be short.  Per-load address arithmetic lives on the scalar unit
+// (FusedBView: buffer resource + SGPR tile/unit offsets; the epilogues' buffer stores with scalar row offsets).
 // Kernels: fused_forward_kernel (inference / module path), fused_backward_kernel (module path), fused_fwd_bwd_kernel
-// (training: both bodies in one launch, the last hidden activation stays in the slab), fused_forward_bf16_kernel
-// (BASELINE config 5).  Segment mode (FusedSeg) hoists the per-scene latent products out of the per-point work.
+// (training: both bodies in one launch, the last hidden activation stays in the slab), fused_forward_bf16_kernel and
+// fused_fwd_bf16_bwd_kernel (BASELINE config 5: bf16 forward body, fp32 backward body).  Segment mode (FusedSeg) hoists the
+// per-scene latent products out of the per-point work, in both precisions.
 #pragma once
 #include <type_traits>
 
