@@ -62,16 +62,4 @@ for name, f in (("decode_sdf as the reference does it (cat + dsdf_decode)", dec_
     for _ in range(10): f()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
     print(f"inference, 1 code x {n} points, {name}: {dt*1e3:.2f} ms = {n/dt/1e6:.1f} M points/s")
-# the multi-GPU step without the all-reduce: forward_backward (gradients written) + adam_step, on one GPU
-lat = (torch.randn(64, bench.L) / math.sqrt(bench.L)).to(dev)
-dlat, m, v = torch.zeros_like(lat), torch.zeros_like(lat), torch.zeros_like(lat)
-b = bench.synth_batches(1, 0, 64, dev, 1000)[0]
-def two_call():
-    eng.train_forward_backward(lat, dlat, b["seg_scene"], b["seg_offset"], b["xyz"], b["gt"], n_norm=16384, clamp_dist=0.1,
-                               reg_coef=1e-6, code_bound=1.0, training=True, seed=0, row_offset=0, seg_len=bench.SAMPLES)
-    eng.adam_step(lat, dlat, m, v, 5e-4, 1e-3)
-for _ in range(60): two_call()
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(300): two_call()
-torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 300
-print(f"two-call step (the N > 1 path minus the all-reduce): {dt*1e3:.4f} ms/step")
+# (the multi-GPU call sequence without the collective is measured by `DSDF_FORCE_DP_PATH=1 python bench.py --no-cpu-baseline`)
