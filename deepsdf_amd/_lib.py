@@ -66,7 +66,7 @@ PROTOTYPES = {
     "dsdf_decode": [_NET, _P, _P, _P, _I64, _I64, _P, _P, _SZ, _P],
     "dsdf_module_forward": [_NET, _P, _P, _P, _I64, _I64, _I32, C.POINTER(C.c_uint32), _P, _P, _SZ, _P],
     "dsdf_module_backward": [_NET, _P, _P, _P, _I64, _I32, C.POINTER(C.c_uint32), _P, _I32, _P, _I64, _P, _SZ, _P],
-    "dsdf_module_jvp": [_NET, _P, _P, _P, _I64, _I64, _I32, _P, _P, _SZ, _P],
+    "dsdf_module_jvp": [_NET, _P, _P, _P, _I64, _I64, _I32, C.POINTER(C.c_uint32), _P, _P, _SZ, _P],
     "dsdf_train_forward_backward": [_NET, _P, _P, _P, _I64, C.POINTER(DsdfBatch), C.POINTER(DsdfLossCfg), _P, _P, _P,
                                     _P, _I32, _P, _SZ, _P],
     "dsdf_grad_norm": [_P, _I64, _F, _P, _P, _P, _SZ, _P],

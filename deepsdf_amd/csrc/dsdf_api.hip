@@ -1180,14 +1180,17 @@ int dsdf_module_backward(const DsdfNet* net, const float* packed, const float* p
 //   the mask is read off the stored activations);  skip layer: in-tangent = [t_l | tangent];  out = tanh' ... tanh' (t_last w_last)
 // Layer-by-layer MFMA GEMM launches (gemm.hpp) -- this is the one-extra-pass tool of mesh.py:420, not the training hot path.
 int dsdf_module_jvp(const DsdfNet* net, const float* packed, const float* params, const float* tangent, int64_t ld_t,
-                    int64_t n, int32_t training, float* jvp_out, void* ws, size_t ws_bytes, void* stream) {
+                    int64_t n, int32_t training, const uint32_t* dropout_key, float* jvp_out, void* ws, size_t ws_bytes, void* stream) {
   TRY(check_common(net, packed, params, ws));
   if (n == 0) return 0;
   if (!tangent || !jvp_out || n < 0 || ld_t < net->in_dim[0]) return fail(DSDF_E_INVALID, "bad tangent/jvp_out/ld_t");
-  if (net_variant(net)) return fail(DSDF_E_INVALID, "dsdf_module_jvp is not implemented for latent_dropout / xyz_in_all / LayerNorm nets");
+  const bool lat_drop = net->latent_dropout && training && net->latent_size > 0;
+  if (lat_drop && !dropout_key) return fail(DSDF_E_INVALID, "dropout_key is NULL (latent_dropout needs the forward's key)");
   const Plan P = make_plan(net, n, 0, false);
   if (ws_bytes < P.total) return fail(DSDF_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, P.total);
   hipStream_t st = (hipStream_t)stream;
+  DsdfParamLayout L;
+  param_layout(net, &L);
   const Packed pk = packed_layout(net);
   const int last = net->n_layers - 1;
   float* t0 = at<float>(ws, P.dzA_off);                      // the input tangent in a 16-byte-aligned, zero-padded layout
@@ -1200,26 +1203,52 @@ int dsdf_module_jvp(const DsdfNet* net, const float* packed, const float* params
                        t0, (long long)P.ldz, (int)n, P.W0);
     LAUNCH_OK("add2_kernel(tangent)");
   }
+  float* t0_layer0 = t0;                                     // latent_dropout: layer 0 sees the tangent of the DROPPED latent,
+  if (lat_drop) {                                            // the skip layer the raw one (deep_sdf_decoder.py:79-89)
+    t0_layer0 = at<float>(ws, P.dzB_off);
+    HIP_OK(hipMemcpyAsync(t0_layer0, t0, (size_t)n * P.ldz * 4, hipMemcpyDeviceToDevice, st));
+    const long long tot = (long long)n * net->latent_size;
+    hipLaunchKernelGGL(latent_drop_bwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, t0_layer0, P.ldz, (int)n,
+                       net->latent_size, dropout_key[LATENT_DROPOUT_KEY], latent_drop_thr(), 1.0f / (1.0f - LATENT_DROPOUT_P), 0u);
+    LAUNCH_OK("latent_drop_bwd_kernel(tangent)");
+  }
+  auto append = [&](float* in_t, int l) -> int {             // what the forward concatenates to layer l's input, for the tangent
+    const bool skip = (net->skip_mask >> l) & 1;
+    if (!skip && !net->xyz_in_all) return 0;
+    const int w = skip ? P.W0 : net->geom_dim;
+    const float* src = skip ? t0 : t0 + net->latent_size;
+    const long long tot = (long long)n * w;
+    hipLaunchKernelGGL(add2_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, src, P.ldz, (const float*)nullptr, 0,
+                       in_t + net->out_dim[l - 1], (long long)P.ld_dp, (int)n, w);
+    return 0;
+  };
   int cur = 0;
   for (int l = 0; l < last; ++l) {
-    float* in_t = l == 0 ? t0 : at<float>(ws, P.dp_off[cur]);
-    if (l > 0 && ((net->skip_mask >> l) & 1)) {              // [t_l | tangent of x0]  (deep_sdf_decoder.py:88-89)
-      const long long tot = (long long)n * P.W0;
-      hipLaunchKernelGGL(add2_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, t0, P.ldz, (const float*)nullptr, 0,
-                         in_t + net->out_dim[l - 1], (long long)P.ld_dp, (int)n, P.W0);
-      LAUNCH_OK("add2_kernel(skip tangent)");
-    }
+    float* in_t = l == 0 ? t0_layer0 : at<float>(ws, P.dp_off[cur]);
+    if (l > 0) { append(in_t, l); LAUNCH_OK("add2_kernel(concat tangent)"); }
     NtArgs a;
     memset(&a, 0, sizeof(a));
     a.A = in_t; a.lda = l == 0 ? P.ldz : P.ld_dp;
     a.B = packed + pk.w_off[l]; a.ldb = pk.ldw[l];
     a.C = at<float>(ws, P.dp_off[l == 0 ? 0 : cur ^ 1]); a.ldc = P.ld_dp;
     a.M = (int)n; a.N = net->out_dim[l]; a.K = net->in_dim[l];
-    a.act = at<float>(ws, P.in_off[l + 1]); a.ldact = P.ld_in[l + 1];
-    a.mask_cols = net->out_dim[l]; a.mask_scale = mask_scale_of(net, l, training);
-    TRY(launch_nt<EPI_BWD>(a, st));
+    if (ln_applied(net, l)) {                                // Linear tangent, then LayerNorm + ReLU/dropout in one row pass
+      TRY(launch_nt<EPI_PLAIN>(a, st));
+      LnJvpArgs j;
+      memset(&j, 0, sizeof(j));
+      j.t = a.C; j.ldt = a.ldc; j.xhat = at<float>(ws, P.lnx_off[l]); j.ldx = P.ld_in[l + 1]; j.rstd = at<float>(ws, P.lnr_off[l]);
+      j.gamma = params + L.ln_w_off[l]; j.act = at<float>(ws, P.in_off[l + 1]); j.ldact = P.ld_in[l + 1];
+      j.mask_scale = mask_scale_of(net, l, training); j.n = (int)n; j.width = net->out_dim[l];
+      hipLaunchKernelGGL(ln_jvp_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, j);
+      LAUNCH_OK("ln_jvp_kernel");
+    } else {
+      a.act = at<float>(ws, P.in_off[l + 1]); a.ldact = P.ld_in[l + 1];
+      a.mask_cols = net->out_dim[l]; a.mask_scale = mask_scale_of(net, l, training);
+      TRY(launch_nt<EPI_BWD>(a, st));
+    }
     if (l > 0) cur ^= 1;
   }
+  if (last > 0) { append(at<float>(ws, P.dp_off[cur]), last); LAUNCH_OK("add2_kernel(concat tangent, last)"); }
   NtArgs a;                                                   // du = t_last . w_last
   memset(&a, 0, sizeof(a));
   a.A = at<float>(ws, P.dp_off[cur]); a.lda = P.ld_dp;

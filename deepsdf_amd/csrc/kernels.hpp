@@ -986,6 +986,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
   }
 }
 
+// forward-mode tangent through LayerNorm + ReLU/dropout (dsdf_module_jvp): ty (tangent of the Linear's output) -> in place
+//   tz = gamma rstd (ty - mean(ty) - xhat mean(ty xhat)) ; ta = [a > 0] scale tz      (the primal's decisions, from the stored a)
+struct LnJvpArgs { float* t; int ldt; const float* xhat; int ldx; const float* rstd; const float* gamma; const float* act; int ldact;
+                   float mask_scale; int n; int width; };
+__global__ __launch_bounds__(256) void ln_jvp_kernel(const LnJvpArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.n) return;
+  float* t = p.t + (size_t)row * p.ldt;
+  const float* xh = p.xhat + (size_t)row * p.ldx;
+  const float* a = p.act + (size_t)row * p.ldact;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = lane; c < p.width; c += 64) { s1 += t[c]; s2 += t[c] * xh[c]; }
+  s1 = wave_sum(s1) / (float)p.width;
+  s2 = wave_sum(s2) / (float)p.width;
+  const float rs = p.rstd[row];
+  for (int c = lane; c < p.width; c += 64) {
+    const float tz = p.gamma[c] * rs * (t[c] - s1 - xh[c] * s2);
+    t[c] = a[c] > 0.f ? tz * p.mask_scale : 0.f;
+  }
+}
+
 // d gamma[c] = sum of ln_bwd's block partials; d beta[c] = sum of the column-sum partials of dz (cs, ncs rows of ldcs);
 // zero != 0: a bn module forward never calls (the LAST Linear's, :60-65 creates it anyway): zero gradient
 struct LnGradArgs {

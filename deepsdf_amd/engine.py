@@ -190,7 +190,8 @@ class Engine:
         ws = self.train_workspace(n, 0)
         out = torch.empty(n, dtype=torch.float32, device=self.device)
         _lib.check(self.lib.dsdf_module_jvp(C.byref(self.cnet), _ptr(self.packed), _ptr(self.params), _ptr(t), t.stride(0), n,
-                                            int(training), _ptr(out), _ptr(ws), ws.numel(), _stream()))
+                                            int(training), getattr(self, "_module_keys", None), _ptr(out), _ptr(ws), ws.numel(),
+                                            _stream()))
         return out.view(n, 1)
 
     # ---- training --------------------------------------------------------------------------------------------

@@ -154,7 +154,8 @@ int dsdf_module_backward(const DsdfNet* net, const float* packed, const float* p
  * control points) by double backward; here it is one extra pass through the same GEMMs with the primal pass's ReLU /
  * dropout decisions.  May be called any number of times after one forward (before or after dsdf_module_backward). */
 int dsdf_module_jvp(const DsdfNet* net, const float* packed, const float* params, const float* tangent, int64_t ld_t,
-                    int64_t n, int32_t training, float* jvp_out, void* ws, size_t ws_bytes, void* stream);
+                    int64_t n, int32_t training, const uint32_t* dropout_key /*[host] as dsdf_module_backward*/,
+                    float* jvp_out, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- training step ---------------------------------------------------------------------------------
  * dsdf_train_forward_backward = train_deep_sdf.py:509-533 for one chunk: max-norm renorm of the looked-up

@@ -356,8 +356,17 @@ def test_decoder_variants_module_path_vs_oracle(name):
     with torch.no_grad():
         y2 = dec(x.cuda())
     assert rel_err(y2.cpu(), orc.decoder_forward(net, p64, x.double(), training=False)[0]) <= FWD_TOL
-    with pytest.raises(Exception, match="not implemented for latent_dropout / xyz_in_all / LayerNorm"):
-        dec.jvp(x.cuda(), x.cuda())
+    # forward-mode tangent (dsdf_module_jvp) through the variant: eval and train (the primal's dropout / latent-dropout decisions)
+    v = torch.randn(N, L + 3, generator=gen)
+    for training in (False, True):
+        dec.train(training)
+        yj, jv = dec.jvp(x.cuda(), v.cuda())
+        masks = orc.dropout_masks(net, dec.dropout_seed, dec._fwd_calls, N) if training else None
+        lmask = orc.latent_dropout_mask(net, dec.dropout_seed, dec._fwd_calls, N) if (training and net.latent_dropout) else None
+        f64 = lambda inp: orc.decoder_forward(net, p64, inp, training=training, masks=masks, latent_mask=lmask)[0]   # noqa: E731
+        yo, jo = torch.autograd.functional.jvp(f64, x.double(), v.double())
+        assert rel_err(yj.cpu(), yo) <= FWD_TOL and rel_err(jv.cpu(), jo) <= 2e-5, training
+    dec.eval()
     # export twin (eval) agrees too
     assert rel_err(dec.export_torchscript(x[:1])(x).detach(), y2.cpu()) <= 1e-5
 
