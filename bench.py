@@ -23,7 +23,6 @@ import json
 import math
 import os
 import statistics
-import subprocess
 import sys
 import threading
 import time
