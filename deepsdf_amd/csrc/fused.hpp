@@ -777,6 +777,9 @@ __device__ __forceinline__ void fused_forward_bf16_body(const FusedFwdArgs& p, f
     fused_load_x0_h(SH, p.x0, p.ldx0, p.W0, row0, p.N, 0);
   }
   __syncthreads();
+#ifdef DSDF_LAB
+  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 0] = __builtin_amdgcn_s_memtime();
+#endif
   for (int l = 0; l < p.n_hidden; ++l) {
     const FusedLayer& L = p.ly[l];
     const int nu = (L.in + 15) >> 4, nact = fused_nact(L.out_dim, w);
@@ -806,7 +809,13 @@ __device__ __forceinline__ void fused_forward_bf16_body(const FusedFwdArgs& p, f
         bf16_prefetch(R, reinterpret_cast<const __bf16*>(Ln.wf), Ln.U, w, lane, fused_nact(Ln.out_dim, w), (Ln.in + 15) >> 4);
       }
     }
+#ifdef DSDF_LAB
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 1 + 3 * l] = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();   // every wave has finished reading the slab: it may be overwritten in place
+#ifdef DSDF_LAB
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 2 + 3 * l] = __builtin_amdgcn_s_memtime();
+#endif
     const bool last_hidden = l + 1 == p.n_hidden;
     if (L.x0_col >= 0) fused_load_x0_h(SH, p.x0, p.ldx0, p.W0, row0, p.N, L.x0_col);
     {
@@ -827,6 +836,9 @@ __device__ __forceinline__ void fused_forward_bf16_body(const FusedFwdArgs& p, f
       for (int i = tid; i < FROWS * zc; i += 256) SH[(i / zc) * FLDH + L.out_dim + (i % zc)] = (__bf16)0.f;
     }
     __syncthreads();
+#ifdef DSDF_LAB
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 3 + 3 * l] = __builtin_amdgcn_s_memtime();
+#endif
   }
   if (p.y_out == nullptr && p.u_out == nullptr) return;   // training: the backward head recomputes the output layer from the slab
   float4 qv[2];

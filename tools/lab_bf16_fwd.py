@@ -7,7 +7,7 @@ from deepsdf_amd.net import NetSpec
 NET = dict(dims=[512] * 8, dropout=list(range(8)), dropout_prob=0.2, norm_layers=list(range(8)), latent_in=[4],
            weight_norm=True, geom_dimension=3)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-for bf in (True, False):
+for bf in ((True,) if os.environ.get("LAB_ONLY_BF16") == "1" else (True, False)):
     eng = Engine(NetSpec(256, forward_bf16=bf, **NET), "cuda")
     eng.init_like_reference(torch.Generator().manual_seed(0))
     z = torch.randn(256, device="cuda") / 16

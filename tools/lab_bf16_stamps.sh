@@ -1,0 +1,3 @@
+R=$GRAFT_REPO_ROOT
+DSDF_LIB_PATH=$R/tools/lab/variants/bf_lab.so LAB_ONLY_BF16=1 DSDF_LAB_DBG=$R/gpurun_out/bf_dbg.bin python3 tools/lab_bf16_fwd.py 16384
+python3 tools/lab_dbg.py $R/gpurun_out/bf_dbg.bin 256
