@@ -134,13 +134,15 @@ def _big_batch(B, S, seed, G=3):
     return idx, xyz, gt
 
 
-def _safe_batch(net, st64, B, S, seed, delta, code_bound, drop_seed, margin=2e-5, relu_margin=1e-6, G=3, masks=None):
+def _safe_batch(net, st64, B, S, seed, delta, code_bound, drop_seed, margin=2e-5, relu_margin=1e-6, G=3, masks=None, scenes=None):
     """Seeded batch whose clamp / sign / ReLU decisions are robust: points with | |y|-delta | or |clamp(y)-clamp(t)|
     within `margin`, or any hidden pre-activation within `relu_margin` of 0 (decided by the float64 oracle), are
     re-drawn.  A clamp/sign flip of one point moves 1/N of the gradient (6e-5 at N=16384); ~10 ReLU flips out of 67 M
     pre-activations put BOTH fp32 implementations (HIP and the CPU oracle) 1.5e-4 from the fp64 truth.  That is
     discontinuity noise, not kernel error, so the comparison is made on a margin-safe batch."""
     idx, xyz, gt = _big_batch(B, S, seed, G)
+    if scenes is not None:                                   # rows of a larger latent table instead of 0 .. B-1
+        idx = scenes.repeat_interleave(S)
     gen = torch.Generator().manual_seed(seed + 999)
     lat = st64.latents.clone()
     orc.renorm_rows_(lat, idx, code_bound)
@@ -554,3 +556,42 @@ def test_all_decoder_variants_together_vs_oracle():
                 for k in st64.params:
                     assert rel_err(P[k], st64.params[k]) <= PARAM_TOL, (step, k)
                 assert rel_err(tr.lat.cpu(), st64.latents) <= PARAM_TOL, step
+
+
+def test_fast_path_with_a_512_scene_table_vs_oracle():
+    """BASELINE config 3's per-rank state on the one-call fast path: a latent table of 512 scenes of which a step touches 64
+    (different ones each step): the dense Adam keeps moving rows that are absent from the batch by their momentum
+    (train_deep_sdf.py:400-411,545), the max-norm renorm only fires for looked-up rows.  Three steps, fp64 oracle."""
+    from deepsdf_amd.engine import make_segments
+    L, T, B, S = 256, 512, 64, 64
+    net = orc.make_net(L, **BIG)
+    spec = spec_from_meta(dict(L=L, net_specs=BIG))
+    params = orc.init_params(net, 71)
+    gen = torch.Generator().manual_seed(72)
+    lat0 = torch.randn(T, L, generator=gen) / math.sqrt(L)
+    lat0[::37] *= 1.5                                        # several rows above CodeBound, only some of them ever looked up
+    st64 = orc.TrainState.create({k: v.double() for k, v in params.items()}, lat0.double())
+    tr = HipTrainer(spec, params, lat0)
+    seen = torch.zeros(T, dtype=torch.bool)
+    for step in range(3):
+        scenes = torch.randperm(T, generator=gen)[:B].sort().values
+        idx, xyz, gt = _safe_batch(net, st64, B, S, 950 + step, 0.1, 1.0, 7, scenes=scenes)
+        before = st64.latents.clone()
+        r64 = orc.train_step(net, st64, idx, xyz.double(), gt.double(), delta=0.1, code_bound=1.0, epoch=57, seed=7)
+        sc, so = make_segments(idx.cuda())
+        tr.eng.train_step(tr.lat, tr.dlat, tr.lat_m, tr.lat_v, sc, so, xyz.cuda().contiguous(), gt.reshape(-1).cuda().contiguous(),
+                          n_norm=B * S, clamp_dist=0.1, reg_coef=1e-4 * 0.57, code_bound=1.0, lr_decoder=5e-4, lr_latent=1e-3,
+                          seed=7, seg_len=S)
+        assert abs(float(tr.eng.loss) - r64["loss"]) <= 1e-5 * abs(r64["loss"]), step
+        lat = tr.lat.cpu()
+        absent_moved = (~seen) & (~torch.isin(torch.arange(T), scenes))
+        assert torch.equal(lat[absent_moved], lat0[absent_moved])                            # never-seen rows do not move at all
+        prev_seen_absent = seen & (~torch.isin(torch.arange(T), scenes))
+        if bool(prev_seen_absent.any()):                                                       # seen before, absent now: momentum only
+            assert float((st64.latents[prev_seen_absent] - before[prev_seen_absent]).abs().max()) > 0
+        assert rel_err(lat, st64.latents) <= PARAM_TOL, step
+        assert rel_err(tr.lat_m.cpu(), st64.m_lat) <= GRAD_TOL and rel_err(tr.lat_v.cpu(), st64.v_lat) <= 2 * GRAD_TOL, step
+        seen |= torch.isin(torch.arange(T), scenes)
+    P = tr.params()
+    for k in st64.params:
+        assert rel_err(P[k], st64.params[k]) <= PARAM_TOL, k
