@@ -15,6 +15,7 @@
 #include "dwstream.hpp"
 #include "sample.hpp"
 #include "fused.hpp"
+#include "fused_bf16x8.hpp"
 #include "gemm.hpp"
 #include "kernels.hpp"
 
@@ -573,7 +574,9 @@ int run_fused_forward(const DsdfNet* net, const Plan& P, void* ws, const float* 
   if (!dbg && getenv("DSDF_LAB_DBG")) { (void)hipMalloc(&dbg, 8192 * 64 * 8); }
   a.dbg = dbg;
 #endif
-  if (net->fwd_bf16) hipLaunchKernelGGL(fused_forward_bf16_kernel, dim3((unsigned)((n + FROWS - 1) / FROWS)), dim3(256), 0, st, a);
+  if (net->fwd_bf16 && !store_act && !getenv("DSDF_BF16_FWD4"))   // inference form: 8 staggered waves (fused_bf16x8.hpp)
+    hipLaunchKernelGGL(fused_forward_bf16x8_kernel, dim3((unsigned)((n + FROWS - 1) / FROWS)), dim3(F8_THREADS), 0, st, a);
+  else if (net->fwd_bf16) hipLaunchKernelGGL(fused_forward_bf16_kernel, dim3((unsigned)((n + FROWS - 1) / FROWS)), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(fused_forward_kernel, dim3((unsigned)((n + FROWS - 1) / FROWS)), dim3(256), 0, st, a);
 #ifdef DSDF_LAB
   if (dbg && getenv("DSDF_LAB_DBG")) {

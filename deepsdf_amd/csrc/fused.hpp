@@ -26,6 +26,7 @@
 // per-scene latent products out of the per-point work, in both precisions.
 #pragma once
 #include <type_traits>
+#include <utility>
 
 #include "common.hpp"
 
@@ -599,6 +600,12 @@ __device__ __forceinline__ void fused_load_x0_h(__bf16* S, const float* x0, int 
 // ONE k-unit of the next layer's weights travels across the epilogue (16 VGPRs); the ring itself lives only inside the
 // k-loop: a ring kept alive across the epilogue made the compiler spill ~600 scratch accesses per layer into it
 // (1.2 GB of scratch traffic per forward: ring 4 ran 30 % SLOWER than ring 2 until the ring became loop-local).
+#ifndef BF_PIPELINED
+#define BF_PIPELINED 0      // lab: 1 = 512x512 layers run their n-tiles one after the other with the previous n-tile's epilogue woven into the k-loop (measured SLOWER)
+#endif
+#ifndef BF_PIPE_DEPTH
+#define BF_PIPE_DEPTH 16    // pipelined layer: (n-tile, k-unit) weight fragments in flight per wave (1 KiB each; the L2 needs >= 24 KiB per CU)
+#endif
 #ifndef BF_PRE_UNITS
 #define BF_PRE_UNITS 1      // k-units of the next layer requested before the epilogue (1 .. BF_RING_UNITS - 1)
 #endif
@@ -732,11 +739,121 @@ __device__ __forceinline__ void bf16_kloop_dispatch(f32x16 (&acc)[2][4], const _
   }
 }
 
+// ---- pipelined layer (BF_PIPELINED): the epilogue hidden under the weight stream -------------------------------------------
+// The plain layer above is  [k-loop of all 4 n-tiles: 17 k cycles, L2-bound]  then  [epilogue of all 4: 8-13 k cycles, VALU]  in
+// series.  bf16 MFMAs leave the VALU free and the k-loop spends half its time waiting for weights, so here the 4 n-tiles of a
+// wave run ONE AFTER THE OTHER (n-tile j over all 32 k-units, both m-tiles), and the epilogue of n-tile j-1 -- bias, ReLU,
+// dropout hash, convert, LDS / global stores, mask bits; one row pair per two k-units -- is woven into the k-loop of n-tile j.
+// Only the last n-tile's epilogue stays exposed.  Same weight bytes (every n-tile's weights are still streamed once); the layer
+// input is read 4x from LDS instead of once (LDS is idle).  Needs a SECOND slab: the output goes to the other buffer while
+// later n-tiles still read the input (2 x 66.5 KB of the 160 KB), which also drops one of the two barriers per layer.
+// Fully unrolled (128 steps of (n-tile, unit)): layers with K = 512 and all 16 n-tiles only; anything else takes the plain path.
+struct Bf16Epi {
+  __amdgpu_buffer_rsrc_t rsrc; int ldb; bool has_out;
+  float bias[4]; uint32_t ck[4]; uint32_t pm; uint32_t drop_thr; float drop_scale;
+  __bf16* outp;          // OUT slab + (4 fh) * FLDH + fr   (+ 32 (w + 4 ni) per n-tile)
+  uint32_t voff0;        // ((4 fh) * ld_out + fr) * 4      (+ 128 (w + 4 ni) per n-tile)
+  int w;
+};
+template <int NI, int PAIR, bool DROP, bool EVEN, bool OUT>   // OUT: global activation copies are kept (training / module path)
+__device__ __forceinline__ void bf16_epi_pair(const f32x16 (&acc)[2][4], const Bf16Epi& E, uint32_t (&mq)[4]) {
+  constexpr int m = PAIR >> 3, rp = PAIR & 7;
+  constexpr int rc = 32 * m + crow(2 * rp);
+  float v0 = fmaxf(acc[m][NI][2 * rp] + E.bias[NI], 0.f), v1 = fmaxf(acc[m][NI][2 * rp + 1] + E.bias[NI], 0.f);
+  if constexpr (DROP) {
+    if constexpr (EVEN) {
+      const uint32_t h = lowbias32(E.ck[NI] ^ (E.pm + (uint32_t)(rc >> 1) * 0x9E3779B1u));
+      v0 = (h & 0xFFFFu) >= E.drop_thr ? v0 * E.drop_scale : 0.f;
+      v1 = (h >> 16) >= E.drop_thr ? v1 * E.drop_scale : 0.f;
+    } else {
+      const uint32_t ha = lowbias32(E.ck[NI] ^ (E.pm + (uint32_t)(rc >> 1) * 0x9E3779B1u));
+      const uint32_t hb = lowbias32(E.ck[NI] ^ (E.pm + (uint32_t)((rc >> 1) + 1) * 0x9E3779B1u));
+      v0 = (ha >> 16) >= E.drop_thr ? v0 * E.drop_scale : 0.f;
+      v1 = (hb & 0xFFFFu) >= E.drop_thr ? v1 * E.drop_scale : 0.f;
+    }
+  }
+  __bf16* hp = E.outp + 32 * (E.w + 4 * NI);
+  hp[rc * FLDH] = (__bf16)v0;
+  hp[(rc + 1) * FLDH] = (__bf16)v1;
+  if constexpr (OUT) {     // (a run-time branch here splits the woven stream into hundreds of basic blocks with spills around each)
+    const uint32_t voff = E.voff0 + 128u * (uint32_t)(E.w + 4 * NI);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), E.rsrc, voff, rc * E.ldb, FUSED_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), E.rsrc, voff, (rc + 1) * E.ldb, FUSED_STORE_AUX);
+  }
+  const uint32_t b2 = (v0 > 0.f ? 1u : 0u) | (v1 > 0.f ? 2u : 0u);
+  mq[2 * m + (NI >> 1)] |= b2 << (16 * (NI & 1) + 2 * rp);
+}
+
+// every index below (step, n-tile, unit position, ring slot, accumulator register) is a compile-time constant: the 128 steps are
+// expanded through an integer sequence, not through a loop the compiler may or may not unroll
+template <bool DROP, bool EVEN, bool OUT>
+struct Bf16Pipe {
+  static constexpr int NU = 32, NS = 4 * NU, D = BF_PIPE_DEPTH;
+  f32x16 (&acc)[2][4];
+  const __bf16* ap; const Bf16BView& B; const int rot; const Bf16Pre& P; const Bf16Epi& E; uint32_t (&mq)[4];
+  bf16x8 ring[D];
+  bf16x8 a[2][2];                               // A fragments of the current / next step, alternating
+
+  __device__ __forceinline__ void load(bf16x8& dst, int tile, int q) const {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const int u = (rot + q) & (NU - 1);
+    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(B.rsrc, B.voff, (B.tb[tile] + u) << 10, 0);
+    dst = __builtin_bit_cast(bf16x8, r);
+  }
+  __device__ __forceinline__ void readA(bf16x8 (&x)[2], int q) const {
+    const int u = (rot + q) & (NU - 1);
+    x[0] = *reinterpret_cast<const bf16x8*>(ap + 16 * u);
+    x[1] = *reinterpret_cast<const bf16x8*>(ap + 32 * FLDH + 16 * u);
+  }
+  template <int S>
+  __device__ __forceinline__ void step() {
+    constexpr int ni = S / NU, q = S % NU, nx = S + D - 1;
+    if constexpr (nx < NS) {
+      if constexpr (nx % NU == 0) ring[nx % D] = P.b[0][nx / NU];     // first unit of the next n-tile: came with the cross-layer prefetch
+      else load(ring[nx % D], nx / NU, nx % NU);
+    }
+    if constexpr (S + 1 < NS) readA(a[(S + 1) & 1], (S + 1) % NU);
+    acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[S & 1][0], ring[S % D], acc[0][ni], 0, 0, 0);
+    acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[S & 1][1], ring[S % D], acc[1][ni], 0, 0, 0);
+    if constexpr (ni > 0 && (q & 1) == 0) bf16_epi_pair<ni - 1, q / 2, DROP, EVEN, OUT>(acc, E, mq);   // one row pair of the PREVIOUS n-tile
+    __builtin_amdgcn_sched_barrier(0);   // keep the steps in program order: left alone, the scheduler hoists the loads of many
+  }                                      // steps to the top and spills the ring
+  template <int... S>
+  __device__ __forceinline__ void steps(std::integer_sequence<int, S...>) { (step<S>(), ...); }
+  template <int... PR>
+  __device__ __forceinline__ void last_tile(std::integer_sequence<int, PR...>) { (bf16_epi_pair<3, PR, DROP, EVEN, OUT>(acc, E, mq), ...); }
+
+  __device__ __forceinline__ void run_steps() {
+    ring[0] = P.b[0][0];
+#pragma unroll
+    for (int s = 1; s < D - 1; ++s) load(ring[s], 0, s);
+    readA(a[0], 0);
+    steps(std::make_integer_sequence<int, NS>{});
+  }
+  __device__ __forceinline__ void run_last() { last_tile(std::make_integer_sequence<int, 16>{}); }   // stays exposed
+};
+
+// next != nullptr: the NEXT layer's first units are requested between the woven part and the exposed last-tile epilogue
+template <bool DROP, bool EVEN, bool OUT>
+__device__ __forceinline__ void bf16_layer_pipelined(f32x16 (&acc)[2][4], const __bf16* ap, const __bf16* wfb, int U, int w, int lane,
+                                                     Bf16Pre& P, const Bf16Epi& E, uint32_t (&mq)[4], const FusedLayer* next) {
+  const Bf16BView B = bf16_bview(wfb, U, w, lane);
+  Bf16Pipe<DROP, EVEN, OUT> pipe{acc, ap, B, bf16_rot(32), P, E, mq};
+  pipe.run_steps();
+  if (next != nullptr)    // (P's last use was step 96: it can take the next layer's units now)
+    bf16_prefetch(P, reinterpret_cast<const __bf16*>(next->wf), next->U, w, lane, fused_nact(next->out_dim, w), (next->in + 15) >> 4);
+  pipe.run_last();
+}
+
 // S: the slab (bf16 view for the hidden layers; the LAST hidden activation is written as fp32, row stride FLD, for the fp32
 // output layer / backward head).  Segment mode: xs / hu / hwx as in fused_forward_body, all values rounded to bf16.
 __device__ __forceinline__ void fused_forward_bf16_body(const FusedFwdArgs& p, float* S, float4* xs, float (*hu)[FMAXW],
                                                         float4 (*hwx)[FMAXW]) {
-  __bf16* SH = reinterpret_cast<__bf16*>(S);
+  // two bf16 slabs (2 x 66.5 KB): a layer reads one and writes the other, so nothing is overwritten in place -- one barrier per
+  // layer instead of two, and the pipelined layers can write their output while later n-tiles still read the input
+  __bf16* SHA = reinterpret_cast<__bf16*>(S);
+  __bf16* SHB = SHA + FROWS * FLDH;
+  __bf16* SH = SHA;                       // the current layer's INPUT slab
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int row0 = blockIdx.x * FROWS;
@@ -802,39 +919,71 @@ __device__ __forceinline__ void fused_forward_bf16_body(const FusedFwdArgs& p, f
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[m][ni][r] = 0.f;
     }
-    if (nu > 0) {
-      bf16_kloop_dispatch(acc, SH + fr * FLDH + 8 * fh, reinterpret_cast<const __bf16*>(L.wf), L.U, w, lane, nu, nact, R);
-      if (l + 1 < p.n_hidden) {   // the next layer's first units travel while this layer's epilogue runs
-        const FusedLayer& Ln = p.ly[l + 1];
-        bf16_prefetch(R, reinterpret_cast<const __bf16*>(Ln.wf), Ln.U, w, lane, fused_nact(Ln.out_dim, w), (Ln.in + 15) >> 4);
-      }
-    }
-#ifdef DSDF_LAB
-    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 1 + 3 * l] = __builtin_amdgcn_s_memtime();
-#endif
-    __syncthreads();   // every wave has finished reading the slab: it may be overwritten in place
-#ifdef DSDF_LAB
-    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 2 + 3 * l] = __builtin_amdgcn_s_memtime();
-#endif
     const bool last_hidden = l + 1 == p.n_hidden;
-    if (L.x0_col >= 0) fused_load_x0_h(SH, p.x0, p.ldx0, p.W0, row0, p.N, L.x0_col);
+    __bf16* OUT = SH == SHA ? SHB : SHA;      // this layer's OUTPUT slab (the last hidden layer writes fp32 over both instead)
+    const bool drop = L.drop_thr != 0u;
+    const bool even = ((p.row_offset + (uint32_t)row0) & 1u) == 0u;
+#if BF_PIPELINED
+    if (hidx < 0 && !last_hidden && L.x0_col < 0 && nu == 32 && L.out_dim == 512 &&
+        (L.out != nullptr || !drop)) {   // epilogue woven into the k-loop (no variant for "dropout without activation copies": plain path)
+      Bf16Epi E;
+      const int rows_here = min(FROWS, p.N - row0);
+      E.has_out = L.out != nullptr;
+      E.rsrc = __builtin_amdgcn_make_buffer_rsrc(E.has_out ? (void*)(L.out + (size_t)row0 * L.ld_out) : (void*)S, 0,
+                                                 E.has_out ? rows_here * L.ld_out * 4 : 0, 0x00020000);
+      E.ldb = L.ld_out * 4;
+      E.pm = ((p.row_offset + (uint32_t)(row0 + 4 * fh)) >> 1) * 0x9E3779B1u;
+      E.drop_thr = L.drop_thr; E.drop_scale = L.drop_scale; E.w = w;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) { E.bias[ni] = biasv[ni]; E.ck[ni] = drop_col_key((uint32_t)(32 * (w + 4 * ni) + fr), L.drop_key); }
+      E.outp = OUT + (4 * fh) * FLDH + fr;
+      E.voff0 = (uint32_t)((4 * fh) * E.ldb + fr * 4);
+      uint32_t mq[4] = {0u, 0u, 0u, 0u};
+      const __bf16* ap = SH + fr * FLDH + 8 * fh;
+      const __bf16* wfb = reinterpret_cast<const __bf16*>(L.wf);
+      if (!E.has_out) bf16_layer_pipelined<false, true, false>(acc, ap, wfb, L.U, w, lane, R, E, mq, &p.ly[l + 1]);   // inference: no dropout either
+      else if (!drop) bf16_layer_pipelined<false, true, true>(acc, ap, wfb, L.U, w, lane, R, E, mq, &p.ly[l + 1]);
+      else if (even) bf16_layer_pipelined<true, true, true>(acc, ap, wfb, L.U, w, lane, R, E, mq, &p.ly[l + 1]);
+      else bf16_layer_pipelined<true, false, true>(acc, ap, wfb, L.U, w, lane, R, E, mq, &p.ly[l + 1]);
+      if (L.maskbits != nullptr)
+        *reinterpret_cast<uint4*>(L.maskbits + ((size_t)blockIdx.x * 256 + threadIdx.x) * 4) = make_uint4(mq[0], mq[1], mq[2], mq[3]);
+#ifdef DSDF_LAB
+      if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 64 + 1 + 3 * l] = __builtin_amdgcn_s_memtime(); p.dbg[blockIdx.x * 64 + 2 + 3 * l] = p.dbg[blockIdx.x * 64 + 1 + 3 * l]; }
+#endif
+    } else
+#endif
     {
-      const bool drop = L.drop_thr != 0u;
-      const bool even = ((p.row_offset + (uint32_t)row0) & 1u) == 0u;
+      if (nu > 0) {
+        bf16_kloop_dispatch(acc, SH + fr * FLDH + 8 * fh, reinterpret_cast<const __bf16*>(L.wf), L.U, w, lane, nu, nact, R);
+        if (l + 1 < p.n_hidden) {   // the next layer's first units travel while this layer's epilogue runs
+          const FusedLayer& Ln = p.ly[l + 1];
+          bf16_prefetch(R, reinterpret_cast<const __bf16*>(Ln.wf), Ln.U, w, lane, fused_nact(Ln.out_dim, w), (Ln.in + 15) >> 4);
+        }
+      }
+#ifdef DSDF_LAB
+      if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 1 + 3 * l] = __builtin_amdgcn_s_memtime();
+#endif
+      if (last_hidden) __syncthreads();   // its fp32 output covers BOTH bf16 slabs: every wave must have finished reading its input
+#ifdef DSDF_LAB
+      if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 2 + 3 * l] = __builtin_amdgcn_s_memtime();
+#endif
+      if (L.x0_col >= 0) fused_load_x0_h(OUT, p.x0, p.ldx0, p.W0, row0, p.N, L.x0_col);
       if (last_hidden) {   // the output layer / the backward head read fp32: its input goes to the slab as fp32
         if (!drop) fused_fwd_epilogue<false, true, false>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
         else if (even) fused_fwd_epilogue<true, true, false>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
         else fused_fwd_epilogue<true, false, false>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
       } else {
-        if (!drop) fused_fwd_epilogue<false, true, true>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
-        else if (even) fused_fwd_epilogue<true, true, true>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
-        else fused_fwd_epilogue<true, false, true>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+        float* OS = reinterpret_cast<float*>(OUT);
+        if (!drop) fused_fwd_epilogue<false, true, true>(acc, biasv, OS, L, w, fr, fh, row0, p.N, p.row_offset);
+        else if (even) fused_fwd_epilogue<true, true, true>(acc, biasv, OS, L, w, fr, fh, row0, p.N, p.row_offset);
+        else fused_fwd_epilogue<true, false, true>(acc, biasv, OS, L, w, fr, fh, row0, p.N, p.row_offset);
+      }
+      if (!last_hidden && L.x0_col < 0) {      // zero pad [out_dim, roundup16) of the bf16 slab (the x0 loader pads its own end)
+        const int zc = ((L.out_dim + 15) & ~15) - L.out_dim;
+        for (int i = tid; i < FROWS * zc; i += 256) OUT[(i / zc) * FLDH + L.out_dim + (i % zc)] = (__bf16)0.f;
       }
     }
-    if (!last_hidden && L.x0_col < 0) {      // zero pad [out_dim, roundup16) of the bf16 slab (the x0 loader pads its own end)
-      const int zc = ((L.out_dim + 15) & ~15) - L.out_dim;
-      for (int i = tid; i < FROWS * zc; i += 256) SH[(i / zc) * FLDH + L.out_dim + (i % zc)] = (__bf16)0.f;
-    }
+    SH = OUT;
     __syncthreads();
 #ifdef DSDF_LAB
     if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 3 + 3 * l] = __builtin_amdgcn_s_memtime();
@@ -869,7 +1018,7 @@ __device__ __forceinline__ void fused_forward_bf16_body(const FusedFwdArgs& p, f
 }
 
 __global__ __launch_bounds__(256, 1) void fused_forward_bf16_kernel(const FusedFwdArgs p) {
-  __shared__ __attribute__((aligned(16))) float S[FROWS * FLD];   // bf16 view for the hidden layers, fp32 for the output layer
+  __shared__ __attribute__((aligned(16))) float S[FROWS * FLD + 256];   // two bf16 slabs (133,120 B) for the hidden layers, one fp32 slab for the output layer
   __shared__ float4 xs[FROWS];
   __shared__ float hu[FHOIST][FMAXW];
   __shared__ float4 hwx[FHOIST][FMAXW];
@@ -1139,7 +1288,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_bwd_kernel(const FusedFwdArg
 
 // Config 5 training step: bf16 forward and fp32 backward of the same 64 points in one launch (same LDS plan as above).
 __global__ __launch_bounds__(256, 1) void fused_fwd_bf16_bwd_kernel(const FusedFwdArgs f, const FusedBwdArgs b) {
-  __shared__ __attribute__((aligned(16))) float S[FROWS * FLD];
+  __shared__ __attribute__((aligned(16))) float S[FROWS * FLD + 256];   // (two bf16 slabs in the forward half, see fused_forward_bf16_body)
   __shared__ float4 xs[FROWS];
   __shared__ float4 scratch[FHOIST * FMAXW + FHOIST * FMAXW / 4];
   float (*hu)[FMAXW] = reinterpret_cast<float (*)[FMAXW]>(scratch);
