@@ -127,7 +127,7 @@ struct Packed {
   int64_t scale_off;   // per-row weight-norm scales of all layers
   // fragment-ordered copies for the fused kernels: Wf (n = out, k = in), WTf (n = in, k = out)
   int64_t wf_off[DSDF_MAX_LAYERS], wtf_off[DSDF_MAX_LAYERS];
-  int64_t wfb_off[DSDF_MAX_LAYERS];   // bf16 copy of Wf (bf16 forward); offset in floats, half the size of Wf
+  int64_t wfb_off[DSDF_MAX_LAYERS];   // bf16 fragment copy of W for the bf16 forward (fused_bf16x8.hpp); offset in floats
   int uf[DSDF_MAX_LAYERS], utf[DSDF_MAX_LAYERS];   // k-units of 16 per n-tile
   int64_t total;
 };
@@ -149,7 +149,7 @@ Packed packed_layout(const DsdfNet* n) {
     p.utf[l] = 2 * ((n->out_dim[l] + 31) / 32);
     p.wf_off[l] = o;  o += ntw * p.uf[l] * 512;
     p.wtf_off[l] = o; o += ntt * p.utf[l] * 512;
-    p.wfb_off[l] = o; o += n->fwd_bf16 ? ntw * p.uf[l] * 256 : 0;
+    p.wfb_off[l] = o; o += n->fwd_bf16 ? ntw * 32 * 256 : 0;   // 32 phase-major k-unit slots of 1 KiB per n-tile
   }
   p.total = rup(o, 64);
   return p;
@@ -574,10 +574,13 @@ int run_fused_forward(const DsdfNet* net, const Plan& P, void* ws, const float* 
   if (!dbg && getenv("DSDF_LAB_DBG")) { (void)hipMalloc(&dbg, 8192 * 64 * 8); }
   a.dbg = dbg;
 #endif
-  if (net->fwd_bf16 && !store_act && !getenv("DSDF_BF16_FWD4"))   // inference form: 8 staggered waves (fused_bf16x8.hpp)
-    hipLaunchKernelGGL(fused_forward_bf16x8_kernel, dim3((unsigned)((n + FROWS - 1) / FROWS)), dim3(F8_THREADS), 0, st, a);
-  else if (net->fwd_bf16) hipLaunchKernelGGL(fused_forward_bf16_kernel, dim3((unsigned)((n + FROWS - 1) / FROWS)), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(fused_forward_kernel, dim3((unsigned)((n + FROWS - 1) / FROWS)), dim3(256), 0, st, a);
+  const dim3 grid((unsigned)((n + FROWS - 1) / FROWS));
+  if (net->fwd_bf16) {   // config 5: 8 staggered waves (fused_bf16x8.hpp); the training form keeps copies + mask words
+    if (store_act) hipLaunchKernelGGL(fused_forward_bf16x8_kernel<true>, grid, dim3(F8_THREADS), 0, st, a);
+    else hipLaunchKernelGGL(fused_forward_bf16x8_kernel<false>, grid, dim3(F8_THREADS), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(fused_forward_kernel, grid, dim3(256), 0, st, a);
+  }
 #ifdef DSDF_LAB
   if (dbg && getenv("DSDF_LAB_DBG")) {
     (void)hipDeviceSynchronize();
@@ -792,6 +795,7 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
   memset(&a, 0, sizeof(a));
   a.N = (int)n;
   a.head = head;
+  a.mask_t = net->fwd_bf16 ? 1 : 0;   // the 8-wave bf16 forward writes one 32-row word per column (fused_bf16x8.hpp)
   const bool segmode = sb != nullptr;
   const int ks = skip_layer(net);
   if (segmode) { a.xyz = sb->seg->xyz; a.G = sb->seg->G; }
@@ -827,8 +831,7 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     (void)wmac;
     if (fwd != nullptr) {
       ProfScope ps(DSDF_PROF_FUSED_FWD_BWD, 4.0 * (double)n * amac, st);   // forward + dX chain
-      if (net->fwd_bf16) hipLaunchKernelGGL(fused_fwd_bf16_bwd_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
-      else hipLaunchKernelGGL(fused_fwd_bwd_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
+      hipLaunchKernelGGL(fused_fwd_bwd_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);   // (fp32 only: see `merged`)
       LAUNCH_OK("fused_fwd_bwd_kernel");
     } else {
       ProfScope ps(DSDF_PROF_FUSED_BWD, 2.0 * (double)n * amac, st);
@@ -1306,7 +1309,8 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
   FusedSeg seg;
   memset(&seg, 0, sizeof(seg));
   FusedFwdArgs fwd_args;                                   // fp32 fused path: forward + backward go out as ONE launch below
-  bool merged = fusedb;
+  bool merged = fusedb && !net->fwd_bf16;   // (config 5: the bf16 forward is a launch of its own -- 512 threads, its own LDS plan)
+  if (getenv("DSDF_NO_MERGE")) merged = false;   // lab / tests: forward and backward as two launches in fp32 too
 #ifdef DSDF_LAB
   if (getenv("DSDF_LAB_DBG")) merged = false;   // lab builds: per-layer stamps are dumped after a forward launch of its own
 #endif

@@ -35,9 +35,7 @@ namespace dsdf {
 constexpr int FROWS = 64;        // points per workgroup
 constexpr int FLD = 516;         // slab row stride in floats
 constexpr int FMAXW = 512;       // widest layer the fused kernels handle
-#ifndef BF_ABLATE
-#define BF_ABLATE 0      // lab (bf16 forward): 1 = no weight loads inside the k-loop, 2 = no MFMAs, 4 = no A reads inside the k-loop,
-#endif                   //                     8 = no global activation stores in the forward epilogue
+                  //                     8 = no global activation stores in the forward epilogue
 #ifndef FUSED_STORE_AUX
 #define FUSED_STORE_AUX 2          // cache policy of the activation / dP copies (lab: 2 = nt, 16 = sc1 write-through)
 #endif
@@ -122,10 +120,9 @@ __device__ __forceinline__ constexpr int crow(int reg) { return (reg & 3) + 8 * 
 // Forward epilogue of one wave: bias + ReLU (+ dropout) on its 2x4 accumulators, written to the LDS slab (next
 // layer's input) and to the global activation copy.  Lean by construction: global stores are buffer stores (hardware
 // bounds check drops rows >= N and masked columns; row offsets are SCALAR), LDS stores use immediate offsets.
-constexpr int FLDH = 520;        // slab row stride in bf16 elements (bf16 forward, fused_forward_bf16_kernel)
+constexpr int FLDH = 520;        // slab row stride in bf16 elements (bf16 forward, fused_bf16x8.hpp)
 
-// HS: the slab holds bf16 (row stride FLDH) instead of fp32 (row stride FLD); the global activation copy stays fp32.
-template <bool DROP, bool EVEN, bool HS = false>
+template <bool DROP, bool EVEN>
 __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[2][4], const float (&biasv)[4], float* S,
                                                    const FusedLayer& L, int w, int fr, int fh, int row0, int N,
                                                    uint32_t row_offset) {
@@ -168,15 +165,9 @@ __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[2][4], co
               v1 = (hb & 0xFFFFu) >= L.drop_thr ? v1 * L.drop_scale : 0.f;
             }
           }
-          if constexpr (HS) {
-            __bf16* hp = reinterpret_cast<__bf16*>(S) + (4 * fh) * FLDH + col;
-            hp[rc * FLDH] = (__bf16)v0;
-            hp[(rc + 1) * FLDH] = (__bf16)v1;
-          } else {
-            sp[rc * FLD] = v0;
-            sp[(rc + 1) * FLD] = v1;
-          }
-          if (!(BF_ABLATE & 8) && has_out) {   // (inference keeps no copies: 128 dropped stores per lane and layer still cost their issue)
+          sp[rc * FLD] = v0;
+          sp[(rc + 1) * FLD] = v1;
+          if (has_out) {   // (inference keeps no copies: 128 dropped stores per lane and layer still cost their issue)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rsrc, voff, rc * ldb, FUSED_STORE_AUX);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rsrc, voff, (rc + 1) * ldb, FUSED_STORE_AUX);
           }
@@ -544,486 +535,9 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(const FusedFwdArg
 }
 
 // ===================================================================================================================
-// BASELINE config 5: the same forward with bf16 GEMM inputs and fp32 accumulation on v_mfma_f32_32x32x16_bf16.
-// Every hidden Linear sees its input rounded to bf16 (the slab holds bf16) and its weight rounded to bf16 (Wfb, written
-// by wn_tiles_kernel: fragment order, lane (r, h) holds k = 16u + 8h + j, j = 0..7, in ONE 16-byte load -- exactly the
-// instruction's operand layout); bias, ReLU, dropout, the stored activation copies (fp32, for the fp32 backward and dW
-// GEMMs), the 512->1 output layer and everything after it stay fp32.  Specification: oracle decoder_forward(bf16=True).
-//
-// Bound: one k-unit of 16 is ONE MFMA per tile (32 cycles) instead of eight fp32 ones (512), so a wave's 8 tiles consume
-// 4 KiB of weights per 256 cycles: 64 points per CU need the layer's 0.5 MB from L2 in the 3.5 us its MFMAs take --
-// 143 GB/s per CU against the ~70 GB/s an XCD's L2 sustains for rows every workgroup shares (MI355X_MICROARCH.md, L2).
-// The k-loop is therefore L2-BANDWIDTH bound (~7 us per 512x512 layer), and what the kernel has to do is keep that stream
-// saturated: a ring of BF_RING k-units of weights per wave in registers (3 units = 12 KiB per wave in flight, 48 KiB per CU
-// ~ bandwidth x L2 latency), refilled one unit per step, and the NEXT layer's first units requested before the epilogue so
-// the stream does not stop while the VALU works.  (bf16 MFMAs do not block the VALU, unlike the fp32 ones -- tools/lab/
-// mfma_valu.hip -- so nothing here needs the fp32 kernel's scalar-address tricks.)
-// Segment mode works as in the fp32 kernel: rounding is element-wise on the operands, so W[:, lat] latent_s is still one
-// vector per scene (seg_hoist_kernel with bf16-rounded operands), and the xyz product is done on bf16-rounded values.
+// BASELINE config 5 (bf16 forward GEMMs, fp32 accumulate): fused_bf16x8.hpp.  Shared pieces:
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-#ifndef BF_RING_UNITS
-#define BF_RING_UNITS 4
-#endif
-constexpr int BF_RING = BF_RING_UNITS;     // even
-
 __device__ __forceinline__ float bf16_round(float x) { return (float)(__bf16)x; }
-
-// rows of x0 (fp32, global) into bf16 slab columns [col0, col0 + W0) + zero pad up to a multiple of 16.  As in fused_load_x0
-// all loads of a pass are issued back-to-back BEFORE the first LDS write (a load-use loop pays the memory latency per trip:
-// 68 trips for a 259-wide x0 cost ~35 us per call).
-__device__ __forceinline__ void fused_load_x0_h(__bf16* S, const float* x0, int ldx0, int W0, int row0, int N, int col0) {
-  constexpr int XCH = 24;
-  const int zc = (((col0 + W0) + 15) & ~15) - col0;      // columns written incl. the zero pad
-  const int total = FROWS * zc;
-  for (int base = 0; base < total; base += 256 * XCH) {
-    float v[XCH];
-#pragma unroll
-    for (int k = 0; k < XCH; ++k) {
-      const int i = base + threadIdx.x + 256 * k;
-      v[k] = 0.f;
-      if (i < total) {
-        const int r = i / zc, c = i - r * zc;
-        if (c < W0 && row0 + r < N) v[k] = x0[(size_t)(row0 + r) * ldx0 + c];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < XCH; ++k) {
-      const int i = base + threadIdx.x + 256 * k;
-      if (i < total) {
-        const int r = i / zc, c = i - r * zc;
-        S[r * FLDH + col0 + c] = (__bf16)v[k];
-      }
-    }
-  }
-}
-
-// ONE k-unit of the next layer's weights travels across the epilogue (16 VGPRs); the ring itself lives only inside the
-// k-loop: a ring kept alive across the epilogue made the compiler spill ~600 scratch accesses per layer into it
-// (1.2 GB of scratch traffic per forward: ring 4 ran 30 % SLOWER than ring 2 until the ring became loop-local).
-#ifndef BF_PIPELINED
-#define BF_PIPELINED 0      // lab: 1 = 512x512 layers run their n-tiles one after the other with the previous n-tile's epilogue woven into the k-loop (measured SLOWER)
-#endif
-#ifndef BF_PIPE_DEPTH
-#define BF_PIPE_DEPTH 16    // pipelined layer: (n-tile, k-unit) weight fragments in flight per wave (1 KiB each; the L2 needs >= 24 KiB per CU)
-#endif
-#ifndef BF_PRE_UNITS
-#define BF_PRE_UNITS 1      // k-units of the next layer requested before the epilogue (1 .. BF_RING_UNITS - 1)
-#endif
-constexpr int BF_PRE = BF_PRE_UNITS;
-struct Bf16Pre { bf16x8 b[BF_PRE][4]; };
-
-// Every workgroup walks the k-units of a layer in its OWN rotated order (unit (u + rot) mod nu): 32 CUs of an XCD that all
-// stream the same weights in the same order at the same pace keep hitting ONE L2 channel at a time.  A rotation of the
-// contraction order only permutes the fp32 summation; it is a fixed function of the workgroup index, so results stay
-// run-to-run bit-identical.
-#ifndef BF_ROTATE
-#define BF_ROTATE 1
-#endif
-__device__ __forceinline__ int bf16_rot(int nu) {
-#if BF_ROTATE
-  return nu > 0 ? (int)(((blockIdx.x >> 3) * (unsigned)nu) >> 5) % nu : 0;   // blocks b, b+8, ... share an XCD (common.hpp)
-#else
-  return 0;
-#endif
-}
-
-// Weights come through a buffer resource with SCALAR offsets (as in the fp32 kernel's FusedBView): the first version built a
-// 64-bit address per load on the VALU -- 48 vector + 40 scalar instructions per 32 MFMAs, more than fits into the shadow of
-// 32-cycle MFMAs (the MFMA stream alone ran at 1.6x its ideal time).  Unit (n-tile t, k-unit u) = 1 KiB at ((t U + u) << 10).
-struct Bf16BView { __amdgpu_buffer_rsrc_t rsrc; int tb[4]; int voff; };
-__device__ __forceinline__ Bf16BView bf16_bview(const __bf16* wfb, int U, int w, int lane) {
-  Bf16BView v;
-  v.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wfb, 0, 0x7FFFFFFF, 0x00020000);
-  const int ws = __builtin_amdgcn_readfirstlane(w);
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni) v.tb[ni] = (ws + 4 * ni) * U;
-  v.voff = lane * 16;
-  return v;
-}
-template <int NACT>
-__device__ __forceinline__ void bf16_load_unit(bf16x8 (&dst)[4], const Bf16BView& B, int u) {
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-  for (int ni = 0; ni < NACT; ++ni) {
-    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(B.rsrc, B.voff, (B.tb[ni] + u) << 10, 0);
-    dst[ni] = __builtin_bit_cast(bf16x8, r);
-  }
-}
-// the FIRST k-unit (of this workgroup's order) of a layer, requested before the previous layer's epilogue
-__device__ __forceinline__ void bf16_prefetch(Bf16Pre& P, const __bf16* wfb, int U, int w, int lane, int nact, int nu) {
-  if (nu <= 0) return;
-  const Bf16BView B = bf16_bview(wfb, U, w, lane);
-  int u = bf16_rot(nu);
-#pragma unroll
-  for (int q = 0; q < BF_PRE; ++q) {          // unconditional (units wrap): every slot is defined, nothing stays live from before
-    switch (nact) {
-      case 4: bf16_load_unit<4>(P.b[q], B, u); break;
-      case 3: bf16_load_unit<3>(P.b[q], B, u); break;
-      case 2: bf16_load_unit<2>(P.b[q], B, u); break;
-      case 1: bf16_load_unit<1>(P.b[q], B, u); break;
-      default: break;
-    }
-    u = u + 1 == nu ? 0 : u + 1;
-  }
-}
-
-// acc[m][ni] += S[64 rows][16 nu] * Wfb; P holds the first unit (bf16_prefetch).  Units are walked in the rotated order
-// rot, rot+1, ..., wrapping at nu; prefetches past the last unit simply wrap too (valid memory, never used), so the loop
-// carries two running SCALAR unit counters and no clamps.
-template <int NACT>
-__device__ __forceinline__ void bf16_kloop(f32x16 (&acc)[2][4], const __bf16* ap, const __bf16* wfb, int U, int w, int lane,
-                                           int nu, const Bf16Pre& P) {
-  bf16x8 ring[BF_RING][4];
-  bf16x8 a0[2], a1[2];
-  const Bf16BView B = bf16_bview(wfb, U, w, lane);
-  auto nextu = [&](int u) { return u + 1 == nu ? 0 : u + 1; };
-  int ub = bf16_rot(nu), ua = bf16_rot(nu);          // next unit to request / next unit's rows to read
-#pragma unroll
-  for (int q = 0; q < BF_PRE; ++q) ub = nextu(ub);   // (the first BF_PRE units came with P)
-  auto readA = [&](bf16x8 (&a)[2]) {
-    if (!(BF_ABLATE & 4) || ua == bf16_rot(nu)) {
-      a[0] = *reinterpret_cast<const bf16x8*>(ap + 16 * ua);
-      a[1] = *reinterpret_cast<const bf16x8*>(ap + 32 * FLDH + 16 * ua);
-    }
-    ua = nextu(ua);
-  };
-  auto loadB = [&](bf16x8 (&dst)[4]) {
-    if (!(BF_ABLATE & 1)) bf16_load_unit<NACT>(dst, B, ub);
-    ub = nextu(ub);
-  };
-  auto mma = [&](const bf16x8 (&a)[2], const bf16x8 (&b)[4]) {
-    if (BF_ABLATE & 2) return;
-#pragma unroll
-    for (int ni = 0; ni < NACT; ++ni) {
-      acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[ni], acc[0][ni], 0, 0, 0);
-      acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[ni], acc[1][ni], 0, 0, 0);
-    }
-  };
-#pragma unroll
-  for (int q = 0; q < BF_PRE; ++q)
-#pragma unroll
-    for (int ni = 0; ni < NACT; ++ni) ring[q][ni] = P.b[q][ni];
-#pragma unroll
-  for (int q = BF_PRE; q < BF_RING - 1; ++q) loadB(ring[q]);   // unconditional: every slot is defined here
-  readA(a0);
-  int s = 0;
-  for (; s + BF_RING <= nu; s += BF_RING) {   // static ring slots; one unit refilled per step, BF_RING - 1 steps ahead
-#pragma unroll
-    for (int q = 0; q < BF_RING; q += 2) {
-      loadB(ring[(q + BF_RING - 1) % BF_RING]);
-      readA(a1);
-      mma(a0, ring[q]);
-      loadB(ring[q % BF_RING]);
-      readA(a0);
-      mma(a1, ring[q + 1]);
-    }
-  }
-  // tail: the remaining (< BF_RING) units sit in ring slots 0 .. rem-1; a0 holds the rows of position s
-#pragma unroll
-  for (int q = 0; q < BF_RING - 1; ++q) {
-    if (s + q < nu) {
-      if (q & 1) { readA(a0); mma(a1, ring[q]); }
-      else { readA(a1); mma(a0, ring[q]); }
-    }
-  }
-}
-
-__device__ __forceinline__ void bf16_kloop_dispatch(f32x16 (&acc)[2][4], const __bf16* ap, const __bf16* wfb, int U, int w,
-                                                    int lane, int nu, int nact, const Bf16Pre& P) {
-  switch (nact) {
-    case 4: bf16_kloop<4>(acc, ap, wfb, U, w, lane, nu, P); break;
-    case 3: bf16_kloop<3>(acc, ap, wfb, U, w, lane, nu, P); break;
-    case 2: bf16_kloop<2>(acc, ap, wfb, U, w, lane, nu, P); break;
-    case 1: bf16_kloop<1>(acc, ap, wfb, U, w, lane, nu, P); break;
-    default: break;
-  }
-}
-
-// ---- pipelined layer (BF_PIPELINED): the epilogue hidden under the weight stream -------------------------------------------
-// The plain layer above is  [k-loop of all 4 n-tiles: 17 k cycles, L2-bound]  then  [epilogue of all 4: 8-13 k cycles, VALU]  in
-// series.  bf16 MFMAs leave the VALU free and the k-loop spends half its time waiting for weights, so here the 4 n-tiles of a
-// wave run ONE AFTER THE OTHER (n-tile j over all 32 k-units, both m-tiles), and the epilogue of n-tile j-1 -- bias, ReLU,
-// dropout hash, convert, LDS / global stores, mask bits; one row pair per two k-units -- is woven into the k-loop of n-tile j.
-// Only the last n-tile's epilogue stays exposed.  Same weight bytes (every n-tile's weights are still streamed once); the layer
-// input is read 4x from LDS instead of once (LDS is idle).  Needs a SECOND slab: the output goes to the other buffer while
-// later n-tiles still read the input (2 x 66.5 KB of the 160 KB), which also drops one of the two barriers per layer.
-// Fully unrolled (128 steps of (n-tile, unit)): layers with K = 512 and all 16 n-tiles only; anything else takes the plain path.
-struct Bf16Epi {
-  __amdgpu_buffer_rsrc_t rsrc; int ldb; bool has_out;
-  float bias[4]; uint32_t ck[4]; uint32_t pm; uint32_t drop_thr; float drop_scale;
-  __bf16* outp;          // OUT slab + (4 fh) * FLDH + fr   (+ 32 (w + 4 ni) per n-tile)
-  uint32_t voff0;        // ((4 fh) * ld_out + fr) * 4      (+ 128 (w + 4 ni) per n-tile)
-  int w;
-};
-template <int NI, int PAIR, bool DROP, bool EVEN, bool OUT>   // OUT: global activation copies are kept (training / module path)
-__device__ __forceinline__ void bf16_epi_pair(const f32x16 (&acc)[2][4], const Bf16Epi& E, uint32_t (&mq)[4]) {
-  constexpr int m = PAIR >> 3, rp = PAIR & 7;
-  constexpr int rc = 32 * m + crow(2 * rp);
-  float v0 = fmaxf(acc[m][NI][2 * rp] + E.bias[NI], 0.f), v1 = fmaxf(acc[m][NI][2 * rp + 1] + E.bias[NI], 0.f);
-  if constexpr (DROP) {
-    if constexpr (EVEN) {
-      const uint32_t h = lowbias32(E.ck[NI] ^ (E.pm + (uint32_t)(rc >> 1) * 0x9E3779B1u));
-      v0 = (h & 0xFFFFu) >= E.drop_thr ? v0 * E.drop_scale : 0.f;
-      v1 = (h >> 16) >= E.drop_thr ? v1 * E.drop_scale : 0.f;
-    } else {
-      const uint32_t ha = lowbias32(E.ck[NI] ^ (E.pm + (uint32_t)(rc >> 1) * 0x9E3779B1u));
-      const uint32_t hb = lowbias32(E.ck[NI] ^ (E.pm + (uint32_t)((rc >> 1) + 1) * 0x9E3779B1u));
-      v0 = (ha >> 16) >= E.drop_thr ? v0 * E.drop_scale : 0.f;
-      v1 = (hb & 0xFFFFu) >= E.drop_thr ? v1 * E.drop_scale : 0.f;
-    }
-  }
-  __bf16* hp = E.outp + 32 * (E.w + 4 * NI);
-  hp[rc * FLDH] = (__bf16)v0;
-  hp[(rc + 1) * FLDH] = (__bf16)v1;
-  if constexpr (OUT) {     // (a run-time branch here splits the woven stream into hundreds of basic blocks with spills around each)
-    const uint32_t voff = E.voff0 + 128u * (uint32_t)(E.w + 4 * NI);
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), E.rsrc, voff, rc * E.ldb, FUSED_STORE_AUX);
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), E.rsrc, voff, (rc + 1) * E.ldb, FUSED_STORE_AUX);
-  }
-  const uint32_t b2 = (v0 > 0.f ? 1u : 0u) | (v1 > 0.f ? 2u : 0u);
-  mq[2 * m + (NI >> 1)] |= b2 << (16 * (NI & 1) + 2 * rp);
-}
-
-// every index below (step, n-tile, unit position, ring slot, accumulator register) is a compile-time constant: the 128 steps are
-// expanded through an integer sequence, not through a loop the compiler may or may not unroll
-template <bool DROP, bool EVEN, bool OUT>
-struct Bf16Pipe {
-  static constexpr int NU = 32, NS = 4 * NU, D = BF_PIPE_DEPTH;
-  f32x16 (&acc)[2][4];
-  const __bf16* ap; const Bf16BView& B; const int rot; const Bf16Pre& P; const Bf16Epi& E; uint32_t (&mq)[4];
-  bf16x8 ring[D];
-  bf16x8 a[2][2];                               // A fragments of the current / next step, alternating
-
-  __device__ __forceinline__ void load(bf16x8& dst, int tile, int q) const {
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const int u = (rot + q) & (NU - 1);
-    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(B.rsrc, B.voff, (B.tb[tile] + u) << 10, 0);
-    dst = __builtin_bit_cast(bf16x8, r);
-  }
-  __device__ __forceinline__ void readA(bf16x8 (&x)[2], int q) const {
-    const int u = (rot + q) & (NU - 1);
-    x[0] = *reinterpret_cast<const bf16x8*>(ap + 16 * u);
-    x[1] = *reinterpret_cast<const bf16x8*>(ap + 32 * FLDH + 16 * u);
-  }
-  template <int S>
-  __device__ __forceinline__ void step() {
-    constexpr int ni = S / NU, q = S % NU, nx = S + D - 1;
-    if constexpr (nx < NS) {
-      if constexpr (nx % NU == 0) ring[nx % D] = P.b[0][nx / NU];     // first unit of the next n-tile: came with the cross-layer prefetch
-      else load(ring[nx % D], nx / NU, nx % NU);
-    }
-    if constexpr (S + 1 < NS) readA(a[(S + 1) & 1], (S + 1) % NU);
-    acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[S & 1][0], ring[S % D], acc[0][ni], 0, 0, 0);
-    acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[S & 1][1], ring[S % D], acc[1][ni], 0, 0, 0);
-    if constexpr (ni > 0 && (q & 1) == 0) bf16_epi_pair<ni - 1, q / 2, DROP, EVEN, OUT>(acc, E, mq);   // one row pair of the PREVIOUS n-tile
-    __builtin_amdgcn_sched_barrier(0);   // keep the steps in program order: left alone, the scheduler hoists the loads of many
-  }                                      // steps to the top and spills the ring
-  template <int... S>
-  __device__ __forceinline__ void steps(std::integer_sequence<int, S...>) { (step<S>(), ...); }
-  template <int... PR>
-  __device__ __forceinline__ void last_tile(std::integer_sequence<int, PR...>) { (bf16_epi_pair<3, PR, DROP, EVEN, OUT>(acc, E, mq), ...); }
-
-  __device__ __forceinline__ void run_steps() {
-    ring[0] = P.b[0][0];
-#pragma unroll
-    for (int s = 1; s < D - 1; ++s) load(ring[s], 0, s);
-    readA(a[0], 0);
-    steps(std::make_integer_sequence<int, NS>{});
-  }
-  __device__ __forceinline__ void run_last() { last_tile(std::make_integer_sequence<int, 16>{}); }   // stays exposed
-};
-
-// next != nullptr: the NEXT layer's first units are requested between the woven part and the exposed last-tile epilogue
-template <bool DROP, bool EVEN, bool OUT>
-__device__ __forceinline__ void bf16_layer_pipelined(f32x16 (&acc)[2][4], const __bf16* ap, const __bf16* wfb, int U, int w, int lane,
-                                                     Bf16Pre& P, const Bf16Epi& E, uint32_t (&mq)[4], const FusedLayer* next) {
-  const Bf16BView B = bf16_bview(wfb, U, w, lane);
-  Bf16Pipe<DROP, EVEN, OUT> pipe{acc, ap, B, bf16_rot(32), P, E, mq};
-  pipe.run_steps();
-  if (next != nullptr)    // (P's last use was step 96: it can take the next layer's units now)
-    bf16_prefetch(P, reinterpret_cast<const __bf16*>(next->wf), next->U, w, lane, fused_nact(next->out_dim, w), (next->in + 15) >> 4);
-  pipe.run_last();
-}
-
-// S: the slab (bf16 view for the hidden layers; the LAST hidden activation is written as fp32, row stride FLD, for the fp32
-// output layer / backward head).  Segment mode: xs / hu / hwx as in fused_forward_body, all values rounded to bf16.
-__device__ __forceinline__ void fused_forward_bf16_body(const FusedFwdArgs& p, float* S, float4* xs, float (*hu)[FMAXW],
-                                                        float4 (*hwx)[FMAXW]) {
-  // two bf16 slabs (2 x 66.5 KB): a layer reads one and writes the other, so nothing is overwritten in place -- one barrier per
-  // layer instead of two, and the pipelined layers can write their output while later n-tiles still read the input
-  __bf16* SHA = reinterpret_cast<__bf16*>(S);
-  __bf16* SHB = SHA + FROWS * FLDH;
-  __bf16* SH = SHA;                       // the current layer's INPUT slab
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int fr = lane & 31, fh = lane >> 5;
-  const int row0 = blockIdx.x * FROWS;
-  const bool segm = p.seg.wg_per_seg > 0;
-  Bf16Pre R;
-  const int lfirst = (segm && p.n_hidden > 1) ? 1 : 0;
-  bf16_prefetch(R, reinterpret_cast<const __bf16*>(p.ly[lfirst].wf), p.ly[lfirst].U, w, lane,
-                fused_nact(p.ly[lfirst].out_dim, w), (p.ly[lfirst].in + 15) >> 4);
-  if (segm) {
-    if (tid < FROWS) {
-      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row0 + tid < p.N) {
-        const float* q = p.seg.xyz + (size_t)(row0 + tid) * p.seg.G;
-        x.x = bf16_round(q[0]);
-        if (p.seg.G > 1) x.y = bf16_round(q[1]);
-        if (p.seg.G > 2) x.z = bf16_round(q[2]);
-        if (p.seg.G > 3) x.w = bf16_round(q[3]);
-      }
-      xs[tid] = x;
-    }
-    const int sidx = blockIdx.x / p.seg.wg_per_seg;
-#pragma unroll
-    for (int t = 0; t < FHOIST; ++t) {
-      const FusedHoist& H = p.seg.h[t];
-      if (H.layer < 0) continue;
-      const int od = p.ly[H.layer].out_dim;
-      for (int c = tid; c < od; c += 256) {
-        hu[t][c] = p.seg.U[((size_t)sidx * FHOIST + t) * p.seg.ldu + c];
-        const float* q = H.wx + (size_t)c * H.ldw;
-        float4 x = make_float4(bf16_round(q[0]), 0.f, 0.f, 0.f);
-        if (p.seg.G > 1) x.y = bf16_round(q[1]);
-        if (p.seg.G > 2) x.z = bf16_round(q[2]);
-        if (p.seg.G > 3) x.w = bf16_round(q[3]);
-        hwx[t][c] = x;
-      }
-    }
-  } else {
-    fused_load_x0_h(SH, p.x0, p.ldx0, p.W0, row0, p.N, 0);
-  }
-  __syncthreads();
-#ifdef DSDF_LAB
-  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 0] = __builtin_amdgcn_s_memtime();
-#endif
-  for (int l = 0; l < p.n_hidden; ++l) {
-    const FusedLayer& L = p.ly[l];
-    const int nu = (L.in + 15) >> 4, nact = fused_nact(L.out_dim, w);
-    f32x16 acc[2][4];
-    float biasv[4];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int col = 32 * (w + 4 * ni) + fr;
-      biasv[ni] = col < L.out_dim ? L.bias[col] : 0.f;
-    }
-    int hidx = -1;
-    if (segm) hidx = l == p.seg.h[0].layer ? 0 : (l == p.seg.h[1].layer ? 1 : -1);
-    if (hidx >= 0) {
-      fused_hoist_init(acc, hu[hidx], hwx[hidx], xs, L.out_dim, w, fr, fh);
-    } else {
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[m][ni][r] = 0.f;
-    }
-    const bool last_hidden = l + 1 == p.n_hidden;
-    __bf16* OUT = SH == SHA ? SHB : SHA;      // this layer's OUTPUT slab (the last hidden layer writes fp32 over both instead)
-    const bool drop = L.drop_thr != 0u;
-    const bool even = ((p.row_offset + (uint32_t)row0) & 1u) == 0u;
-#if BF_PIPELINED
-    if (hidx < 0 && !last_hidden && L.x0_col < 0 && nu == 32 && L.out_dim == 512 &&
-        (L.out != nullptr || !drop)) {   // epilogue woven into the k-loop (no variant for "dropout without activation copies": plain path)
-      Bf16Epi E;
-      const int rows_here = min(FROWS, p.N - row0);
-      E.has_out = L.out != nullptr;
-      E.rsrc = __builtin_amdgcn_make_buffer_rsrc(E.has_out ? (void*)(L.out + (size_t)row0 * L.ld_out) : (void*)S, 0,
-                                                 E.has_out ? rows_here * L.ld_out * 4 : 0, 0x00020000);
-      E.ldb = L.ld_out * 4;
-      E.pm = ((p.row_offset + (uint32_t)(row0 + 4 * fh)) >> 1) * 0x9E3779B1u;
-      E.drop_thr = L.drop_thr; E.drop_scale = L.drop_scale; E.w = w;
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) { E.bias[ni] = biasv[ni]; E.ck[ni] = drop_col_key((uint32_t)(32 * (w + 4 * ni) + fr), L.drop_key); }
-      E.outp = OUT + (4 * fh) * FLDH + fr;
-      E.voff0 = (uint32_t)((4 * fh) * E.ldb + fr * 4);
-      uint32_t mq[4] = {0u, 0u, 0u, 0u};
-      const __bf16* ap = SH + fr * FLDH + 8 * fh;
-      const __bf16* wfb = reinterpret_cast<const __bf16*>(L.wf);
-      if (!E.has_out) bf16_layer_pipelined<false, true, false>(acc, ap, wfb, L.U, w, lane, R, E, mq, &p.ly[l + 1]);   // inference: no dropout either
-      else if (!drop) bf16_layer_pipelined<false, true, true>(acc, ap, wfb, L.U, w, lane, R, E, mq, &p.ly[l + 1]);
-      else if (even) bf16_layer_pipelined<true, true, true>(acc, ap, wfb, L.U, w, lane, R, E, mq, &p.ly[l + 1]);
-      else bf16_layer_pipelined<true, false, true>(acc, ap, wfb, L.U, w, lane, R, E, mq, &p.ly[l + 1]);
-      if (L.maskbits != nullptr)
-        *reinterpret_cast<uint4*>(L.maskbits + ((size_t)blockIdx.x * 256 + threadIdx.x) * 4) = make_uint4(mq[0], mq[1], mq[2], mq[3]);
-#ifdef DSDF_LAB
-      if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 64 + 1 + 3 * l] = __builtin_amdgcn_s_memtime(); p.dbg[blockIdx.x * 64 + 2 + 3 * l] = p.dbg[blockIdx.x * 64 + 1 + 3 * l]; }
-#endif
-    } else
-#endif
-    {
-      if (nu > 0) {
-        bf16_kloop_dispatch(acc, SH + fr * FLDH + 8 * fh, reinterpret_cast<const __bf16*>(L.wf), L.U, w, lane, nu, nact, R);
-        if (l + 1 < p.n_hidden) {   // the next layer's first units travel while this layer's epilogue runs
-          const FusedLayer& Ln = p.ly[l + 1];
-          bf16_prefetch(R, reinterpret_cast<const __bf16*>(Ln.wf), Ln.U, w, lane, fused_nact(Ln.out_dim, w), (Ln.in + 15) >> 4);
-        }
-      }
-#ifdef DSDF_LAB
-      if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 1 + 3 * l] = __builtin_amdgcn_s_memtime();
-#endif
-      if (last_hidden) __syncthreads();   // its fp32 output covers BOTH bf16 slabs: every wave must have finished reading its input
-#ifdef DSDF_LAB
-      if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 2 + 3 * l] = __builtin_amdgcn_s_memtime();
-#endif
-      if (L.x0_col >= 0) fused_load_x0_h(OUT, p.x0, p.ldx0, p.W0, row0, p.N, L.x0_col);
-      if (last_hidden) {   // the output layer / the backward head read fp32: its input goes to the slab as fp32
-        if (!drop) fused_fwd_epilogue<false, true, false>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
-        else if (even) fused_fwd_epilogue<true, true, false>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
-        else fused_fwd_epilogue<true, false, false>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
-      } else {
-        float* OS = reinterpret_cast<float*>(OUT);
-        if (!drop) fused_fwd_epilogue<false, true, true>(acc, biasv, OS, L, w, fr, fh, row0, p.N, p.row_offset);
-        else if (even) fused_fwd_epilogue<true, true, true>(acc, biasv, OS, L, w, fr, fh, row0, p.N, p.row_offset);
-        else fused_fwd_epilogue<true, false, true>(acc, biasv, OS, L, w, fr, fh, row0, p.N, p.row_offset);
-      }
-      if (!last_hidden && L.x0_col < 0) {      // zero pad [out_dim, roundup16) of the bf16 slab (the x0 loader pads its own end)
-        const int zc = ((L.out_dim + 15) & ~15) - L.out_dim;
-        for (int i = tid; i < FROWS * zc; i += 256) OUT[(i / zc) * FLDH + L.out_dim + (i % zc)] = (__bf16)0.f;
-      }
-    }
-    SH = OUT;
-    __syncthreads();
-#ifdef DSDF_LAB
-    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 3 + 3 * l] = __builtin_amdgcn_s_memtime();
-#endif
-  }
-  if (p.y_out == nullptr && p.u_out == nullptr) return;   // training: the backward head recomputes the output layer from the slab
-  float4 qv[2];
-#pragma unroll
-  for (int cc = 0; cc < 2; ++cc) {
-    const int c = 4 * lane + 256 * cc;
-    qv[cc] = c < p.in_last ? *reinterpret_cast<const float4*>(p.w_last + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  const float blast = p.b_last[0];
-  for (int rr = 0; rr < FROWS / 4; ++rr) {
-    const int row = (FROWS / 4) * w + rr;
-    float dot = 0.f;
-#pragma unroll
-    for (int cc = 0; cc < 2; ++cc) {
-      const int c = 4 * lane + 256 * cc;
-      if (c < p.in_last) {
-        const float4 a = *reinterpret_cast<const float4*>(S + row * FLD + c);
-        dot += a.x * qv[cc].x + a.y * qv[cc].y + a.z * qv[cc].z + a.w * qv[cc].w;
-      }
-    }
-    const float u = wave_sum(dot) + blast;
-    const float t1 = p.use_tanh ? tanhf(u) : u;
-    if (lane == 0 && row0 + row < p.N) {
-      if (p.y_out) p.y_out[row0 + row] = tanhf(t1);
-      if (p.u_out) p.u_out[row0 + row] = u;
-    }
-  }
-}
-
-__global__ __launch_bounds__(256, 1) void fused_forward_bf16_kernel(const FusedFwdArgs p) {
-  __shared__ __attribute__((aligned(16))) float S[FROWS * FLD + 256];   // two bf16 slabs (133,120 B) for the hidden layers, one fp32 slab for the output layer
-  __shared__ float4 xs[FROWS];
-  __shared__ float hu[FHOIST][FMAXW];
-  __shared__ float4 hwx[FHOIST][FMAXW];
-  fused_forward_bf16_body(p, S, xs, hu, hwx);
-}
 
 // ===================================================================================================================
 // Fused backward dX chain.  Slab = dP_l [64][out_l]; per layer l = last-1 .. 1:
@@ -1060,6 +574,8 @@ struct FusedBwdHead {
 };
 struct FusedBwdArgs {
   int n_layers, N;                 // entries of ly[], processed in order (deepest layer first)
+  int mask_t;                      // 0: maskbits as fused_fwd_epilogue writes them; 1: [n_wg][2 m][FMAXW columns], bit r of word (m, c) =
+                                   //    output[32m + r][c] > 0 (the 8-wave bf16 forward, fused_bf16x8.hpp)
   const float* dp_in; int ld_in; int w_in;   // HEAD_DP_GIVEN: dP of the deepest hidden layer [N][ld_in], w_in columns
   const float* xyz; int G;                   // segment mode ([N][G], G <= FGEO), else nullptr
   FusedBwdHead head;
@@ -1248,7 +764,22 @@ __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float
     const FusedBView bv = fused_bview(L.wtf, L.U, w, lane);
     const float* ap = S + fr * FLD + 8 * fh;
     uint4 mq = make_uint4(0u, 0u, 0u, 0u);
-    if (L.maskbits != nullptr) mq = *reinterpret_cast<const uint4*>(L.maskbits + ((size_t)blockIdx.x * 256 + tid) * 4);
+    if (L.maskbits != nullptr) {
+      if (!p.mask_t) {
+        mq = *reinterpret_cast<const uint4*>(L.maskbits + ((size_t)blockIdx.x * 256 + tid) * 4);
+      } else {   // one word per (m, column) with the rows in natural order: pick this lane's 16 rows (crow(r) + 4 fh) into the usual order
+        uint32_t q[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            const uint32_t x = L.maskbits[(size_t)blockIdx.x * (2 * FMAXW) + m * FMAXW + 32 * (w + 4 * ni) + fr] >> (4 * fh);
+            const uint32_t pk = (x & 0xFu) | ((x >> 4) & 0xF0u) | ((x >> 8) & 0xF00u) | ((x >> 12) & 0xF000u);
+            q[2 * m + (ni >> 1)] |= pk << (16 * (ni & 1));
+          }
+        mq = make_uint4(q[0], q[1], q[2], q[3]);
+      }
+    }
     fused_kloop_dispatch(acc, ap, bv, nu, fused_nact(L.ncols, w), PB);
     if (i + 1 < p.n_layers) {
       const FusedBwdLayer& Ln = p.ly[i + 1];
@@ -1283,21 +814,6 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_bwd_kernel(const FusedFwdArg
   float (*hsc)[2] = reinterpret_cast<float (*)[2]>(scratch + 4 * 2 * FMAXW / 4);
   fused_forward_body(f, S, xs, hu, hwx, 150 * 1024);
   __syncthreads();
-  fused_backward_body(b, S, xs, hred, hsc, true);
-}
-
-// Config 5 training step: bf16 forward and fp32 backward of the same 64 points in one launch (same LDS plan as above).
-__global__ __launch_bounds__(256, 1) void fused_fwd_bf16_bwd_kernel(const FusedFwdArgs f, const FusedBwdArgs b) {
-  __shared__ __attribute__((aligned(16))) float S[FROWS * FLD + 256];   // (two bf16 slabs in the forward half, see fused_forward_bf16_body)
-  __shared__ float4 xs[FROWS];
-  __shared__ float4 scratch[FHOIST * FMAXW + FHOIST * FMAXW / 4];
-  float (*hu)[FMAXW] = reinterpret_cast<float (*)[FMAXW]>(scratch);
-  float4 (*hwx)[FMAXW] = reinterpret_cast<float4 (*)[FMAXW]>(scratch + FHOIST * FMAXW / 4);
-  float (*hred)[2 * FMAXW] = reinterpret_cast<float (*)[2 * FMAXW]>(scratch);
-  float (*hsc)[2] = reinterpret_cast<float (*)[2]>(scratch + 4 * 2 * FMAXW / 4);
-  fused_forward_bf16_body(f, S, xs, hu, hwx);
-  __syncthreads();
-  // (the backward body refills xs with the UNROUNDED xyz: the fp32 backward / dW use the fp32 layer inputs)
   fused_backward_body(b, S, xs, hred, hsc, true);
 }
 

@@ -25,22 +25,31 @@ namespace dsdf {
 
 constexpr int F8_THREADS = 512;
 #ifndef BF8_RING_UNITS
-#define BF8_RING_UNITS 4
+#define BF8_RING_UNITS 6
 #endif
-constexpr int BF8_RING = BF8_RING_UNITS;   // even; k-units of weights in flight per wave (2 KiB each)
+constexpr int BF8_RING = BF8_RING_UNITS;   // multiple of 3; k-units of weights in flight per wave + 1 (2 KiB each)
 
-// k-units of a layer input split by producer set: unit u (input columns 16u .. 16u+15) lies in n-tile u/2 of the previous layer
+// k-units of a layer input split by producer set: unit u (input columns 16u .. 16u+15) lies in n-tile u/2 of the previous layer;
+// phase 0 = the units of the even tiles (set A's), phase 1 = those of the odd tiles (set B's).
 __device__ __forceinline__ int bf8_count(int nu, int ph) {
   const int r = nu & 3;
   return 2 * (nu >> 2) + (ph == 0 ? min(r, 2) : max(r - 2, 0));
 }
-__device__ __forceinline__ int bf8_unit(int j, int ph) { return 4 * (j >> 1) + 2 * ph + (j & 1); }
+// PHASE-MAJOR order of the contraction index, used by BOTH operands so that the k-loop's cursors are plain counters: the slab keeps
+// feature f (32-column tile t = f >> 5) in column bf8_col(f): even tiles in columns 0..255, odd tiles in 256..511; Wfb keeps k-unit u
+// of an n-tile in slot ((u >> 1) & 1) * 16 + 2 * (u >> 2) + (u & 1) of 32 (wn_tiles_kernel).  Slot s of phase p is s = 16 p + j.
+constexpr int BF8_HALF = 16;       // slots per phase
+__device__ __forceinline__ int bf8_tile_slot(int t) { return (t & 1) * 8 + (t >> 1); }          // slab tile (32 columns) of n-tile t
+__device__ __forceinline__ int bf8_col(int f) { return 32 * bf8_tile_slot(f >> 5) + (f & 31); }
+
+template <int... I, class F>
+__device__ __forceinline__ void bf8_static_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 
 struct Bf8View { __amdgpu_buffer_rsrc_t rsrc; int tb[2]; int voff; };
-__device__ __forceinline__ Bf8View bf8_view(const __bf16* wfb, int U, int ntiles, int t0, int lane) {
+__device__ __forceinline__ Bf8View bf8_view(const __bf16* wfb, int ntiles, int t0, int lane) {
   Bf8View v;
-  v.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wfb, 0, (ntiles * U) << 10, 0x00020000);   // exact size: nothing past the layer's copy is ever read
-  v.tb[0] = t0 * U; v.tb[1] = (t0 + 8) * U;
+  v.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wfb, 0, (ntiles * 32) << 10, 0x00020000);   // exact size: nothing past the layer's copy is ever read
+  v.tb[0] = t0 * 32; v.tb[1] = (t0 + 8) * 32;
   v.voff = lane * 16;
   return v;
 }
@@ -48,68 +57,120 @@ __device__ __forceinline__ Bf8View bf8_view(const __bf16* wfb, int U, int ntiles
 // acc[m][j] += W[n-tile j of this wave][units of phase ph] * X^T[.][rows 32m ..]: D = W X^T, lane (fh, fr) register 4g+i =
 // Y[row 32m + fr][feature 32 t_j + 8g + 4fh + i].  Loads past the last unit are dropped by the buffer bounds check (the vector
 // offset is pushed out of range): a wrapped-around prefetch would cost real L2 bandwidth, which is the bound here.
+//
+// REGISTER REUSE DISTANCE (measured, tools/lab_bf16x8_err.py): with TWO waves per SIMD an MFMA may still be reading its A/B source
+// registers when a later-issued ds_read (or an out-of-range buffer load, which returns at once) writes them: the first version let
+// the allocator give a load the registers the MFMA just in front of it had read -- fine for a lone wave per SIMD (the 4-wave kernel
+// runs the same pattern bit-reproducibly), but here 3 % of the rows came out different from run to run, always rows 48-63 of a
+// workgroup (the late columns of the LAST MFMA of a group).  So a step's loads are issued AFTER its MFMAs, they only ever replace
+// what the step BEFORE consumed, and the fragments the step itself consumed are kept live (empty asm) until those loads are out:
+// the allocator cannot hand their registers to a load before a full step (4 MFMAs, >= 128 cycles) has passed.
 template <int NT>
-__device__ __forceinline__ void bf8_kloop(f32x16 (&acc)[2][2], const __bf16* ap, const Bf8View& B, int nu, int ph) {
+__device__ __forceinline__ void bf8_keep(const bf16x8 (&a)[2], const bf16x8 (&b)[2]) {
+  asm volatile("" ::"v"(a[0]), "v"(a[1]));
+#pragma unroll
+  for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(b[j]));
+}
+// One pass over ALL k-units of a layer: first those of phase `first`, then the others.  (No per-workgroup rotation of the unit order
+// as in the fp32 kernel: the two sets are half a layer apart anyway, and the cursor arithmetic it needs costs more scalar
+// instructions per step than the loop has room for.)
+// The ring is indexed by the ITEM number n (slot n % R, row-fragment buffer n % 3, both compile-time inside a chunk of R steps).
+// BAR (set A): the workgroup barrier sits between the two phases -- the second phase's input columns are being written by set B's
+// epilogue until then, so row fragments are not read ahead across it; the WEIGHT ring does not care and keeps streaming: phase 1 is
+// padded with bubbles (items without a unit: nothing loaded, nothing multiplied) up to a multiple of R, so that phase 2 starts on
+// ring slot 0 again with its first R-1 units already requested during the last steps of phase 1.
+template <int NT, bool BAR>
+__device__ __forceinline__ void bf8_kloop(f32x16 (&acc)[2][2], const __bf16* ap, const Bf8View& B, int nu, int first) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  const int cnt = bf8_count(nu, ph);
-  if (cnt <= 0) return;
-  const int rot = (int)((((unsigned)blockIdx.x >> 3) * (unsigned)cnt) >> 5) % cnt;   // blocks b, b+8, ... share an XCD
-  bf16x8 ring[BF8_RING][2];
-  bf16x8 a0[2], a1[2];
-  int jb = rot, ib = 0, ja = rot;   // position (mod cnt) of the next unit to request / to read rows for; ib = units requested
-  auto loadB = [&](bf16x8 (&dst)[2]) {
-    const int u = bf8_unit(jb, ph);
-    const int vo = ib < cnt ? B.voff : (int)0xFFFFFF00u;   // past num_records by any reading of the range check
+  constexpr int R = BF8_RING;
+  static_assert(R % 3 == 0, "the A fragments rotate through 3 buffers");
+  const int c0 = bf8_count(nu, first), c1 = bf8_count(nu, 1 - first), T = c0 + c1;
+  const int P = BAR ? ((c0 + R - 1) / R) * R : c0;      // first item of phase 2
+  const int N = P + c1;                                 // items in all
+  bf16x8 ring[R][2];
+  bf16x8 a[3][2];
+  // item n of the load side / unit k of the row side -> slot (16 phase + rotated position): a handful of scalar selects, no branches
+  int bn = 0, ak = 0;
+  const int base0 = first * BF8_HALF, base1 = (1 - first) * BF8_HALF - c0;
+  auto slot_of = [&](int k) __attribute__((always_inline)) { return k + (k >= c0 ? base1 : base0); };   // k-th unit of the sequence (0 .. T-1)
+  auto loadB = [&](bf16x8 (&dst)[2]) __attribute__((always_inline)) {   // item bn: a unit, a bubble, or past the end (the last two: dropped)
+    const bool real = (bn < c0 || bn >= P) && bn < N;
+    const int sl = slot_of(bn < c0 ? bn : bn - P + c0);
+    const int vo = real ? B.voff : (int)0xFFFFFF00u;    // past num_records by any reading of the range check
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(B.rsrc, vo, (B.tb[j] + u) << 10, 0);
+      const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(B.rsrc, vo, (B.tb[j] + sl) << 10, 0);
       dst[j] = __builtin_bit_cast(bf16x8, r);
     }
-    jb = jb + 1 == cnt ? 0 : jb + 1; ++ib;
+    ++bn;
   };
-  auto readA = [&](bf16x8 (&a)[2]) {
-    const int u = bf8_unit(ja, ph);
-    a[0] = *reinterpret_cast<const bf16x8*>(ap + 16 * u);
-    a[1] = *reinterpret_cast<const bf16x8*>(ap + 32 * FLDH + 16 * u);
-    ja = ja + 1 == cnt ? 0 : ja + 1;
+  auto readA = [&](bf16x8 (&x)[2]) __attribute__((always_inline)) {   // (past the end: the last unit again -- valid data, never used)
+    const int sl = slot_of(ak);
+    x[0] = *reinterpret_cast<const bf16x8*>(ap + 16 * sl);
+    x[1] = *reinterpret_cast<const bf16x8*>(ap + 32 * FLDH + 16 * sl);
+    ak = ak + 1 < T ? ak + 1 : ak;
   };
-  auto mma = [&](const bf16x8 (&a)[2], const bf16x8 (&b)[2]) {
+  auto mma = [&](const bf16x8 (&x)[2], const bf16x8 (&b)[2]) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[0], acc[0][j], 0, 0, 0);
-      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[1], acc[1][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], x[0], acc[0][j], 0, 0, 0);
+      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], x[1], acc[1][j], 0, 0, 0);
     }
   };
+  // one step with compile-time buffer indices; GUARD: phase-1 boundary chunk / tail (items may be bubbles or past the end)
+  auto step = [&](int n, auto qc, auto guardc, int lim_mma, int lim_pre) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc)::value;
+    constexpr bool GUARD = decltype(guardc)::value;
+    if (!GUARD || n < lim_mma) mma(a[q % 3], ring[q]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!GUARD || n + 2 < lim_pre) readA(a[(q + 2) % 3]);      // rows of item n+2 -> the buffer step n-1 consumed
+    loadB(ring[(q + R - 1) % R]);                              // weights of item n+R-1 -> the slot step n-1 consumed
+    __builtin_amdgcn_sched_barrier(0);
+    bf8_keep<NT>(a[q % 3], ring[q]);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto chunk = [&](int s, auto guardc, int lim_mma, int lim_pre) __attribute__((always_inline)) {
+    bf8_static_for(std::make_integer_sequence<int, R>{},
+                   [&](auto qc) __attribute__((always_inline)) { step(s + decltype(qc)::value, qc, guardc, lim_mma, lim_pre); });
+  };
 #pragma unroll
-  for (int q = 0; q < BF8_RING - 1; ++q) loadB(ring[q]);
-  readA(a0);
+  for (int q = 0; q < R - 1; ++q) loadB(ring[q]);
   int s = 0;
-  for (; s + BF8_RING <= cnt; s += BF8_RING) {
-#pragma unroll
-    for (int q = 0; q < BF8_RING; q += 2) {
-      loadB(ring[(q + BF8_RING - 1) % BF8_RING]);
-      readA(a1);
-      mma(a0, ring[q]);
-      loadB(ring[q % BF8_RING]);
-      readA(a0);
-      mma(a1, ring[q + 1]);
-    }
+  if (BAR) {
+    if (0 < c0) readA(a[0]);
+    if (1 < c0) readA(a[1]);
+    for (; s + R + 2 <= c0; s += R) chunk(s, std::false_type{}, 0, 0);     // every step multiplies and reads two steps ahead
+    for (; s < P; s += R) chunk(s, std::true_type{}, c0, c0);               // the boundary: last units, bubbles, no reading ahead
+    __syncthreads();                 // set B's epilogue is complete: its columns (phase 2) may be read
+    readA(a[0]);
+    readA(a[1]);
+  } else {
+    readA(a[0]);
+    readA(a[1]);
   }
+  for (; s + R <= N; s += R) chunk(s, std::false_type{}, 0, 0);
+  if (s < N) chunk(s, std::true_type{}, N, N + 2);   // tail (reading ahead past the end is harmless)
+  // leaving: whatever comes next (the epilogue's table reads) loads into fresh registers at once -- wait until the LAST MFMA has
+  // written back (a VALU read of its result), only then let go of the fragment registers
+  float done;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(done) : "v"(acc[1][NT - 1][15]));
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int q = 0; q < BF8_RING - 1; ++q) {
-    if (s + q < cnt) {
-      if (q & 1) { readA(a0); mma(a1, ring[q]); }
-      else { readA(a1); mma(a0, ring[q]); }
-    }
-  }
+  for (int q = 0; q < 3; ++q) asm volatile("" ::"v"(a[q][0]), "v"(a[q][1]), "v"(done));
+#pragma unroll
+  for (int q = 0; q < R; ++q)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(ring[q][j]));
+  __builtin_amdgcn_sched_barrier(0);
 }
-__device__ __forceinline__ void bf8_kloop_dispatch(f32x16 (&acc)[2][2], const __bf16* ap, const Bf8View& B, int nu, int ph, int nt) {
-  if (nt == 2) bf8_kloop<2>(acc, ap, B, nu, ph);
-  else if (nt == 1) bf8_kloop<1>(acc, ap, B, nu, ph);
+// every wave of set A takes the mid-layer barrier exactly once per layer, with or without work
+template <bool BAR>
+__device__ __forceinline__ void bf8_kloop_dispatch(f32x16 (&acc)[2][2], const __bf16* ap, const Bf8View& B, int nu, int first, int nt) {
+  if (nt == 2 && nu > 0) bf8_kloop<2, BAR>(acc, ap, B, nu, first);
+  else if (nt == 1 && nu > 0) bf8_kloop<1, BAR>(acc, ap, B, nu, first);
+  else if (BAR) __syncthreads();
 }
 
-// per-lane constants of a layer's epilogue: bias (and, for the last hidden layer, the output layer's weights) of the lane's
-// features, requested before the k-loop
 __device__ __forceinline__ void bf8_load_vec(float (&dst)[2][16], const float* src, int od, int t0, int fh) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -155,55 +216,117 @@ __device__ __forceinline__ void bf8_hoist_init(f32x16 (&acc)[2][2], const float*
   }
 }
 
-// bias + ReLU -> bf16 -> OUT slab (row stride FLDH), 4 features per 8-byte store.  odp: columns this layer owns in the slab
-// (out_dim, or out_dim rounded up to the k-unit when no x0 columns follow: the pad is written as zeros -- features past out_dim
-// come out as exactly 0 by themselves: zero weight rows, zero bias, zero hoist).  A tile that ends inside the slab's owned
-// columns needs no checks at all; the one ragged tile of a layer takes the element-wise path.
-template <bool FULL>
-__device__ __forceinline__ void bf8_epilogue_tile(const f32x16& a0, const f32x16& a1, const float (&bias)[16], __bf16* OUT, int odp,
-                                                  int t, int fr, int fh) {
+// lane LANE of `old` := the scalar `sval` (v_writelane_b32; the lane select is an immediate, so the loops around it are compile-time).
+// This compiler has no builtin for it, but the LLVM intrinsic is reachable through its symbol name.  NOT inline asm: the hazard
+// recogniser does not look into asm, and a v_writelane right behind the v_cmp that produced its scalar operand needs a wait state
+// (the asm version wrote wrong mask words: every gradient below the last hidden layer came out wrong).
+extern "C" __device__ int dsdf_llvm_writelane(int, int, int) __asm("llvm.amdgcn.writelane.i32");
+template <int LANE>
+__device__ __forceinline__ uint32_t bf8_writelane(uint32_t old, uint32_t sval) {
+  return (uint32_t)dsdf_llvm_writelane((int)sval, LANE, (int)old);
+}
+
+// Everything the epilogue of one layer needs besides the accumulators (wave-uniform unless noted).
+struct Bf8Epi {
+  __bf16* OUT;            // next layer's input slab
+  int od, odp;            // out_dim; columns this layer owns in the slab (out_dim, or rounded up to the k-unit when no x0 columns
+                          // follow: the pad is written as zeros -- features past out_dim come out as exactly 0 by themselves)
+  const float* btab;      // LDS: bias per column (0 past out_dim)
+  const uint32_t* cktab;  // LDS: dropout column keys
+  __amdgpu_buffer_rsrc_t rsrc; int ldb;   // TRAIN: the global activation copy of this workgroup's rows (rows >= N are out of range)
+  uint32_t* maskw;        // TRAIN: this workgroup's mask words [2 m][FMAXW columns] (bit r of word (m, c) = output[32m + r][c] > 0), or nullptr
+  uint32_t thr; float scale;
+  uint32_t pm[2];         // per lane: (global row of (m, fr) >> 1) * 0x9E3779B1
+  int par16;              // per lane: 16 * (global row & 1)  -- which half of the pair hash is this row's
+};
+
+// One n-tile: bias + ReLU (+ dropout) on the lane's 2 x 16 values = rows 32m + fr, features 32t + 8g + 4fh + i.
+//   !LASTL: -> bf16 -> OUT slab, 4 features per 8-byte store;   LASTL: the output layer's dot product instead (part[m])
+//   TRAIN : + the fp32 activation copy (16-byte stores) + the keep/positive bits for the backward: ballot over the 64 lanes =
+//           32 rows of column 8g+i and of column 8g+4+i, collected with v_writelane into ONE register whose lane c then holds the
+//           32-row word of column c of the tile
+// FULL: the tile ends inside the layer's columns -- no checks at all; the one ragged tile of a layer takes the guarded stores.
+template <bool FULL, bool TRAIN, bool DROP, bool LASTL>
+__device__ __forceinline__ void bf8_epilogue_tile(const f32x16& a0, const f32x16& a1, const Bf8Epi& E, const float (&wl)[16],
+                                                  float (&part)[2], int t, int lane) {
   typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const int fr = lane & 31, fh = lane >> 5;
+  uint32_t mw[2] = {0u, 0u};
+  bf8_static_for(std::make_integer_sequence<int, 4>{}, [&](auto gc) __attribute__((always_inline)) {
+    constexpr int G = decltype(gc)::value;
+    constexpr int g = G;
     const int f0 = 32 * t + 8 * g + 4 * fh;
+    const float4 b4 = *reinterpret_cast<const float4*>(E.btab + f0);
+    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+    uint32_t ck[4] = {0u, 0u, 0u, 0u};
+    if constexpr (DROP) {
+      const uint4 c4 = *reinterpret_cast<const uint4*>(E.cktab + f0);
+      ck[0] = c4.x; ck[1] = c4.y; ck[2] = c4.z; ck[3] = c4.w;
+    }
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       const f32x16& a = m == 0 ? a0 : a1;
       float v[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = fmaxf(a[4 * g + i] + bias[4 * g + i], 0.f);
-      __bf16* dst = OUT + (32 * m + fr) * FLDH + f0;
-      if (FULL || f0 + 3 < odp) {
-        const bf16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-        *reinterpret_cast<bf16x4*>(dst) = h;
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (f0 + i < odp) dst[i] = (__bf16)v[i];
+      for (int i = 0; i < 4; ++i) {
+        v[i] = fmaxf(a[4 * g + i] + bb[i], 0.f);
+        if constexpr (DROP) {
+          const uint32_t h = lowbias32(ck[i] ^ E.pm[m]);
+          v[i] = ((h >> E.par16) & 0xFFFFu) >= E.thr ? v[i] * E.scale : 0.f;
+        }
       }
+      if constexpr (LASTL) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[m] = fmaf(v[i], wl[4 * g + i], part[m]);   // (wl is 0 past out_dim)
+      } else {
+        __bf16* dst = E.OUT + (32 * m + fr) * FLDH + 32 * bf8_tile_slot(t) + 8 * g + 4 * fh;   // (phase-major column of feature f0)
+        if (FULL || f0 + 3 < E.odp) {
+          const bf16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+          *reinterpret_cast<bf16x4*>(dst) = h;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (f0 + i < E.odp) dst[i] = (__bf16)v[i];
+        }
+      }
+      if constexpr (TRAIN) {
+        const uint32_t voff = (uint32_t)((32 * m + fr) * E.ldb + f0 * 4);
+        if (FULL || f0 + 3 < E.od) {
+          const u32x4 q = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+          __builtin_amdgcn_raw_buffer_store_b128(q, E.rsrc, voff, 0, FUSED_STORE_AUX);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (f0 + i < E.od) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[i]), E.rsrc, voff + 4 * i, 0, FUSED_STORE_AUX);
+        }
+        if (E.maskw != nullptr) {   // (wave-uniform)
+          bf8_static_for(std::make_integer_sequence<int, 4>{}, [&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(v[i] > 0.f);
+            mw[m] = bf8_writelane<8 * G + i>(mw[m], (uint32_t)bal);
+            mw[m] = bf8_writelane<8 * G + 4 + i>(mw[m], (uint32_t)(bal >> 32));
+          });
+        }
+      }
+    }
+  });
+  if constexpr (TRAIN) {
+    if (E.maskw != nullptr && lane < 32) {
+      E.maskw[32 * t + lane] = mw[0];
+      E.maskw[FMAXW + 32 * t + lane] = mw[1];
     }
   }
 }
-template <int NT>
-__device__ __forceinline__ void bf8_epilogue(const f32x16 (&acc)[2][2], const float (&bias)[2][16], __bf16* OUT, int odp, int t0,
-                                             int fr, int fh) {
+template <int NT, bool TRAIN, bool DROP, bool LASTL>
+__device__ __forceinline__ void bf8_epilogue(const f32x16 (&acc)[2][2], const Bf8Epi& E, const float (&wl)[2][16], float (&part)[2],
+                                             int t0, int lane) {
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int t = t0 + 8 * j;
-    if (32 * t + 32 <= odp) bf8_epilogue_tile<true>(acc[0][j], acc[1][j], bias[j], OUT, odp, t, fr, fh);
-    else bf8_epilogue_tile<false>(acc[0][j], acc[1][j], bias[j], OUT, odp, t, fr, fh);
+    if (32 * t + 32 <= E.od) bf8_epilogue_tile<true, TRAIN, DROP, LASTL>(acc[0][j], acc[1][j], E, wl[j], part, t, lane);
+    else bf8_epilogue_tile<false, TRAIN, DROP, LASTL>(acc[0][j], acc[1][j], E, wl[j], part, t, lane);
   }
-}
-// last hidden layer: its activation stays in registers and meets the output layer's weights there
-template <int NT>
-__device__ __forceinline__ void bf8_epilogue_last(const f32x16 (&acc)[2][2], const float (&bias)[2][16], const float (&wl)[2][16],
-                                                  float (&part)[2]) {
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-#pragma unroll
-      for (int m = 0; m < 2; ++m) part[m] = fmaf(fmaxf(acc[m][j][r] + bias[j][r], 0.f), wl[j][r], part[m]);   // (bias / wl are 0 past out_dim)
 }
 
 template <int NTHR>
@@ -227,18 +350,25 @@ __device__ __forceinline__ void bf8_load_x0(__bf16* S, const float* x0, int ldx0
       const int i = base + tid + NTHR * k;
       if (i < total) {
         const int r = i / zc, c = i - r * zc;
-        S[r * FLDH + col0 + c] = (__bf16)v[k];
+        S[r * FLDH + bf8_col(col0 + c)] = (__bf16)v[k];
       }
     }
   }
 }
 
+// TRAIN = false: inference (dsdf_decode / dsdf_decode_latent: no copies, no dropout, no mask words);
+// TRAIN = true : training / module form -- every layer's activation goes to FusedLayer::out as fp32 (what the fp32 backward and the
+//                dW GEMMs read), FusedLayer::maskbits receives the mask words in the layout described at Bf8Epi::maskw
+//                (FusedBwdArgs::mask_t tells the backward), dropout per FusedLayer::drop_*.
+template <bool TRAIN>
 __global__ __launch_bounds__(F8_THREADS, 1) void fused_forward_bf16x8_kernel(const FusedFwdArgs p) {
   __shared__ __attribute__((aligned(16))) __bf16 SLAB[2 * FROWS * FLDH];   // layer l reads slab l & 1 and writes the other
   __shared__ float4 xs[FROWS];
   __shared__ float hu[FHOIST][FMAXW];
   __shared__ float4 hwx[FHOIST][FMAXW];
   __shared__ float red[16][FROWS];     // output-layer partials: [wave][fh][row]
+  __shared__ __attribute__((aligned(16))) float btab[FMAXW];      // bias / dropout column keys of the layer a set is working on: each set
+  __shared__ __attribute__((aligned(16))) uint32_t cktab[FMAXW];  // writes and reads only the columns of ITS n-tiles (see the schedule)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int set = w >> 2, t0 = 2 * (w & 3) + set;     // this wave's n-tiles: t0 and t0 + 8
@@ -281,48 +411,66 @@ __global__ __launch_bounds__(F8_THREADS, 1) void fused_forward_bf16x8_kernel(con
   __syncthreads();
 
   f32x16 acc[2][2];
-  float bias[2][16], wl[2][16];
+  float wl[2][16];
   float part[2] = {0.f, 0.f};
-  int nt_prev = 0;
+  const int rows_here = min(FROWS, p.N - row0);
+  // the column of the per-set tables this thread fills: the k-th column of the set's 8 n-tiles
+  const int tcol = 32 * (2 * ((tid & 255) >> 5) + set) + (tid & 31);
 
-  // everything a wave needs before the k-loop of layer l: accumulators, epilogue constants
-  auto begin = [&](int l) -> int {
+  // everything a wave needs before the k-loop of layer l: accumulators, its set's epilogue tables; returns the wave's n-tile count
+  auto begin = [&](int l) __attribute__((always_inline)) -> int {
     const FusedLayer& L = p.ly[l];
     const int nt = (32 * t0 < L.out_dim ? 1 : 0) + (32 * (t0 + 8) < L.out_dim ? 1 : 0);
     int hidx = -1;
     if (segm) hidx = l == p.seg.h[0].layer ? 0 : (l == p.seg.h[1].layer ? 1 : -1);
     if (hidx >= 0) bf8_hoist_init(acc, hu[hidx], hwx[hidx], xs, L.out_dim, t0, fr, fh);
     else bf8_zero(acc);
-    bf8_load_vec(bias, L.bias, L.out_dim, t0, fh);
+    btab[tcol] = tcol < L.out_dim ? L.bias[tcol] : 0.f;
+    if (TRAIN && L.drop_thr != 0u) cktab[tcol] = drop_col_key((uint32_t)tcol, L.drop_key);
     if (l + 1 == nh) bf8_load_vec(wl, p.w_last, min(L.out_dim, p.in_last), t0, fh);
     return nt;
   };
-  auto kloop = [&](int l, int ph, int nt) {
+  auto kloop = [&](int l, int nt, auto barc) __attribute__((always_inline)) {   // barc: set A (mid-layer barrier inside) or set B
     const FusedLayer& L = p.ly[l];
     const int nu = (L.in + 15) >> 4;
-    if (nu <= 0 || nt == 0) return;
-    const Bf8View B = bf8_view(reinterpret_cast<const __bf16*>(L.wf), L.U, (L.out_dim + 31) >> 5, t0, lane);
-    bf8_kloop_dispatch(acc, SLAB + (l & 1) * (FROWS * FLDH) + fr * FLDH + 8 * fh, B, nu, ph, nt);
+    const Bf8View B = bf8_view(reinterpret_cast<const __bf16*>(L.wf), (L.out_dim + 31) >> 5, t0, lane);
+    bf8_kloop_dispatch<decltype(barc)::value>(acc, SLAB + (l & 1) * (FROWS * FLDH) + fr * FLDH + 8 * fh, B, nu,
+                                              decltype(barc)::value ? 0 : 1, nt);
   };
-  auto epilogue = [&](int l, int nt) {
+  auto epilogue = [&](int l, int nt) __attribute__((always_inline)) {
+    if (nt == 0) return;
     const FusedLayer& L = p.ly[l];
-    if (l + 1 == nh) {
-      if (nt == 2) bf8_epilogue_last<2>(acc, bias, wl, part);
-      else if (nt == 1) bf8_epilogue_last<1>(acc, bias, wl, part);
-      return;
+    Bf8Epi E;
+    E.OUT = SLAB + ((l + 1) & 1) * (FROWS * FLDH);
+    E.od = L.out_dim;
+    E.odp = L.x0_col >= 0 ? L.out_dim : ((L.out_dim + 15) & ~15);
+    E.btab = btab; E.cktab = cktab;
+    const bool has_out = TRAIN && L.out != nullptr;
+    E.rsrc = __builtin_amdgcn_make_buffer_rsrc(has_out ? (void*)(L.out + (size_t)row0 * L.ld_out) : (void*)SLAB, 0,
+                                               has_out ? rows_here * L.ld_out * 4 : 0, 0x00020000);
+    E.ldb = L.ld_out * 4;
+    E.maskw = (TRAIN && L.maskbits != nullptr) ? L.maskbits + (size_t)blockIdx.x * (2 * FMAXW) : nullptr;
+    E.thr = L.drop_thr; E.scale = L.drop_scale;
+    const uint32_t grow = p.row_offset + (uint32_t)(row0 + fr);
+    E.pm[0] = (grow >> 1) * 0x9E3779B1u; E.pm[1] = ((grow + 32u) >> 1) * 0x9E3779B1u;
+    E.par16 = (int)(grow & 1u) * 16;
+    const bool lastl = l + 1 == nh;
+    const bool drop = TRAIN && L.drop_thr != 0u;
+#define BF8_EPI(NT_, DROP_, LAST_) bf8_epilogue<NT_, TRAIN, DROP_, LAST_>(acc, E, wl, part, t0, lane)
+    if (nt == 2) {
+      if (lastl) { if (drop) BF8_EPI(2, true, true); else BF8_EPI(2, false, true); }
+      else       { if (drop) BF8_EPI(2, true, false); else BF8_EPI(2, false, false); }
+    } else {
+      if (lastl) { if (drop) BF8_EPI(1, true, true); else BF8_EPI(1, false, true); }
+      else       { if (drop) BF8_EPI(1, true, false); else BF8_EPI(1, false, false); }
     }
-    __bf16* OUT = SLAB + ((l + 1) & 1) * (FROWS * FLDH);
-    const int odp = L.x0_col >= 0 ? L.out_dim : ((L.out_dim + 15) & ~15);
-    if (nt == 2) bf8_epilogue<2>(acc, bias, OUT, odp, t0, fr, fh);
-    else if (nt == 1) bf8_epilogue<1>(acc, bias, OUT, odp, t0, fr, fh);
+#undef BF8_EPI
   };
 
   if (set == 0) {
     for (int l = 0; l < nh; ++l) {
       const int nt = begin(l);
-      kloop(l, 0, nt);
-      __syncthreads();                       // E_B(l-1) is complete
-      kloop(l, 1, nt);
+      kloop(l, nt, std::true_type{});        // K_l(UA) | barrier: E_B(l-1) is complete, this set's tables of layer l are visible | K_l(UB)
       epilogue(l, nt);
       if (p.ly[l].x0_col >= 0 && l + 1 < nh)   // general mode, skip layer: x0 joins the next layer's input (columns no epilogue writes)
         bf8_load_x0<256>(SLAB + ((l + 1) & 1) * (FROWS * FLDH), p.x0, p.ldx0, p.W0, row0, p.N, p.ly[l].x0_col, tid);
@@ -330,20 +478,20 @@ __global__ __launch_bounds__(F8_THREADS, 1) void fused_forward_bf16x8_kernel(con
     }
     __syncthreads();
   } else {
-    for (int l = 0; l < nh; ++l) {
+    int nt_prev = 0;
+    for (int l = 0; l <= nh; ++l) {
       if (l > 0) epilogue(l - 1, nt_prev);
       __syncthreads();
-      const int nt = begin(l);
-      kloop(l, 1, nt);
-      kloop(l, 0, nt);
-      nt_prev = nt;
-      __syncthreads();
+      if (l < nh) {
+        const int nt = begin(l);
+        kloop(l, nt, std::false_type{});     // K_l(UB) K_l(UA)
+        nt_prev = nt;
+        __syncthreads();
+      }
     }
-    epilogue(nh - 1, nt_prev);
-    __syncthreads();
   }
-  // (the barrier above orders nothing for `red`: each slot below has exactly one writer)
-  red[2 * w + fh][fr] = part[0];
+  if (p.y_out == nullptr && p.u_out == nullptr) return;   // training: the backward head recomputes the output layer
+  red[2 * w + fh][fr] = part[0];        // (each slot has exactly one writer)
   red[2 * w + fh][32 + fr] = part[1];
   __syncthreads();
   if (tid < FROWS && row0 + tid < p.N) {

@@ -365,10 +365,13 @@ __global__ __launch_bounds__(256) void wn_tiles_kernel(const WnAll p) {
     float4 v4 = make_float4(tile[fr][kk], tile[fr][kk + 1], tile[fr][kk + 2], tile[fr][kk + 3]);
     *reinterpret_cast<float4*>(L.Wf + ((size_t)(rb * L.Uf + 2 * cb + uu) * 2 + i) * 256 + lane * 4) = v4;
   }
-  if (L.Wfb != nullptr) {  // bf16(W), lane (r, h) holds k = 16u + 8h + j (j = 0..7) contiguously: this thread's j = 4i .. 4i+3
+  if (L.Wfb != nullptr) {  // bf16(W), lane (r, h) holds k = 16u + 8h + j (j = 0..7) contiguously: this thread's j = 4i .. 4i+3.
+    // k-units are stored PHASE-MAJOR, 32 slots per n-tile (fused_bf16x8.hpp): the units of the even 32-column input tiles in slots
+    // 0.., those of the odd tiles in slots 16.. -- the order the 8-wave forward contracts them in (slot = bf8_slot(u))
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
     const bf16x4 h4 = {(__bf16)tile[fr][kk], (__bf16)tile[fr][kk + 1], (__bf16)tile[fr][kk + 2], (__bf16)tile[fr][kk + 3]};
-    *reinterpret_cast<bf16x4*>(L.Wfb + ((size_t)(rb * L.Uf + 2 * cb + uu) * 64 + lane) * 8 + 4 * i) = h4;
+    const int slot = (cb & 1) * 16 + 2 * (cb >> 1) + uu;      // unit u = 2 cb + uu
+    *reinterpret_cast<bf16x4*>(L.Wfb + ((size_t)(rb * 32 + slot) * 64 + lane) * 8 + 4 * i) = h4;
   }
   if (L.WTf != nullptr) {  // B = W^T: n = in index (tile cols), k = out index (tile rows)
     float4 v4 = make_float4(tile[kk][fr], tile[kk + 1][fr], tile[kk + 2][fr], tile[kk + 3][fr]);
