@@ -575,12 +575,12 @@ int run_fused_forward(const DsdfNet* net, const Plan& P, void* ws, const float* 
   a.dbg = dbg;
 #endif
   const dim3 grid((unsigned)((n + FROWS - 1) / FROWS));
-  if (net->fwd_bf16) {   // config 5: 8 staggered waves (fused_bf16x8.hpp); the training form keeps copies + mask words
-    if (store_act) hipLaunchKernelGGL(fused_forward_bf16x8_kernel<true>, grid, dim3(F8_THREADS), 0, st, a);
-    else hipLaunchKernelGGL(fused_forward_bf16x8_kernel<false>, grid, dim3(F8_THREADS), 0, st, a);
-  } else {
+  if (net->fwd_bf16 && !store_act)   // config 5, inference form: 8 staggered waves, transposed accumulators (fused_bf16x8.hpp)
+    hipLaunchKernelGGL(fused_forward_bf16x8_kernel, grid, dim3(F8_THREADS), 0, st, a);
+  else if (net->fwd_bf16)            // with activation copies (module path; training goes out merged with the backward)
+    hipLaunchKernelGGL(fused_forward_bf16_kernel, grid, dim3(256), 0, st, a);
+  else
     hipLaunchKernelGGL(fused_forward_kernel, grid, dim3(256), 0, st, a);
-  }
 #ifdef DSDF_LAB
   if (dbg && getenv("DSDF_LAB_DBG")) {
     (void)hipDeviceSynchronize();
@@ -795,7 +795,6 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
   memset(&a, 0, sizeof(a));
   a.N = (int)n;
   a.head = head;
-  a.mask_t = net->fwd_bf16 ? 1 : 0;   // the 8-wave bf16 forward writes one 32-row word per column (fused_bf16x8.hpp)
   const bool segmode = sb != nullptr;
   const int ks = skip_layer(net);
   if (segmode) { a.xyz = sb->seg->xyz; a.G = sb->seg->G; }
@@ -831,7 +830,8 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     (void)wmac;
     if (fwd != nullptr) {
       ProfScope ps(DSDF_PROF_FUSED_FWD_BWD, 4.0 * (double)n * amac, st);   // forward + dX chain
-      hipLaunchKernelGGL(fused_fwd_bwd_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);   // (fp32 only: see `merged`)
+      if (net->fwd_bf16) hipLaunchKernelGGL(fused_fwd_bf16_bwd_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
+      else hipLaunchKernelGGL(fused_fwd_bwd_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
       LAUNCH_OK("fused_fwd_bwd_kernel");
     } else {
       ProfScope ps(DSDF_PROF_FUSED_BWD, 2.0 * (double)n * amac, st);
@@ -1309,7 +1309,7 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
   FusedSeg seg;
   memset(&seg, 0, sizeof(seg));
   FusedFwdArgs fwd_args;                                   // fp32 fused path: forward + backward go out as ONE launch below
-  bool merged = fusedb && !net->fwd_bf16;   // (config 5: the bf16 forward is a launch of its own -- 512 threads, its own LDS plan)
+  bool merged = fusedb;
   if (getenv("DSDF_NO_MERGE")) merged = false;   // lab / tests: forward and backward as two launches in fp32 too
 #ifdef DSDF_LAB
   if (getenv("DSDF_LAB_DBG")) merged = false;   // lab builds: per-layer stamps are dumped after a forward launch of its own

@@ -122,7 +122,8 @@ __device__ __forceinline__ constexpr int crow(int reg) { return (reg & 3) + 8 * 
 // bounds check drops rows >= N and masked columns; row offsets are SCALAR), LDS stores use immediate offsets.
 constexpr int FLDH = 520;        // slab row stride in bf16 elements (bf16 forward, fused_bf16x8.hpp)
 
-template <bool DROP, bool EVEN>
+// HS: the slab holds bf16 (row stride FLDH) instead of fp32 (row stride FLD); the global activation copy stays fp32.
+template <bool DROP, bool EVEN, bool HS = false>
 __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[2][4], const float (&biasv)[4], float* S,
                                                    const FusedLayer& L, int w, int fr, int fh, int row0, int N,
                                                    uint32_t row_offset) {
@@ -165,8 +166,14 @@ __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[2][4], co
               v1 = (hb & 0xFFFFu) >= L.drop_thr ? v1 * L.drop_scale : 0.f;
             }
           }
-          sp[rc * FLD] = v0;
-          sp[(rc + 1) * FLD] = v1;
+          if constexpr (HS) {
+            __bf16* hp = reinterpret_cast<__bf16*>(S) + (4 * fh) * FLDH + col;
+            hp[rc * FLDH] = (__bf16)v0;
+            hp[(rc + 1) * FLDH] = (__bf16)v1;
+          } else {
+            sp[rc * FLD] = v0;
+            sp[(rc + 1) * FLD] = v1;
+          }
           if (has_out) {   // (inference keeps no copies: 128 dropped stores per lane and layer still cost their issue)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rsrc, voff, rc * ldb, FUSED_STORE_AUX);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rsrc, voff, (rc + 1) * ldb, FUSED_STORE_AUX);
@@ -539,6 +546,335 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(const FusedFwdArg
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ float bf16_round(float x) { return (float)(__bf16)x; }
 
+// BASELINE config 5: the same forward with bf16 GEMM inputs and fp32 accumulation on v_mfma_f32_32x32x16_bf16.
+// Every hidden Linear sees its input rounded to bf16 (the slab holds bf16) and its weight rounded to bf16 (Wfb, written
+// by wn_tiles_kernel: fragment order, lane (r, h) holds k = 16u + 8h + j, j = 0..7, in ONE 16-byte load -- exactly the
+// instruction's operand layout); bias, ReLU, dropout, the stored activation copies (fp32, for the fp32 backward and dW
+// GEMMs), the 512->1 output layer and everything after it stay fp32.  Specification: oracle decoder_forward(bf16=True).
+//
+// Bound: one k-unit of 16 is ONE MFMA per tile (32 cycles) instead of eight fp32 ones (512), so a wave's 8 tiles consume
+// 4 KiB of weights per 256 cycles: 64 points per CU need the layer's 0.5 MB from L2 in the 3.5 us its MFMAs take --
+// 143 GB/s per CU against the ~70 GB/s an XCD's L2 sustains for rows every workgroup shares (MI355X_MICROARCH.md, L2).
+// The k-loop is therefore L2-BANDWIDTH bound (~7 us per 512x512 layer), and what the kernel has to do is keep that stream
+// saturated: a ring of BF_RING k-units of weights per wave in registers (3 units = 12 KiB per wave in flight, 48 KiB per CU
+// ~ bandwidth x L2 latency), refilled one unit per step, and the NEXT layer's first units requested before the epilogue so
+// the stream does not stop while the VALU works.  (bf16 MFMAs do not block the VALU, unlike the fp32 ones -- tools/lab/
+// mfma_valu.hip -- so nothing here needs the fp32 kernel's scalar-address tricks.)
+// Segment mode works as in the fp32 kernel: rounding is element-wise on the operands, so W[:, lat] latent_s is still one
+// vector per scene (seg_hoist_kernel with bf16-rounded operands), and the xyz product is done on bf16-rounded values.
+#ifndef BF_RING_UNITS
+#define BF_RING_UNITS 4
+#endif
+constexpr int BF_RING = BF_RING_UNITS;     // even
+
+
+// rows of x0 (fp32, global) into bf16 slab columns [col0, col0 + W0) + zero pad up to a multiple of 16.  As in fused_load_x0
+// all loads of a pass are issued back-to-back BEFORE the first LDS write (a load-use loop pays the memory latency per trip:
+// 68 trips for a 259-wide x0 cost ~35 us per call).
+__device__ __forceinline__ void fused_load_x0_h(__bf16* S, const float* x0, int ldx0, int W0, int row0, int N, int col0) {
+  constexpr int XCH = 24;
+  const int zc = (((col0 + W0) + 15) & ~15) - col0;      // columns written incl. the zero pad
+  const int total = FROWS * zc;
+  for (int base = 0; base < total; base += 256 * XCH) {
+    float v[XCH];
+#pragma unroll
+    for (int k = 0; k < XCH; ++k) {
+      const int i = base + threadIdx.x + 256 * k;
+      v[k] = 0.f;
+      if (i < total) {
+        const int r = i / zc, c = i - r * zc;
+        if (c < W0 && row0 + r < N) v[k] = x0[(size_t)(row0 + r) * ldx0 + c];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < XCH; ++k) {
+      const int i = base + threadIdx.x + 256 * k;
+      if (i < total) {
+        const int r = i / zc, c = i - r * zc;
+        S[r * FLDH + col0 + c] = (__bf16)v[k];
+      }
+    }
+  }
+}
+
+// ONE k-unit of the next layer's weights travels across the epilogue (16 VGPRs); the ring itself lives only inside the
+// k-loop: a ring kept alive across the epilogue made the compiler spill ~600 scratch accesses per layer into it
+// (1.2 GB of scratch traffic per forward: ring 4 ran 30 % SLOWER than ring 2 until the ring became loop-local).
+#ifndef BF_PRE_UNITS
+#define BF_PRE_UNITS 1      // k-units of the next layer requested before the epilogue (1 .. BF_RING_UNITS - 1)
+#endif
+constexpr int BF_PRE = BF_PRE_UNITS;
+struct Bf16Pre { bf16x8 b[BF_PRE][4]; };
+
+// Every workgroup walks the k-units of a layer in its OWN rotated order (unit (u + rot) mod nu): 32 CUs of an XCD that all
+// stream the same weights in the same order at the same pace keep hitting ONE L2 channel at a time.  A rotation of the
+// contraction order only permutes the fp32 summation; it is a fixed function of the workgroup index, so results stay
+// run-to-run bit-identical.
+#ifndef BF_ROTATE
+#define BF_ROTATE 1
+#endif
+__device__ __forceinline__ int bf16_rot(int nu) {
+#if BF_ROTATE
+  return nu > 0 ? (int)(((blockIdx.x >> 3) * (unsigned)nu) >> 5) % nu : 0;   // blocks b, b+8, ... share an XCD (common.hpp)
+#else
+  return 0;
+#endif
+}
+
+// Weights come through a buffer resource with SCALAR offsets (as in the fp32 kernel's FusedBView): the first version built a
+// 64-bit address per load on the VALU -- 48 vector + 40 scalar instructions per 32 MFMAs, more than fits into the shadow of
+// 32-cycle MFMAs (the MFMA stream alone ran at 1.6x its ideal time).  Unit (n-tile t, k-unit u) = 1 KiB at ((t U + u) << 10).
+struct Bf16BView { __amdgpu_buffer_rsrc_t rsrc; int tb[4]; int voff; };
+__device__ __forceinline__ Bf16BView bf16_bview(const __bf16* wfb, int U, int w, int lane) {
+  Bf16BView v;
+  v.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wfb, 0, 0x7FFFFFFF, 0x00020000);
+  const int ws = __builtin_amdgcn_readfirstlane(w);
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) v.tb[ni] = (ws + 4 * ni) * 32;   // Wfb: 32 phase-major k-unit slots per n-tile (wn_tiles_kernel, fused_bf16x8.hpp)
+  v.voff = lane * 16;
+  return v;
+}
+template <int NACT>
+__device__ __forceinline__ void bf16_load_unit(bf16x8 (&dst)[4], const Bf16BView& B, int u) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const int slot = ((u >> 1) & 1) * 16 + 2 * (u >> 2) + (u & 1);   // where unit u lives
+#pragma unroll
+  for (int ni = 0; ni < NACT; ++ni) {
+    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(B.rsrc, B.voff, (B.tb[ni] + slot) << 10, 0);
+    dst[ni] = __builtin_bit_cast(bf16x8, r);
+  }
+}
+// the FIRST k-unit (of this workgroup's order) of a layer, requested before the previous layer's epilogue
+__device__ __forceinline__ void bf16_prefetch(Bf16Pre& P, const __bf16* wfb, int U, int w, int lane, int nact, int nu) {
+  if (nu <= 0) return;
+  const Bf16BView B = bf16_bview(wfb, U, w, lane);
+  int u = bf16_rot(nu);
+#pragma unroll
+  for (int q = 0; q < BF_PRE; ++q) {          // unconditional (units wrap): every slot is defined, nothing stays live from before
+    switch (nact) {
+      case 4: bf16_load_unit<4>(P.b[q], B, u); break;
+      case 3: bf16_load_unit<3>(P.b[q], B, u); break;
+      case 2: bf16_load_unit<2>(P.b[q], B, u); break;
+      case 1: bf16_load_unit<1>(P.b[q], B, u); break;
+      default: break;
+    }
+    u = u + 1 == nu ? 0 : u + 1;
+  }
+}
+
+// acc[m][ni] += S[64 rows][16 nu] * Wfb; P holds the first unit (bf16_prefetch).  Units are walked in the rotated order
+// rot, rot+1, ..., wrapping at nu; prefetches past the last unit simply wrap too (valid memory, never used), so the loop
+// carries two running SCALAR unit counters and no clamps.
+template <int NACT>
+__device__ __forceinline__ void bf16_kloop(f32x16 (&acc)[2][4], const __bf16* ap, const __bf16* wfb, int U, int w, int lane,
+                                           int nu, const Bf16Pre& P) {
+  bf16x8 ring[BF_RING][4];
+  bf16x8 a0[2], a1[2];
+  const Bf16BView B = bf16_bview(wfb, U, w, lane);
+  auto nextu = [&](int u) { return u + 1 == nu ? 0 : u + 1; };
+  int ub = bf16_rot(nu), ua = bf16_rot(nu);          // next unit to request / next unit's rows to read
+#pragma unroll
+  for (int q = 0; q < BF_PRE; ++q) ub = nextu(ub);   // (the first BF_PRE units came with P)
+  auto readA = [&](bf16x8 (&a)[2]) {
+    a[0] = *reinterpret_cast<const bf16x8*>(ap + 16 * ua);
+    a[1] = *reinterpret_cast<const bf16x8*>(ap + 32 * FLDH + 16 * ua);
+    ua = nextu(ua);
+  };
+  auto loadB = [&](bf16x8 (&dst)[4]) {
+    bf16_load_unit<NACT>(dst, B, ub);
+    ub = nextu(ub);
+  };
+  auto mma = [&](const bf16x8 (&a)[2], const bf16x8 (&b)[4]) {
+#pragma unroll
+    for (int ni = 0; ni < NACT; ++ni) {
+      acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[ni], acc[0][ni], 0, 0, 0);
+      acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[ni], acc[1][ni], 0, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int q = 0; q < BF_PRE; ++q)
+#pragma unroll
+    for (int ni = 0; ni < NACT; ++ni) ring[q][ni] = P.b[q][ni];
+#pragma unroll
+  for (int q = BF_PRE; q < BF_RING - 1; ++q) loadB(ring[q]);   // unconditional: every slot is defined here
+  readA(a0);
+  int s = 0;
+  for (; s + BF_RING <= nu; s += BF_RING) {   // static ring slots; one unit refilled per step, BF_RING - 1 steps ahead
+#pragma unroll
+    for (int q = 0; q < BF_RING; q += 2) {
+      loadB(ring[(q + BF_RING - 1) % BF_RING]);
+      readA(a1);
+      mma(a0, ring[q]);
+      loadB(ring[q % BF_RING]);
+      readA(a0);
+      mma(a1, ring[q + 1]);
+    }
+  }
+  // tail: the remaining (< BF_RING) units sit in ring slots 0 .. rem-1; a0 holds the rows of position s
+#pragma unroll
+  for (int q = 0; q < BF_RING - 1; ++q) {
+    if (s + q < nu) {
+      if (q & 1) { readA(a0); mma(a1, ring[q]); }
+      else { readA(a1); mma(a0, ring[q]); }
+    }
+  }
+}
+
+__device__ __forceinline__ void bf16_kloop_dispatch(f32x16 (&acc)[2][4], const __bf16* ap, const __bf16* wfb, int U, int w,
+                                                    int lane, int nu, int nact, const Bf16Pre& P) {
+  switch (nact) {
+    case 4: bf16_kloop<4>(acc, ap, wfb, U, w, lane, nu, P); break;
+    case 3: bf16_kloop<3>(acc, ap, wfb, U, w, lane, nu, P); break;
+    case 2: bf16_kloop<2>(acc, ap, wfb, U, w, lane, nu, P); break;
+    case 1: bf16_kloop<1>(acc, ap, wfb, U, w, lane, nu, P); break;
+    default: break;
+  }
+}
+
+// S: the slab (bf16 view for the hidden layers; the LAST hidden activation is written as fp32, row stride FLD, for the fp32
+// output layer / backward head).  Segment mode: xs / hu / hwx as in fused_forward_body, all values rounded to bf16.
+__device__ __forceinline__ void fused_forward_bf16_body(const FusedFwdArgs& p, float* S, float4* xs, float (*hu)[FMAXW],
+                                                        float4 (*hwx)[FMAXW]) {
+  __bf16* SH = reinterpret_cast<__bf16*>(S);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int row0 = blockIdx.x * FROWS;
+  const bool segm = p.seg.wg_per_seg > 0;
+  Bf16Pre R;
+  const int lfirst = (segm && p.n_hidden > 1) ? 1 : 0;
+  bf16_prefetch(R, reinterpret_cast<const __bf16*>(p.ly[lfirst].wf), p.ly[lfirst].U, w, lane,
+                fused_nact(p.ly[lfirst].out_dim, w), (p.ly[lfirst].in + 15) >> 4);
+  if (segm) {
+    if (tid < FROWS) {
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + tid < p.N) {
+        const float* q = p.seg.xyz + (size_t)(row0 + tid) * p.seg.G;
+        x.x = bf16_round(q[0]);
+        if (p.seg.G > 1) x.y = bf16_round(q[1]);
+        if (p.seg.G > 2) x.z = bf16_round(q[2]);
+        if (p.seg.G > 3) x.w = bf16_round(q[3]);
+      }
+      xs[tid] = x;
+    }
+    const int sidx = blockIdx.x / p.seg.wg_per_seg;
+#pragma unroll
+    for (int t = 0; t < FHOIST; ++t) {
+      const FusedHoist& H = p.seg.h[t];
+      if (H.layer < 0) continue;
+      const int od = p.ly[H.layer].out_dim;
+      for (int c = tid; c < od; c += 256) {
+        hu[t][c] = p.seg.U[((size_t)sidx * FHOIST + t) * p.seg.ldu + c];
+        const float* q = H.wx + (size_t)c * H.ldw;
+        float4 x = make_float4(bf16_round(q[0]), 0.f, 0.f, 0.f);
+        if (p.seg.G > 1) x.y = bf16_round(q[1]);
+        if (p.seg.G > 2) x.z = bf16_round(q[2]);
+        if (p.seg.G > 3) x.w = bf16_round(q[3]);
+        hwx[t][c] = x;
+      }
+    }
+  } else {
+    fused_load_x0_h(SH, p.x0, p.ldx0, p.W0, row0, p.N, 0);
+  }
+  __syncthreads();
+#ifdef DSDF_LAB
+  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 0] = __builtin_amdgcn_s_memtime();
+#endif
+  for (int l = 0; l < p.n_hidden; ++l) {
+    const FusedLayer& L = p.ly[l];
+    const int nu = (L.in + 15) >> 4, nact = fused_nact(L.out_dim, w);
+    f32x16 acc[2][4];
+    float biasv[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int col = 32 * (w + 4 * ni) + fr;
+      biasv[ni] = col < L.out_dim ? L.bias[col] : 0.f;
+    }
+    int hidx = -1;
+    if (segm) hidx = l == p.seg.h[0].layer ? 0 : (l == p.seg.h[1].layer ? 1 : -1);
+    if (hidx >= 0) {
+      fused_hoist_init(acc, hu[hidx], hwx[hidx], xs, L.out_dim, w, fr, fh);
+    } else {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][ni][r] = 0.f;
+    }
+    if (nu > 0) {
+      bf16_kloop_dispatch(acc, SH + fr * FLDH + 8 * fh, reinterpret_cast<const __bf16*>(L.wf), L.U, w, lane, nu, nact, R);
+      if (l + 1 < p.n_hidden) {   // the next layer's first units travel while this layer's epilogue runs
+        const FusedLayer& Ln = p.ly[l + 1];
+        bf16_prefetch(R, reinterpret_cast<const __bf16*>(Ln.wf), Ln.U, w, lane, fused_nact(Ln.out_dim, w), (Ln.in + 15) >> 4);
+      }
+    }
+#ifdef DSDF_LAB
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 1 + 3 * l] = __builtin_amdgcn_s_memtime();
+#endif
+    __syncthreads();   // every wave has finished reading the slab: it may be overwritten in place
+#ifdef DSDF_LAB
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 2 + 3 * l] = __builtin_amdgcn_s_memtime();
+#endif
+    const bool last_hidden = l + 1 == p.n_hidden;
+    if (L.x0_col >= 0) fused_load_x0_h(SH, p.x0, p.ldx0, p.W0, row0, p.N, L.x0_col);
+    {
+      const bool drop = L.drop_thr != 0u;
+      const bool even = ((p.row_offset + (uint32_t)row0) & 1u) == 0u;
+      if (last_hidden) {   // the output layer / the backward head read fp32: its input goes to the slab as fp32
+        if (!drop) fused_fwd_epilogue<false, true, false>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+        else if (even) fused_fwd_epilogue<true, true, false>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+        else fused_fwd_epilogue<true, false, false>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+      } else {
+        if (!drop) fused_fwd_epilogue<false, true, true>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+        else if (even) fused_fwd_epilogue<true, true, true>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+        else fused_fwd_epilogue<true, false, true>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+      }
+    }
+    if (!last_hidden && L.x0_col < 0) {      // zero pad [out_dim, roundup16) of the bf16 slab (the x0 loader pads its own end)
+      const int zc = ((L.out_dim + 15) & ~15) - L.out_dim;
+      for (int i = tid; i < FROWS * zc; i += 256) SH[(i / zc) * FLDH + L.out_dim + (i % zc)] = (__bf16)0.f;
+    }
+    __syncthreads();
+#ifdef DSDF_LAB
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 3 + 3 * l] = __builtin_amdgcn_s_memtime();
+#endif
+  }
+  if (p.y_out == nullptr && p.u_out == nullptr) return;   // training: the backward head recomputes the output layer from the slab
+  float4 qv[2];
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc) {
+    const int c = 4 * lane + 256 * cc;
+    qv[cc] = c < p.in_last ? *reinterpret_cast<const float4*>(p.w_last + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float blast = p.b_last[0];
+  for (int rr = 0; rr < FROWS / 4; ++rr) {
+    const int row = (FROWS / 4) * w + rr;
+    float dot = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      const int c = 4 * lane + 256 * cc;
+      if (c < p.in_last) {
+        const float4 a = *reinterpret_cast<const float4*>(S + row * FLD + c);
+        dot += a.x * qv[cc].x + a.y * qv[cc].y + a.z * qv[cc].z + a.w * qv[cc].w;
+      }
+    }
+    const float u = wave_sum(dot) + blast;
+    const float t1 = p.use_tanh ? tanhf(u) : u;
+    if (lane == 0 && row0 + row < p.N) {
+      if (p.y_out) p.y_out[row0 + row] = tanhf(t1);
+      if (p.u_out) p.u_out[row0 + row] = u;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void fused_forward_bf16_kernel(const FusedFwdArgs p) {
+  __shared__ __attribute__((aligned(16))) float S[FROWS * FLD];   // bf16 view for the hidden layers, fp32 for the output layer
+  __shared__ float4 xs[FROWS];
+  __shared__ float hu[FHOIST][FMAXW];
+  __shared__ float4 hwx[FHOIST][FMAXW];
+  fused_forward_bf16_body(p, S, xs, hu, hwx);
+}
+
 // ===================================================================================================================
 // Fused backward dX chain.  Slab = dP_l [64][out_l]; per layer l = last-1 .. 1:
 //   dP_{l-1}[:, c] = (dP_l W_l)[:, c] * [a_l[:, c] > 0] * scale      c <  mask_cols (= out_{l-1})   -> slab, global dP_{l-1},
@@ -574,8 +910,6 @@ struct FusedBwdHead {
 };
 struct FusedBwdArgs {
   int n_layers, N;                 // entries of ly[], processed in order (deepest layer first)
-  int mask_t;                      // 0: maskbits as fused_fwd_epilogue writes them; 1: [n_wg][2 m][FMAXW columns], bit r of word (m, c) =
-                                   //    output[32m + r][c] > 0 (the 8-wave bf16 forward, fused_bf16x8.hpp)
   const float* dp_in; int ld_in; int w_in;   // HEAD_DP_GIVEN: dP of the deepest hidden layer [N][ld_in], w_in columns
   const float* xyz; int G;                   // segment mode ([N][G], G <= FGEO), else nullptr
   FusedBwdHead head;
@@ -764,22 +1098,7 @@ __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float
     const FusedBView bv = fused_bview(L.wtf, L.U, w, lane);
     const float* ap = S + fr * FLD + 8 * fh;
     uint4 mq = make_uint4(0u, 0u, 0u, 0u);
-    if (L.maskbits != nullptr) {
-      if (!p.mask_t) {
-        mq = *reinterpret_cast<const uint4*>(L.maskbits + ((size_t)blockIdx.x * 256 + tid) * 4);
-      } else {   // one word per (m, column) with the rows in natural order: pick this lane's 16 rows (crow(r) + 4 fh) into the usual order
-        uint32_t q[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) {
-            const uint32_t x = L.maskbits[(size_t)blockIdx.x * (2 * FMAXW) + m * FMAXW + 32 * (w + 4 * ni) + fr] >> (4 * fh);
-            const uint32_t pk = (x & 0xFu) | ((x >> 4) & 0xF0u) | ((x >> 8) & 0xF00u) | ((x >> 12) & 0xF000u);
-            q[2 * m + (ni >> 1)] |= pk << (16 * (ni & 1));
-          }
-        mq = make_uint4(q[0], q[1], q[2], q[3]);
-      }
-    }
+    if (L.maskbits != nullptr) mq = *reinterpret_cast<const uint4*>(L.maskbits + ((size_t)blockIdx.x * 256 + tid) * 4);
     fused_kloop_dispatch(acc, ap, bv, nu, fused_nact(L.ncols, w), PB);
     if (i + 1 < p.n_layers) {
       const FusedBwdLayer& Ln = p.ly[i + 1];
@@ -814,6 +1133,21 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_bwd_kernel(const FusedFwdArg
   float (*hsc)[2] = reinterpret_cast<float (*)[2]>(scratch + 4 * 2 * FMAXW / 4);
   fused_forward_body(f, S, xs, hu, hwx, 150 * 1024);
   __syncthreads();
+  fused_backward_body(b, S, xs, hred, hsc, true);
+}
+
+// Config 5 training step: bf16 forward and fp32 backward of the same 64 points in one launch (same LDS plan as above).
+__global__ __launch_bounds__(256, 1) void fused_fwd_bf16_bwd_kernel(const FusedFwdArgs f, const FusedBwdArgs b) {
+  __shared__ __attribute__((aligned(16))) float S[FROWS * FLD];
+  __shared__ float4 xs[FROWS];
+  __shared__ float4 scratch[FHOIST * FMAXW + FHOIST * FMAXW / 4];
+  float (*hu)[FMAXW] = reinterpret_cast<float (*)[FMAXW]>(scratch);
+  float4 (*hwx)[FMAXW] = reinterpret_cast<float4 (*)[FMAXW]>(scratch + FHOIST * FMAXW / 4);
+  float (*hred)[2 * FMAXW] = reinterpret_cast<float (*)[2 * FMAXW]>(scratch);
+  float (*hsc)[2] = reinterpret_cast<float (*)[2]>(scratch + 4 * 2 * FMAXW / 4);
+  fused_forward_bf16_body(f, S, xs, hu, hwx);
+  __syncthreads();
+  // (the backward body refills xs with the UNROUNDED xyz: the fp32 backward / dW use the fp32 layer inputs)
   fused_backward_body(b, S, xs, hred, hsc, true);
 }
 

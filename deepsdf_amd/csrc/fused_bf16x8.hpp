@@ -25,7 +25,7 @@ namespace dsdf {
 
 constexpr int F8_THREADS = 512;
 #ifndef BF8_RING_UNITS
-#define BF8_RING_UNITS 6
+#define BF8_RING_UNITS 3
 #endif
 constexpr int BF8_RING = BF8_RING_UNITS;   // multiple of 3; k-units of weights in flight per wave + 1 (2 KiB each)
 
@@ -113,7 +113,7 @@ __device__ __forceinline__ void bf8_kloop(f32x16 (&acc)[2][2], const __bf16* ap,
   auto mma = [&](const bf16x8 (&x)[2], const bf16x8 (&b)[2]) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], x[0], acc[0][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], x[0], acc[0][j], 0, 0, 0);   // D = W X^T
       acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], x[1], acc[1][j], 0, 0, 0);
     }
   };
@@ -216,66 +216,33 @@ __device__ __forceinline__ void bf8_hoist_init(f32x16 (&acc)[2][2], const float*
   }
 }
 
-// lane LANE of `old` := the scalar `sval` (v_writelane_b32; the lane select is an immediate, so the loops around it are compile-time).
-// This compiler has no builtin for it, but the LLVM intrinsic is reachable through its symbol name.  NOT inline asm: the hazard
-// recogniser does not look into asm, and a v_writelane right behind the v_cmp that produced its scalar operand needs a wait state
-// (the asm version wrote wrong mask words: every gradient below the last hidden layer came out wrong).
-extern "C" __device__ int dsdf_llvm_writelane(int, int, int) __asm("llvm.amdgcn.writelane.i32");
-template <int LANE>
-__device__ __forceinline__ uint32_t bf8_writelane(uint32_t old, uint32_t sval) {
-  return (uint32_t)dsdf_llvm_writelane((int)sval, LANE, (int)old);
-}
-
-// Everything the epilogue of one layer needs besides the accumulators (wave-uniform unless noted).
+// Everything the epilogue of one layer needs besides the accumulators (wave-uniform).
 struct Bf8Epi {
   __bf16* OUT;            // next layer's input slab
   int od, odp;            // out_dim; columns this layer owns in the slab (out_dim, or rounded up to the k-unit when no x0 columns
                           // follow: the pad is written as zeros -- features past out_dim come out as exactly 0 by themselves)
   const float* btab;      // LDS: bias per column (0 past out_dim)
-  const uint32_t* cktab;  // LDS: dropout column keys
-  __amdgpu_buffer_rsrc_t rsrc; int ldb;   // TRAIN: the global activation copy of this workgroup's rows (rows >= N are out of range)
-  uint32_t* maskw;        // TRAIN: this workgroup's mask words [2 m][FMAXW columns] (bit r of word (m, c) = output[32m + r][c] > 0), or nullptr
-  uint32_t thr; float scale;
-  uint32_t pm[2];         // per lane: (global row of (m, fr) >> 1) * 0x9E3779B1
-  int par16;              // per lane: 16 * (global row & 1)  -- which half of the pair hash is this row's
 };
 
-// One n-tile: bias + ReLU (+ dropout) on the lane's 2 x 16 values = rows 32m + fr, features 32t + 8g + 4fh + i.
+// One n-tile: bias + ReLU on the lane's 2 x 16 values = rows 32m + fr, features 32t + 8g + 4fh + i.
 //   !LASTL: -> bf16 -> OUT slab, 4 features per 8-byte store;   LASTL: the output layer's dot product instead (part[m])
-//   TRAIN : + the fp32 activation copy (16-byte stores) + the keep/positive bits for the backward: ballot over the 64 lanes =
-//           32 rows of column 8g+i and of column 8g+4+i, collected with v_writelane into ONE register whose lane c then holds the
-//           32-row word of column c of the tile
 // FULL: the tile ends inside the layer's columns -- no checks at all; the one ragged tile of a layer takes the guarded stores.
-template <bool FULL, bool TRAIN, bool DROP, bool LASTL>
+template <bool FULL, bool LASTL>
 __device__ __forceinline__ void bf8_epilogue_tile(const f32x16& a0, const f32x16& a1, const Bf8Epi& E, const float (&wl)[16],
                                                   float (&part)[2], int t, int lane) {
   typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   const int fr = lane & 31, fh = lane >> 5;
-  uint32_t mw[2] = {0u, 0u};
-  bf8_static_for(std::make_integer_sequence<int, 4>{}, [&](auto gc) __attribute__((always_inline)) {
-    constexpr int G = decltype(gc)::value;
-    constexpr int g = G;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
     const int f0 = 32 * t + 8 * g + 4 * fh;
     const float4 b4 = *reinterpret_cast<const float4*>(E.btab + f0);
     const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-    uint32_t ck[4] = {0u, 0u, 0u, 0u};
-    if constexpr (DROP) {
-      const uint4 c4 = *reinterpret_cast<const uint4*>(E.cktab + f0);
-      ck[0] = c4.x; ck[1] = c4.y; ck[2] = c4.z; ck[3] = c4.w;
-    }
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       const f32x16& a = m == 0 ? a0 : a1;
       float v[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        v[i] = fmaxf(a[4 * g + i] + bb[i], 0.f);
-        if constexpr (DROP) {
-          const uint32_t h = lowbias32(ck[i] ^ E.pm[m]);
-          v[i] = ((h >> E.par16) & 0xFFFFu) >= E.thr ? v[i] * E.scale : 0.f;
-        }
-      }
+      for (int i = 0; i < 4; ++i) v[i] = fmaxf(a[4 * g + i] + bb[i], 0.f);
       if constexpr (LASTL) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) part[m] = fmaf(v[i], wl[4 * g + i], part[m]);   // (wl is 0 past out_dim)
@@ -290,42 +257,17 @@ __device__ __forceinline__ void bf8_epilogue_tile(const f32x16& a0, const f32x16
             if (f0 + i < E.odp) dst[i] = (__bf16)v[i];
         }
       }
-      if constexpr (TRAIN) {
-        const uint32_t voff = (uint32_t)((32 * m + fr) * E.ldb + f0 * 4);
-        if (FULL || f0 + 3 < E.od) {
-          const u32x4 q = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-          __builtin_amdgcn_raw_buffer_store_b128(q, E.rsrc, voff, 0, FUSED_STORE_AUX);
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (f0 + i < E.od) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[i]), E.rsrc, voff + 4 * i, 0, FUSED_STORE_AUX);
-        }
-        if (E.maskw != nullptr) {   // (wave-uniform)
-          bf8_static_for(std::make_integer_sequence<int, 4>{}, [&](auto ic) __attribute__((always_inline)) {
-            constexpr int i = decltype(ic)::value;
-            const unsigned long long bal = __builtin_amdgcn_ballot_w64(v[i] > 0.f);
-            mw[m] = bf8_writelane<8 * G + i>(mw[m], (uint32_t)bal);
-            mw[m] = bf8_writelane<8 * G + 4 + i>(mw[m], (uint32_t)(bal >> 32));
-          });
-        }
-      }
-    }
-  });
-  if constexpr (TRAIN) {
-    if (E.maskw != nullptr && lane < 32) {
-      E.maskw[32 * t + lane] = mw[0];
-      E.maskw[FMAXW + 32 * t + lane] = mw[1];
     }
   }
 }
-template <int NT, bool TRAIN, bool DROP, bool LASTL>
+template <int NT, bool LASTL>
 __device__ __forceinline__ void bf8_epilogue(const f32x16 (&acc)[2][2], const Bf8Epi& E, const float (&wl)[2][16], float (&part)[2],
                                              int t0, int lane) {
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int t = t0 + 8 * j;
-    if (32 * t + 32 <= E.od) bf8_epilogue_tile<true, TRAIN, DROP, LASTL>(acc[0][j], acc[1][j], E, wl[j], part, t, lane);
-    else bf8_epilogue_tile<false, TRAIN, DROP, LASTL>(acc[0][j], acc[1][j], E, wl[j], part, t, lane);
+    if (32 * t + 32 <= E.od) bf8_epilogue_tile<true, LASTL>(acc[0][j], acc[1][j], E, wl[j], part, t, lane);
+    else bf8_epilogue_tile<false, LASTL>(acc[0][j], acc[1][j], E, wl[j], part, t, lane);
   }
 }
 
@@ -356,19 +298,19 @@ __device__ __forceinline__ void bf8_load_x0(__bf16* S, const float* x0, int ldx0
   }
 }
 
-// TRAIN = false: inference (dsdf_decode / dsdf_decode_latent: no copies, no dropout, no mask words);
-// TRAIN = true : training / module form -- every layer's activation goes to FusedLayer::out as fp32 (what the fp32 backward and the
-//                dW GEMMs read), FusedLayer::maskbits receives the mask words in the layout described at Bf8Epi::maskw
-//                (FusedBwdArgs::mask_t tells the backward), dropout per FusedLayer::drop_*.
-template <bool TRAIN>
+// Inference only (dsdf_decode / dsdf_decode_latent / the module's eval forward without copies): no activation copies, no dropout, no
+// mask bits.  The training form keeps the 4-wave kernels of fused.hpp: with 268 MB of fp32 activation copies per forward the layer
+// is bound by the store path, not by the weight stream, and neither form of this kernel's epilogue (16-byte stores of one row per
+// lane; 4-byte or quad-transposed 16-byte stores of the untransposed layout) got its stores out faster than the 4-wave kernel's
+// (measured: 139 / 175 us against 118 us).
 __global__ __launch_bounds__(F8_THREADS, 1) void fused_forward_bf16x8_kernel(const FusedFwdArgs p) {
   __shared__ __attribute__((aligned(16))) __bf16 SLAB[2 * FROWS * FLDH];   // layer l reads slab l & 1 and writes the other
   __shared__ float4 xs[FROWS];
   __shared__ float hu[FHOIST][FMAXW];
   __shared__ float4 hwx[FHOIST][FMAXW];
   __shared__ float red[16][FROWS];     // output-layer partials: [wave][fh][row]
-  __shared__ __attribute__((aligned(16))) float btab[FMAXW];      // bias / dropout column keys of the layer a set is working on: each set
-  __shared__ __attribute__((aligned(16))) uint32_t cktab[FMAXW];  // writes and reads only the columns of ITS n-tiles (see the schedule)
+  __shared__ __attribute__((aligned(16))) float btab[FMAXW];      // bias of the layer a set is working on: each set writes and reads
+                                                                  // only the columns of ITS n-tiles (see the schedule)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int set = w >> 2, t0 = 2 * (w & 3) + set;     // this wave's n-tiles: t0 and t0 + 8
@@ -413,11 +355,10 @@ __global__ __launch_bounds__(F8_THREADS, 1) void fused_forward_bf16x8_kernel(con
   f32x16 acc[2][2];
   float wl[2][16];
   float part[2] = {0.f, 0.f};
-  const int rows_here = min(FROWS, p.N - row0);
-  // the column of the per-set tables this thread fills: the k-th column of the set's 8 n-tiles
+  // the column of the per-set table this thread fills: the k-th column of the set's 8 n-tiles
   const int tcol = 32 * (2 * ((tid & 255) >> 5) + set) + (tid & 31);
 
-  // everything a wave needs before the k-loop of layer l: accumulators, its set's epilogue tables; returns the wave's n-tile count
+  // everything a wave needs before the k-loop of layer l: accumulators, its set's bias table; returns the wave's n-tile count
   auto begin = [&](int l) __attribute__((always_inline)) -> int {
     const FusedLayer& L = p.ly[l];
     const int nt = (32 * t0 < L.out_dim ? 1 : 0) + (32 * (t0 + 8) < L.out_dim ? 1 : 0);
@@ -426,16 +367,15 @@ __global__ __launch_bounds__(F8_THREADS, 1) void fused_forward_bf16x8_kernel(con
     if (hidx >= 0) bf8_hoist_init(acc, hu[hidx], hwx[hidx], xs, L.out_dim, t0, fr, fh);
     else bf8_zero(acc);
     btab[tcol] = tcol < L.out_dim ? L.bias[tcol] : 0.f;
-    if (TRAIN && L.drop_thr != 0u) cktab[tcol] = drop_col_key((uint32_t)tcol, L.drop_key);
     if (l + 1 == nh) bf8_load_vec(wl, p.w_last, min(L.out_dim, p.in_last), t0, fh);
     return nt;
   };
   auto kloop = [&](int l, int nt, auto barc) __attribute__((always_inline)) {   // barc: set A (mid-layer barrier inside) or set B
+    constexpr bool BAR = decltype(barc)::value;
     const FusedLayer& L = p.ly[l];
     const int nu = (L.in + 15) >> 4;
     const Bf8View B = bf8_view(reinterpret_cast<const __bf16*>(L.wf), (L.out_dim + 31) >> 5, t0, lane);
-    bf8_kloop_dispatch<decltype(barc)::value>(acc, SLAB + (l & 1) * (FROWS * FLDH) + fr * FLDH + 8 * fh, B, nu,
-                                              decltype(barc)::value ? 0 : 1, nt);
+    bf8_kloop_dispatch<BAR>(acc, SLAB + (l & 1) * (FROWS * FLDH) + fr * FLDH + 8 * fh, B, nu, BAR ? 0 : 1, nt);
   };
   auto epilogue = [&](int l, int nt) __attribute__((always_inline)) {
     if (nt == 0) return;
@@ -444,53 +384,55 @@ __global__ __launch_bounds__(F8_THREADS, 1) void fused_forward_bf16x8_kernel(con
     E.OUT = SLAB + ((l + 1) & 1) * (FROWS * FLDH);
     E.od = L.out_dim;
     E.odp = L.x0_col >= 0 ? L.out_dim : ((L.out_dim + 15) & ~15);
-    E.btab = btab; E.cktab = cktab;
-    const bool has_out = TRAIN && L.out != nullptr;
-    E.rsrc = __builtin_amdgcn_make_buffer_rsrc(has_out ? (void*)(L.out + (size_t)row0 * L.ld_out) : (void*)SLAB, 0,
-                                               has_out ? rows_here * L.ld_out * 4 : 0, 0x00020000);
-    E.ldb = L.ld_out * 4;
-    E.maskw = (TRAIN && L.maskbits != nullptr) ? L.maskbits + (size_t)blockIdx.x * (2 * FMAXW) : nullptr;
-    E.thr = L.drop_thr; E.scale = L.drop_scale;
-    const uint32_t grow = p.row_offset + (uint32_t)(row0 + fr);
-    E.pm[0] = (grow >> 1) * 0x9E3779B1u; E.pm[1] = ((grow + 32u) >> 1) * 0x9E3779B1u;
-    E.par16 = (int)(grow & 1u) * 16;
-    const bool lastl = l + 1 == nh;
-    const bool drop = TRAIN && L.drop_thr != 0u;
-#define BF8_EPI(NT_, DROP_, LAST_) bf8_epilogue<NT_, TRAIN, DROP_, LAST_>(acc, E, wl, part, t0, lane)
-    if (nt == 2) {
-      if (lastl) { if (drop) BF8_EPI(2, true, true); else BF8_EPI(2, false, true); }
-      else       { if (drop) BF8_EPI(2, true, false); else BF8_EPI(2, false, false); }
+    E.btab = btab;
+    if (l + 1 == nh) {
+      if (nt == 2) bf8_epilogue<2, true>(acc, E, wl, part, t0, lane);
+      else bf8_epilogue<1, true>(acc, E, wl, part, t0, lane);
     } else {
-      if (lastl) { if (drop) BF8_EPI(1, true, true); else BF8_EPI(1, false, true); }
-      else       { if (drop) BF8_EPI(1, true, false); else BF8_EPI(1, false, false); }
+      if (nt == 2) bf8_epilogue<2, false>(acc, E, wl, part, t0, lane);
+      else bf8_epilogue<1, false>(acc, E, wl, part, t0, lane);
     }
-#undef BF8_EPI
   };
 
+#ifdef DSDF_LAB
+  // lab: s_memtime stamps of wave 0 (set A, slots 0..31) and wave 4 (set B, slots 32..63) of every workgroup, 4 per layer
+  auto stamp = [&](int slot) __attribute__((always_inline)) {
+    if (p.dbg && lane == 0 && (w & 3) == 0 && slot < 32) p.dbg[blockIdx.x * 64 + 32 * set + slot] = __builtin_amdgcn_s_memtime();
+  };
+#else
+  auto stamp = [&](int) __attribute__((always_inline)) {};
+#endif
   if (set == 0) {
     for (int l = 0; l < nh; ++l) {
+      stamp(4 * l);
       const int nt = begin(l);
       kloop(l, nt, std::true_type{});        // K_l(UA) | barrier: E_B(l-1) is complete, this set's tables of layer l are visible | K_l(UB)
+      stamp(4 * l + 1);
       epilogue(l, nt);
+      stamp(4 * l + 2);
       if (p.ly[l].x0_col >= 0 && l + 1 < nh)   // general mode, skip layer: x0 joins the next layer's input (columns no epilogue writes)
         bf8_load_x0<256>(SLAB + ((l + 1) & 1) * (FROWS * FLDH), p.x0, p.ldx0, p.W0, row0, p.N, p.ly[l].x0_col, tid);
       __syncthreads();                       // E_A(l) (+ x0) is complete
+      stamp(4 * l + 3);
     }
     __syncthreads();
   } else {
     int nt_prev = 0;
     for (int l = 0; l <= nh; ++l) {
+      stamp(4 * l);
       if (l > 0) epilogue(l - 1, nt_prev);
+      stamp(4 * l + 1);
       __syncthreads();
+      stamp(4 * l + 2);
       if (l < nh) {
         const int nt = begin(l);
         kloop(l, nt, std::false_type{});     // K_l(UB) K_l(UA)
         nt_prev = nt;
+        stamp(4 * l + 3);
         __syncthreads();
       }
     }
   }
-  if (p.y_out == nullptr && p.u_out == nullptr) return;   // training: the backward head recomputes the output layer
   red[2 * w + fh][fr] = part[0];        // (each slot has exactly one writer)
   red[2 * w + fh][32 + fr] = part[1];
   __syncthreads();
