@@ -1,8 +1,8 @@
-// Config 5 forward, second form: 8 waves per 64-point workgroup in two STAGGERED sets, transposed accumulators.
+// Config 5 forward, inference form: 8 waves per 64-point workgroup in two STAGGERED sets, transposed accumulators.
 //
 // Why: with 64 points per CU a 512x512 bf16 layer is an L2 weight stream (17 k cycles, ~14 TB/s chip-wide) followed by a
-// VALU/LDS epilogue (8-13 k cycles) -- the 256 MFMAs per SIMD are only 8.2 k.  Weaving the epilogue into the k-loop of ONE wave
-// (fused.hpp BF_PIPELINED) lost to the compiler's scheduling/spills.  Here the overlap comes from two wave sets per SIMD instead:
+// VALU/LDS epilogue (8 k cycles in the 4-wave kernel of fused.hpp) -- the 256 MFMAs per SIMD are only 8.2 k.  Weaving the epilogue
+// into the k-loop of ONE wave lost to the compiler's scheduling/spills.  Here the overlap comes from two wave sets per SIMD instead:
 //   set A (waves 0-3) owns the EVEN 32-column n-tiles, set B (waves 4-7) the ODD ones (a wave: up to 2 n-tiles x 64 rows = 64
 //   accumulator registers).  B runs half a layer behind A:
 //        A:  K_l(UA) | K_l(UB)  E_l     | K_l+1(UA) | K_l+1(UB)  E_l+1 | ...
@@ -15,9 +15,10 @@
 // registers are the same either way), so a lane holds ONE point and 4 consecutive output features per register group: the
 // epilogue converts 4 values and writes them with one 8-byte LDS store (the untransposed form needs 128 two-byte stores per lane
 // and layer), and the 512 -> 1 output layer becomes a per-lane dot product folded into the last hidden layer's epilogue (no fp32
-// slab).  Inference form (no activation copies, no dropout, no mask bits): dsdf_decode / dsdf_decode_latent.
+// slab).  No activation copies, no dropout, no mask bits: dsdf_decode / dsdf_decode_latent (the training form stays with the
+// 4-wave kernels, see the kernel's comment below).
 // Specification: oracle decoder_forward(bf16=True); the k-units are contracted in another order than in the 4-wave kernel
-// (own set's units first, rotated per workgroup), which only permutes the fp32 accumulation.
+// (own set's units first), which only permutes the fp32 accumulation.
 #pragma once
 #include "fused.hpp"
 
@@ -25,7 +26,7 @@ namespace dsdf {
 
 constexpr int F8_THREADS = 512;
 #ifndef BF8_RING_UNITS
-#define BF8_RING_UNITS 3
+#define BF8_RING_UNITS 6
 #endif
 constexpr int BF8_RING = BF8_RING_UNITS;   // multiple of 3; k-units of weights in flight per wave + 1 (2 KiB each)
 
