@@ -16,6 +16,7 @@ Beside the contract's line (value / ms_per_step over the barrier-bracketed timed
                   (MFMA FLOPs actually issued, from SQ counters) measured by rocprofv3 --pmc child passes of THIS command
   cpu_baseline    the step in stock torch ops (oracle/torch_native.py) on this host: all cores and one core
   config.one_scene_ms_per_step   the locality extreme B=1 x S=16384
+  config.inference_forward       --config bf16 only: the bf16 forward alone (one code x the step's points)
 """
 import argparse
 import ctypes as C
@@ -294,6 +295,25 @@ def main():
         torch.cuda.synchronize()
         one_scene = 1e3 * (time.perf_counter() - t1) / 100
 
+    # ---- config 5 only: its INFERENCE forward alone (one code x the step's points: dsdf_decode_latent = hoist + the 8-wave kernel) ----
+    bf16_fwd = None
+    if rank == 0 and world == 1 and bf16 and not args.no_extras:
+        z = (torch.randn(L, generator=torch.Generator().manual_seed(9)) / math.sqrt(L)).to(dev)
+        q = (torch.rand(n_local, 3, generator=torch.Generator().manual_seed(10)) * 2 - 1).to(dev)
+        for _ in range(10):
+            eng.decode_latent(z, q)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(100):
+            eng.decode_latent(z, q)
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / 100
+        tf = 2.0 * n_local * spec.w_mac / (us * 1e-6) / 1e12
+        bf16_fwd = dict(us_per_call=us, tflops=tf, frac_of_bf16_dense_peak=tf / 2500.0, points=n_local,
+                        note="HIP events around 100 calls of Engine.decode_latent (seg_hoist_kernel + fused_forward_bf16x8_kernel + the "
+                             "host-side launch path); the kernel alone: profiles/r02_bf16_decode_kernel_stats.csv")
+
     # ---- PMC child passes (GPU, child processes) run WHILE the CPU baseline runs (host cores); both after all GPU timing ----
     if want_pmc:
         extra = ["--scenes-per-batch", str(B), "--samples", str(S), "--config", args.config]
@@ -335,6 +355,8 @@ def main():
                             f"configs[2]: {total_scenes} scenes sharded over {world} ranks, {n_local} pts/step/rank, RCCL all-reduce of "
                             "decoder grads (asynchronous, latent Adam under it)"),
                "points_per_step_per_gpu": n_local, "headline_config": headline, "parallelism": f"dp{world}", "final_loss": loss}
+        if bf16_fwd is not None:
+            cfg["inference_forward"] = bf16_fwd
         if one_scene is not None:
             cfg["one_scene_ms_per_step"] = one_scene
             cfg["one_scene_value"] = 16384 / (one_scene * 1e-3)
