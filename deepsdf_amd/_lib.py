@@ -6,7 +6,7 @@ import os
 from .build import LIB
 
 MAX_LAYERS = 16
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class DsdfNet(C.Structure):
@@ -14,7 +14,8 @@ class DsdfNet(C.Structure):
                 ("in_dim", C.c_int32 * MAX_LAYERS), ("out_dim", C.c_int32 * MAX_LAYERS),
                 ("weight_norm_mask", C.c_uint32), ("dropout_mask", C.c_uint32), ("skip_mask", C.c_uint32),
                 ("dropout_p", C.c_float), ("use_tanh", C.c_int32), ("fwd_bf16", C.c_int32),
-                ("latent_dropout", C.c_int32), ("xyz_in_all", C.c_int32), ("ln_param_mask", C.c_uint32)]
+                ("latent_dropout", C.c_int32), ("xyz_in_all", C.c_int32), ("ln_param_mask", C.c_uint32),
+                ("gemm_split", C.c_int32)]
 
 
 class DsdfParamLayout(C.Structure):

@@ -110,6 +110,13 @@ int validate(const DsdfNet* n) {
   }
   if ((n->latent_dropout || n->xyz_in_all || n->ln_param_mask) && n->fwd_bf16)
     return fail(DSDF_E_INVALID, "fwd_bf16 is not available with latent_dropout / xyz_in_all / LayerNorm");
+  if (n->gemm_split) {
+    if (n->fwd_bf16 || n->latent_dropout || n->xyz_in_all || n->ln_param_mask)
+      return fail(DSDF_E_INVALID, "gemm_split is not available with fwd_bf16 / latent_dropout / xyz_in_all / LayerNorm");
+    for (int l = 0; l < n->n_layers; ++l)
+      if (n->in_dim[l] > 512 || (l < n->n_layers - 1 && n->out_dim[l] > 512))
+        return fail(DSDF_E_INVALID, "gemm_split needs every layer width <= 512 (layer %d: %d -> %d)", l, n->in_dim[l], n->out_dim[l]);
+  }
   if (n->ln_param_mask) {
     if (n->weight_norm_mask) return fail(DSDF_E_INVALID, "LayerNorm (ln_param_mask) and weight norm exclude each other");
     if (n->ln_param_mask >> n->n_layers) return fail(DSDF_E_INVALID, "ln_param_mask names a layer >= n_layers");
@@ -129,6 +136,8 @@ struct Packed {
   int64_t wf_off[DSDF_MAX_LAYERS], wtf_off[DSDF_MAX_LAYERS];
   int64_t wfb_off[DSDF_MAX_LAYERS];   // bf16 fragment copy of W for the bf16 forward (fused_bf16x8.hpp); offset in floats
   int uf[DSDF_MAX_LAYERS], utf[DSDF_MAX_LAYERS];   // k-units of 16 per n-tile
+  int64_t ws_off[DSDF_MAX_LAYERS], wts_off[DSDF_MAX_LAYERS];       // gemm_split: 3 bf16 planes of W / W^T in fragment order (offsets in floats)
+  int64_t ws_plane[DSDF_MAX_LAYERS], wts_plane[DSDF_MAX_LAYERS];   //   bf16 elements per plane
   int64_t total;
 };
 Packed packed_layout(const DsdfNet* n) {
@@ -150,6 +159,9 @@ Packed packed_layout(const DsdfNet* n) {
     p.wf_off[l] = o;  o += ntw * p.uf[l] * 512;
     p.wtf_off[l] = o; o += ntt * p.utf[l] * 512;
     p.wfb_off[l] = o; o += n->fwd_bf16 ? ntw * 32 * 256 : 0;   // 32 phase-major k-unit slots of 1 KiB per n-tile
+    p.ws_plane[l] = ntw * p.uf[l] * 512; p.wts_plane[l] = ntt * p.utf[l] * 512;     // (1 KiB = 512 bf16 per tile and k-unit)
+    p.ws_off[l] = o;  o += n->gemm_split ? 3 * p.ws_plane[l] / 2 : 0;
+    p.wts_off[l] = o; o += n->gemm_split ? 3 * p.wts_plane[l] / 2 : 0;
   }
   p.total = rup(o, 64);
   return p;
@@ -435,6 +447,10 @@ int materialize(const DsdfNet* net, const float* params, float* packed, hipStrea
     y.WTf = last ? nullptr : packed + pk.wtf_off[l];
     y.Wfb = (last || !net->fwd_bf16) ? nullptr : reinterpret_cast<__bf16*>(packed + pk.wfb_off[l]);
     y.Uf = pk.uf[l]; y.UTf = pk.utf[l];
+    const bool sp = net->gemm_split && !last;
+    y.Ws = sp ? reinterpret_cast<__bf16*>(packed + pk.ws_off[l]) : nullptr;
+    y.WTs = sp ? reinterpret_cast<__bf16*>(packed + pk.wts_off[l]) : nullptr;
+    y.ws_plane = pk.ws_plane[l]; y.wts_plane = pk.wts_plane[l];
     rows += y.out;
     tiles += ((y.out + 31) / 32) * y.tcols;
   }
@@ -539,7 +555,8 @@ int run_fused_forward(const DsdfNet* net, const Plan& P, void* ws, const float* 
   a.row_offset = row_offset;
   for (int l = 0; l < last; ++l) {
     FusedLayer& y = a.ly[l];
-    y.wf = net->fwd_bf16 ? packed + pk.wfb_off[l] : packed + pk.wf_off[l];   // bf16 forward: the bf16 fragment copy
+    y.wf = net->fwd_bf16 ? packed + pk.wfb_off[l] : (net->gemm_split ? packed + pk.ws_off[l] : packed + pk.wf_off[l]);   // (bf16 copy / split planes)
+    y.wplane = (int)(pk.ws_plane[l] * 2);   // bytes per plane (gemm_split)
     y.bias = params + L.bias_off[l];
     y.out = store_act ? at<float>(ws, P.in_off[l + 1]) : nullptr;
     y.ld_out = P.ld_in[l + 1];
@@ -580,7 +597,8 @@ int run_fused_forward(const DsdfNet* net, const Plan& P, void* ws, const float* 
   else if (net->fwd_bf16)            // with activation copies (module path; training goes out merged with the backward)
     hipLaunchKernelGGL(fused_forward_bf16_kernel, grid, dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL(fused_forward_kernel, grid, dim3(256), 0, st, a);
+    if (net->gemm_split) hipLaunchKernelGGL(fused_forward_split_kernel, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(fused_forward_kernel, grid, dim3(256), 0, st, a);
 #ifdef DSDF_LAB
   if (dbg && getenv("DSDF_LAB_DBG")) {
     (void)hipDeviceSynchronize();
@@ -803,7 +821,8 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
   for (int l = last - 1; l >= 0; --l) {
     if (l == 0 && ncols_dz <= 0) break;
     FusedBwdLayer& y = a.ly[cnt++];
-    y.wtf = packed + pk.wtf_off[l]; y.U = pk.utf[l]; y.K = net->out_dim[l];
+    y.wtf = net->gemm_split ? packed + pk.wts_off[l] : packed + pk.wtf_off[l]; y.U = pk.utf[l]; y.K = net->out_dim[l];
+    y.wplane = (int)(pk.wts_plane[l] * 2);
     if (l > 0) {
       const bool skip = (net->skip_mask >> l) & 1;
       y.mask_cols = net->out_dim[l - 1];
@@ -831,11 +850,13 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     if (fwd != nullptr) {
       ProfScope ps(DSDF_PROF_FUSED_FWD_BWD, 4.0 * (double)n * amac, st);   // forward + dX chain
       if (net->fwd_bf16) hipLaunchKernelGGL(fused_fwd_bf16_bwd_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
+      else if (net->gemm_split) hipLaunchKernelGGL(fused_fwd_bwd_split_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
       else hipLaunchKernelGGL(fused_fwd_bwd_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
       LAUNCH_OK("fused_fwd_bwd_kernel");
     } else {
       ProfScope ps(DSDF_PROF_FUSED_BWD, 2.0 * (double)n * amac, st);
-      hipLaunchKernelGGL(fused_backward_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, a);
+      if (net->gemm_split) hipLaunchKernelGGL(fused_backward_split_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL(fused_backward_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, a);
       LAUNCH_OK("fused_backward_kernel");
     }
   }
@@ -986,6 +1007,7 @@ FusedBwdHead make_head(const DsdfNet* net, const Plan& P, void* ws, const float*
 int check_common(const DsdfNet* net, const void* packed, const void* params, const void* ws) {
   TRY(validate(net));
   if (net->fwd_bf16 && !fused_enabled()) return fail(DSDF_E_INVALID, "fwd_bf16 exists only in the fused kernels (DSDF_NO_FUSED is set)");
+  if (net->gemm_split && !fused_enabled()) return fail(DSDF_E_INVALID, "gemm_split exists only in the fused kernels (DSDF_NO_FUSED is set)");
   if (!packed || !params || !ws) return fail(DSDF_E_INVALID, "NULL packed/params/workspace pointer");
   if (!aligned16(packed) || !aligned16(params) || (reinterpret_cast<uintptr_t>(ws) & 255))
     return fail(DSDF_E_INVALID, "packed/params must be 16-byte and workspace 256-byte aligned");

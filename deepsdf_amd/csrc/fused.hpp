@@ -41,7 +41,8 @@ constexpr int FMAXW = 512;       // widest layer the fused kernels handle
 #endif
 
 struct FusedLayer {
-  const float* wf;       // fragment-ordered B operand
+  const float* wf;       // fragment-ordered B operand (split mode: the three bf16 planes, `wplane` bytes apart)
+  int wplane;
   const float* bias;     // forward only
   float* out; int ld_out;          // global copy of this layer's output (activation for backward / dP for the dW GEMMs)
   int in, out_dim, U;              // K, N, k-units allocated per n-tile in wf
@@ -120,6 +121,7 @@ __device__ __forceinline__ constexpr int crow(int reg) { return (reg & 3) + 8 * 
 // Forward epilogue of one wave: bias + ReLU (+ dropout) on its 2x4 accumulators, written to the LDS slab (next
 // layer's input) and to the global activation copy.  Lean by construction: global stores are buffer stores (hardware
 // bounds check drops rows >= N and masked columns; row offsets are SCALAR), LDS stores use immediate offsets.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int FLDH = 520;        // slab row stride in bf16 elements (bf16 forward, fused_bf16x8.hpp)
 
 // HS: the slab holds bf16 (row stride FLDH) instead of fp32 (row stride FLD); the global activation copy stays fp32.
@@ -358,14 +360,156 @@ __device__ __forceinline__ void fused_kloop(f32x16 (&acc)[2][4], const float* ap
   if (u + 1 < nu) mma(a1, b1);
 }
 
-__device__ __forceinline__ void fused_kloop_dispatch(f32x16 (&acc)[2][4], const float* ap, const FusedBView& bv,
-                                                     int nu, int nact, FusedBSets& PB) {
-  switch (nact) {
-    case 4: fused_kloop<4>(acc, ap, bv, nu, PB); break;
-    case 3: fused_kloop<3>(acc, ap, bv, nu, PB); break;
-    case 2: fused_kloop<2>(acc, ap, bv, nu, PB); break;
-    case 1: fused_kloop<1>(acc, ap, bv, nu, PB); break;
-    default: break;
+// ---- fp32 GEMM on the bf16 matrix pipe: split mode (DsdfNet.gemm_split) ------------------------------------------------------------
+// Every fp32 operand value is cut into THREE bf16 terms  x = h + m + l  (8 + 8 + 8 mantissa bits: h = the top 16 bits of x, m = the top 16
+// bits of x - h, l = x - h - m; the subtractions are exact, so the sum is x exactly -- and bf16 keeps the fp32 exponent, nothing can
+// overflow), and a 16-deep tile product becomes 6 of the 9 cross products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation:
+//   a b  ~  al bh + ah bl + am bm + am bh + ah bm + ah bh        (dropped: am bl, al bm, al bl  <= 2^-24 |a b|)
+// Every bf16 x bf16 product is exact in fp32, so the result is as accurate as the fp32 MFMA's (tools/lab/split_accuracy.py: 2.4e-7 against
+// 2.5e-7 relative at K = 512; the parity tests run with the same tolerances).  6 x 32 cycles per tile and k-unit instead of 8 x 64.
+// WEIGHTS are cut once per step (wn_tiles_kernel: planes h, m, l of W and W^T in the bf16 fragment order); ACTIVATIONS / dP stay fp32
+// in the slab -- a lane's two 16-byte reads are exactly the 8 consecutive k the bf16 MFMA wants -- and are cut in registers, ~5.5
+// VALU instructions per value in the shadow of the MFMAs (bf16 MFMAs leave the VALU free).  First version: weights cut
+// in the k-loop too (264 VALU instructions per k-unit against 48 MFMAs = the VALU port exactly full): 553 us against 807.
+// Same accumulator layout as v_mfma_f32_32x32x2_f32: prologues and epilogues do not know the difference.
+struct Split3 { bf16x8 h, m, l; };
+__device__ __forceinline__ Split3 split8(const float4& q0, const float4& q1) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const float x[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+  uint32_t hw[4], mw[4], lw[4];
+#pragma unroll
+  for (int pr = 0; pr < 4; ++pr) {
+    float r[2], t[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float v = x[2 * pr + e];
+      r[e] = v - __uint_as_float(__float_as_uint(v) & 0xFFFF0000u);
+      t[e] = r[e] - __uint_as_float(__float_as_uint(r[e]) & 0xFFFF0000u);
+    }
+    // pack the high halves of two values into one register: element 2pr in the low 16 bits (v_perm_b32)
+    hw[pr] = __builtin_amdgcn_perm(__float_as_uint(x[2 * pr + 1]), __float_as_uint(x[2 * pr]), 0x07060302u);
+    mw[pr] = __builtin_amdgcn_perm(__float_as_uint(r[1]), __float_as_uint(r[0]), 0x07060302u);
+    lw[pr] = __builtin_amdgcn_perm(__float_as_uint(t[1]), __float_as_uint(t[0]), 0x07060302u);
+  }
+  Split3 s;
+  s.h = __builtin_bit_cast(bf16x8, (u32x4){hw[0], hw[1], hw[2], hw[3]});
+  s.m = __builtin_bit_cast(bf16x8, (u32x4){mw[0], mw[1], mw[2], mw[3]});
+  s.l = __builtin_bit_cast(bf16x8, (u32x4){lw[0], lw[1], lw[2], lw[3]});
+  return s;
+}
+
+struct SplitBSet { bf16x8 b[4][3]; };   // weights of k-unit 0 of the NEXT layer (4 n-tiles x 3 planes), requested before the epilogue
+struct SplitBView { __amdgpu_buffer_rsrc_t rsrc; int tbase[4]; int plane; int voff; };   // tbase[ni] = (w + 4 ni) * U; plane: bytes
+__device__ __forceinline__ SplitBView split_bview(const float* ws, int plane, int U, int w, int lane) {
+  SplitBView v;
+  v.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ws, 0, 0x7FFFFFFF, 0x00020000);
+  const int wsc = __builtin_amdgcn_readfirstlane(w);
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) v.tbase[ni] = (wsc + 4 * ni) * U;
+  v.plane = plane;
+  v.voff = lane * 16;
+  return v;
+}
+__device__ __forceinline__ bf16x8 split_bload(const SplitBView& B, int ni, int u, int pl) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(B.rsrc, B.voff, pl * B.plane + ((B.tbase[ni] + u) << 10), 0);
+  return __builtin_bit_cast(bf16x8, r);
+}
+__device__ __forceinline__ void split_prefetch_b(SplitBSet& P, const float* ws, int plane, int U, int w, int lane, int nact, int nu) {
+  if (nu <= 0) return;
+  const SplitBView B = split_bview(ws, plane, U, w, lane);
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+    if (ni < nact) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) P.b[ni][pl] = split_bload(B, ni, 0, pl);
+    }
+}
+
+template <int NACT>
+__device__ __forceinline__ void fused_kloop_split(f32x16 (&acc)[2][4], const float* ap, const SplitBView& bv, int nu, SplitBSet& PB) {
+  bf16x8 b0[NACT][3], b1[NACT][3], b2[NACT][3];
+  float4 a0[4], a1[4], a2[4];   // [m-tile + 2 * half]: 4 consecutive k of rows fr and 32 + fr
+  const int ulast = nu - 1;
+  auto loadB = [&](bf16x8 (&b)[NACT][3], int u) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ni = 0; ni < NACT; ++ni)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) b[ni][pl] = split_bload(bv, ni, u, pl);
+  };
+  auto readA = [&](float4 (&a)[4], int u) __attribute__((always_inline)) {
+    a[0] = *reinterpret_cast<const float4*>(ap + 16 * u);
+    a[1] = *reinterpret_cast<const float4*>(ap + 32 * FLD + 16 * u);
+    a[2] = *reinterpret_cast<const float4*>(ap + 16 * u + 4);
+    a[3] = *reinterpret_cast<const float4*>(ap + 32 * FLD + 16 * u + 4);
+  };
+  // 6 passes over the 2 x NACT accumulators: consecutive MFMAs never touch the same accumulator; small terms first
+  auto mma = [&](const float4 (&a)[4], const bf16x8 (&b)[NACT][3]) __attribute__((always_inline)) {
+    Split3 sa[2];
+    sa[0] = split8(a[0], a[2]);
+    sa[1] = split8(a[1], a[3]);
+#define SPLIT_PASS(AX, PL)                                                                                     \
+    _Pragma("unroll") for (int ni = 0; ni < NACT; ++ni) {                                                      \
+      acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[0].AX, b[ni][PL], acc[0][ni], 0, 0, 0);          \
+      acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[1].AX, b[ni][PL], acc[1][ni], 0, 0, 0);          \
+    }
+    SPLIT_PASS(l, 0) SPLIT_PASS(h, 2) SPLIT_PASS(m, 1) SPLIT_PASS(m, 0) SPLIT_PASS(h, 1) SPLIT_PASS(h, 0)
+#undef SPLIT_PASS
+  };
+#pragma unroll
+  for (int ni = 0; ni < NACT; ++ni)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) b0[ni][pl] = PB.b[ni][pl];     // unit 0 came with the cross-layer prefetch
+  loadB(b1, min(1, ulast));
+  readA(a0, 0);
+  int u = 0;
+  for (; u + 2 < nu; u += 3) {
+    loadB(b2, u + 2);
+    readA(a1, u + 1);
+    mma(a0, b0);
+    loadB(b0, min(u + 3, ulast));
+    readA(a2, u + 2);
+    mma(a1, b1);
+    loadB(b1, min(u + 4, ulast));
+    readA(a0, min(u + 3, ulast));
+    mma(a2, b2);
+  }
+  if (u < nu) {
+    if (u + 1 < nu) readA(a1, u + 1);
+    mma(a0, b0);
+  }
+  if (u + 1 < nu) mma(a1, b1);
+}
+
+// what a body needs from the k-loop, in either mode: the carried prefetch set, the prefetch, the loop
+template <bool SPLIT> struct KlSets { typedef FusedBSets type; };
+template <> struct KlSets<true> { typedef SplitBSet type; };
+template <bool SPLIT>
+__device__ __forceinline__ void kl_prefetch(typename KlSets<SPLIT>::type& PB, const float* wf, int wplane, int U, int w, int lane, int nact, int nu) {
+  if constexpr (SPLIT) split_prefetch_b(PB, wf, wplane, U, w, lane, nact, nu);
+  else fused_prefetch_b(PB, wf, U, w, lane, nact, nu);
+}
+template <bool SPLIT>
+__device__ __forceinline__ void fused_kloop_dispatch(f32x16 (&acc)[2][4], const float* ap, const float* wf, int wplane, int U, int w, int lane,
+                                                     int nu, int nact, typename KlSets<SPLIT>::type& PB) {
+  if constexpr (SPLIT) {
+    const SplitBView bv = split_bview(wf, wplane, U, w, lane);
+    switch (nact) {
+      case 4: fused_kloop_split<4>(acc, ap, bv, nu, PB); break;
+      case 3: fused_kloop_split<3>(acc, ap, bv, nu, PB); break;
+      case 2: fused_kloop_split<2>(acc, ap, bv, nu, PB); break;
+      case 1: fused_kloop_split<1>(acc, ap, bv, nu, PB); break;
+      default: break;
+    }
+  } else {
+    const FusedBView bv = fused_bview(wf, U, w, lane);
+    switch (nact) {
+      case 4: fused_kloop<4>(acc, ap, bv, nu, PB); break;
+      case 3: fused_kloop<3>(acc, ap, bv, nu, PB); break;
+      case 2: fused_kloop<2>(acc, ap, bv, nu, PB); break;
+      case 1: fused_kloop<1>(acc, ap, bv, nu, PB); break;
+      default: break;
+    }
   }
 }
 
@@ -400,6 +544,7 @@ __device__ __forceinline__ void fused_hoist_init(f32x16 (&acc)[2][4], const floa
 
 // S: the slab; xs: segment mode, xyz of the 64 points (zero padded); hu / hwx: segment mode, U_s of the hoisted layers and
 // their xyz weight columns.  On return in the training form (no y_out / u_out) the slab holds the last hidden activation.
+template <bool SPLIT = false>
 __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float* S, float4* xs, float (*hu)[FMAXW],
                                                    float4 (*hwx)[FMAXW], int warm_bytes) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -409,9 +554,9 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
   const uint32_t warm = warm_own_code(warm_bytes);
   if (warm == 0x9E3779B1u && p.N < 0) S[0] = 1.f;   // never true: keeps the loads
 
-  FusedBSets PB;
+  typename KlSets<SPLIT>::type PB;
   const int lfirst = (segm && p.n_hidden > 1) ? 1 : 0;   // first layer with an MFMA pass (segment mode: layer 0 has none)
-  fused_prefetch_b(PB, p.ly[lfirst].wf, p.ly[lfirst].U, w, lane, fused_nact(p.ly[lfirst].out_dim, w), (p.ly[lfirst].in + 15) >> 4);
+  kl_prefetch<SPLIT>(PB, p.ly[lfirst].wf, p.ly[lfirst].wplane, p.ly[lfirst].U, w, lane, fused_nact(p.ly[lfirst].out_dim, w), (p.ly[lfirst].in + 15) >> 4);
   if (segm) {
     if (tid < FROWS) {
       float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -473,13 +618,12 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[m][ni][r] = 0.f;
     }
-    const FusedBView bv = fused_bview(L.wf, L.U, w, lane);
     const float* ap = S + fr * FLD + 8 * fh;
     if (nu > 0) {
-      fused_kloop_dispatch(acc, ap, bv, nu, fused_nact(L.out_dim, w), PB);
+      fused_kloop_dispatch<SPLIT>(acc, ap, L.wf, L.wplane, L.U, w, lane, nu, fused_nact(L.out_dim, w), PB);
       if (l + 1 < p.n_hidden) {   // next layer's first weights travel while this layer's epilogue runs
         const FusedLayer& Ln = p.ly[l + 1];
-        fused_prefetch_b(PB, Ln.wf, Ln.U, w, lane, fused_nact(Ln.out_dim, w), (Ln.in + 15) >> 4);
+        kl_prefetch<SPLIT>(PB, Ln.wf, Ln.wplane, Ln.U, w, lane, fused_nact(Ln.out_dim, w), (Ln.in + 15) >> 4);
       }
     }
 #ifdef DSDF_LAB
@@ -540,10 +684,17 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(const FusedFwdArg
   __shared__ float4 hwx[FHOIST][FMAXW];
   fused_forward_body(p, S, xs, hu, hwx, 80 * 1024);
 }
+// the same with the hidden GEMMs in split mode (fused_kloop_split); a kernel of its own so that the fp32 kernel keeps its registers
+__global__ __launch_bounds__(256, 1) void fused_forward_split_kernel(const FusedFwdArgs p) {
+  __shared__ __attribute__((aligned(16))) float S[FROWS * FLD];
+  __shared__ float4 xs[FROWS];
+  __shared__ float hu[FHOIST][FMAXW];
+  __shared__ float4 hwx[FHOIST][FMAXW];
+  fused_forward_body<true>(p, S, xs, hu, hwx, 80 * 1024);
+}
 
 // ===================================================================================================================
 // BASELINE config 5 (bf16 forward GEMMs, fp32 accumulate): fused_bf16x8.hpp.  Shared pieces:
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ float bf16_round(float x) { return (float)(__bf16)x; }
 
 // BASELINE config 5: the same forward with bf16 GEMM inputs and fp32 accumulation on v_mfma_f32_32x32x16_bf16.
@@ -883,7 +1034,8 @@ __global__ __launch_bounds__(256, 1) void fused_forward_bf16_kernel(const FusedF
 // and for l = 0 only the latent columns of d/dx0 (no mask).  The ReLU/dropout mask comes from the forward's mask bits
 // (same lane <-> element mapping), so no activation is re-read here.
 struct FusedBwdLayer {
-  const float* wtf; int U;         // fragment-ordered W^T (n = in index, k = out index)
+  const float* wtf; int U;         // fragment-ordered W^T (n = in index, k = out index); split mode: three bf16 planes
+  int wplane;                      //   bytes per plane
   int K;                           // out_l
   int ncols;                       // output columns to compute (mask_cols + dz_cols)
   int mask_cols; float mask_scale; const uint32_t* maskbits;
@@ -977,6 +1129,7 @@ __device__ __forceinline__ void fused_bwd_epilogue(const f32x16 (&acc)[2][4], fl
 
 // slab_ready: the slab already holds the last hidden activation (the merged forward+backward kernel) -- no reload, no code
 // warm-up; hred / hsc: scratch of the head's cross-wave reductions.
+template <bool SPLIT = false>
 __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float* S, float4* xs, float (*hred)[2 * FMAXW],
                                                     float (*hsc)[2], bool slab_ready) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1081,8 +1234,8 @@ __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float
     }
     fused_zero_pad(S, H.in_last);
   }
-  FusedBSets PB;
-  if (p.n_layers > 0) fused_prefetch_b(PB, p.ly[0].wtf, p.ly[0].U, w, lane, fused_nact(p.ly[0].ncols, w), (p.ly[0].K + 15) >> 4);
+  typename KlSets<SPLIT>::type PB;
+  if (p.n_layers > 0) kl_prefetch<SPLIT>(PB, p.ly[0].wtf, p.ly[0].wplane, p.ly[0].U, w, lane, fused_nact(p.ly[0].ncols, w), (p.ly[0].K + 15) >> 4);
   __syncthreads();
 
   for (int i = 0; i < p.n_layers; ++i) {
@@ -1095,14 +1248,13 @@ __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float
       for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][ni][r] = 0.f;
-    const FusedBView bv = fused_bview(L.wtf, L.U, w, lane);
     const float* ap = S + fr * FLD + 8 * fh;
     uint4 mq = make_uint4(0u, 0u, 0u, 0u);
     if (L.maskbits != nullptr) mq = *reinterpret_cast<const uint4*>(L.maskbits + ((size_t)blockIdx.x * 256 + tid) * 4);
-    fused_kloop_dispatch(acc, ap, bv, nu, fused_nact(L.ncols, w), PB);
+    fused_kloop_dispatch<SPLIT>(acc, ap, L.wtf, L.wplane, L.U, w, lane, nu, fused_nact(L.ncols, w), PB);
     if (i + 1 < p.n_layers) {
       const FusedBwdLayer& Ln = p.ly[i + 1];
-      fused_prefetch_b(PB, Ln.wtf, Ln.U, w, lane, fused_nact(Ln.ncols, w), (Ln.K + 15) >> 4);
+      kl_prefetch<SPLIT>(PB, Ln.wtf, Ln.wplane, Ln.U, w, lane, fused_nact(Ln.ncols, w), (Ln.K + 15) >> 4);
     }
     __syncthreads();
     if (L.xsum != nullptr) fused_bwd_epilogue<true>(acc, S, L, w, fr, fh, row0, p.N, mq, xs);
@@ -1119,6 +1271,13 @@ __global__ __launch_bounds__(256, 2) void fused_backward_kernel(const FusedBwdAr
   __shared__ float hsc[4][2];
   fused_backward_body(p, S, xs, hred, hsc, false);
 }
+__global__ __launch_bounds__(256, 1) void fused_backward_split_kernel(const FusedBwdArgs p) {
+  __shared__ __attribute__((aligned(16))) float S[FROWS * FLD];
+  __shared__ float4 xs[FROWS];
+  __shared__ float hred[4][2 * FMAXW];
+  __shared__ float hsc[4][2];
+  fused_backward_body<true>(p, S, xs, hred, hsc, false);
+}
 
 // Training step, segment or general mode: forward and backward of the SAME 64 points by the same workgroup in one launch.
 // The last hidden activation stays in the slab for the head (no 33 MB re-read), one launch / prologue / instruction
@@ -1134,6 +1293,18 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_bwd_kernel(const FusedFwdArg
   fused_forward_body(f, S, xs, hu, hwx, 150 * 1024);
   __syncthreads();
   fused_backward_body(b, S, xs, hred, hsc, true);
+}
+__global__ __launch_bounds__(256, 1) void fused_fwd_bwd_split_kernel(const FusedFwdArgs f, const FusedBwdArgs b) {
+  __shared__ __attribute__((aligned(16))) float S[FROWS * FLD];
+  __shared__ float4 xs[FROWS];
+  __shared__ float4 scratch[FHOIST * FMAXW + FHOIST * FMAXW / 4];   // 20 KB: hu [2][512] floats + hwx [2][512] float4
+  float (*hu)[FMAXW] = reinterpret_cast<float (*)[FMAXW]>(scratch);
+  float4 (*hwx)[FMAXW] = reinterpret_cast<float4 (*)[FMAXW]>(scratch + FHOIST * FMAXW / 4);
+  float (*hred)[2 * FMAXW] = reinterpret_cast<float (*)[2 * FMAXW]>(scratch);            // 16 KB
+  float (*hsc)[2] = reinterpret_cast<float (*)[2]>(scratch + 4 * 2 * FMAXW / 4);
+  fused_forward_body<true>(f, S, xs, hu, hwx, 150 * 1024);
+  __syncthreads();
+  fused_backward_body<true>(b, S, xs, hred, hsc, true);
 }
 
 // Config 5 training step: bf16 forward and fp32 backward of the same 64 points in one launch (same LDS plan as above).

@@ -290,6 +290,8 @@ struct WnLayer {
   float* Wf; float* WTf;   // fragment-ordered copies for the fused kernels (see fused.hpp), or nullptr
   __bf16* Wfb;             // bf16 fragment-ordered copy for the bf16 forward (fused_forward_bf16_kernel), or nullptr
   int Uf, UTf;             // k-units (of 16) allocated per n-tile in Wf / WTf
+  __bf16* Ws; __bf16* WTs; // DsdfNet.gemm_split: W and W^T cut into three bf16 planes (h, m, l: fused.hpp fused_kloop_split) in the
+  long long ws_plane, wts_plane;   // fragment order of Wfb with NATURAL k-unit order; elements per plane.  Or nullptr.
 };
 // (an optional dense Adam update -- the latent table -- rides on the same launch: blocks >= total_tiles, kernels.hpp adam_kernel math)
 struct AdamRide {
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(256) void wn_tiles_kernel(const WnAll p) {
     }
     tile[rr][tx] = w;
   }
-  if (L.WT == nullptr && L.Wf == nullptr && L.Wfb == nullptr) return;
+  if (L.WT == nullptr && L.Wf == nullptr && L.Wfb == nullptr && L.Ws == nullptr) return;
   __syncthreads();
   if (L.WT != nullptr) {
 #pragma unroll
@@ -376,6 +378,30 @@ __global__ __launch_bounds__(256) void wn_tiles_kernel(const WnAll p) {
   if (L.WTf != nullptr) {  // B = W^T: n = in index (tile cols), k = out index (tile rows)
     float4 v4 = make_float4(tile[kk][fr], tile[kk + 1][fr], tile[kk + 2][fr], tile[kk + 3][fr]);
     *reinterpret_cast<float4*>(L.WTf + ((size_t)(cb * L.UTf + 2 * rb + uu) * 2 + i) * 256 + lane * 4) = v4;
+  }
+  if (L.Ws != nullptr) {   // x = h + m + l, every term the top 16 bits of what is left (exact: see fused_kloop_split)
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    auto cut = [](const float (&x)[4], bf16x4& h, bf16x4& m, bf16x4& l) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float hf = __uint_as_float(__float_as_uint(x[e]) & 0xFFFF0000u), r = x[e] - hf;
+        const float mf = __uint_as_float(__float_as_uint(r) & 0xFFFF0000u), t = r - mf;
+        h[e] = (__bf16)hf; m[e] = (__bf16)mf; l[e] = (__bf16)__uint_as_float(__float_as_uint(t) & 0xFFFF0000u);
+      }
+    };
+    bf16x4 h, m, l;
+    const float xw[4] = {tile[fr][kk], tile[fr][kk + 1], tile[fr][kk + 2], tile[fr][kk + 3]};
+    cut(xw, h, m, l);
+    __bf16* q = L.Ws + ((size_t)(rb * L.Uf + 2 * cb + uu) * 64 + lane) * 8 + 4 * i;
+    *reinterpret_cast<bf16x4*>(q) = h;
+    *reinterpret_cast<bf16x4*>(q + L.ws_plane) = m;
+    *reinterpret_cast<bf16x4*>(q + 2 * L.ws_plane) = l;
+    const float xt[4] = {tile[kk][fr], tile[kk + 1][fr], tile[kk + 2][fr], tile[kk + 3][fr]};
+    cut(xt, h, m, l);
+    q = L.WTs + ((size_t)(cb * L.UTf + 2 * rb + uu) * 64 + lane) * 8 + 4 * i;
+    *reinterpret_cast<bf16x4*>(q) = h;
+    *reinterpret_cast<bf16x4*>(q + L.wts_plane) = m;
+    *reinterpret_cast<bf16x4*>(q + 2 * L.wts_plane) = l;
   }
 }
 

@@ -116,11 +116,12 @@ class _DecoderFn(torch.autograd.Function):
 
 class Decoder(nn.Module):
     def __init__(self, latent_size, dims, geom_dimension, dropout=None, dropout_prob=0.0, norm_layers=(), latent_in=(),
-                 weight_norm=False, xyz_in_all=None, use_tanh=False, latent_dropout=False, forward_bf16=False):
+                 weight_norm=False, xyz_in_all=None, use_tanh=False, latent_dropout=False, forward_bf16=False, gemm_split=None):
         super().__init__()
         self.spec = NetSpec(latent_size, dims, geom_dimension, dropout=dropout, dropout_prob=dropout_prob,
                             norm_layers=norm_layers, latent_in=latent_in, weight_norm=weight_norm,
-                            xyz_in_all=xyz_in_all, use_tanh=use_tanh, latent_dropout=latent_dropout, forward_bf16=forward_bf16)
+                            xyz_in_all=xyz_in_all, use_tanh=use_tanh, latent_dropout=latent_dropout, forward_bf16=forward_bf16,
+                            gemm_split=gemm_split)
         s = self.spec
         self.num_layers = s.n_layers + 1
         self.geom_dimension = s.geom_dimension

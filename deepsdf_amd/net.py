@@ -5,6 +5,7 @@ does its layer-size arithmetic (:29-48) and produces (a) the ``DsdfNet`` POD of 
 flat parameter-arena layout in the reference module's ``named_parameters()`` order, with the reference's
 state-dict key names (``lin{i}.bias``, ``lin{i}.parametrizations.weight.original0/1``, ``lin{i}.weight``).
 """
+import os
 from dataclasses import dataclass
 from typing import List, Tuple
 
@@ -32,9 +33,13 @@ class NetSpec:
     LayerNorm (norm_layers without weight_norm) -- used by no shipped spec -- run on the layer-by-layer kernels."""
 
     def __init__(self, latent_size, dims, geom_dimension, dropout=None, dropout_prob=0.0, norm_layers=(),
-                 latent_in=(), weight_norm=False, xyz_in_all=None, use_tanh=False, latent_dropout=False, forward_bf16=False):
+                 latent_in=(), weight_norm=False, xyz_in_all=None, use_tanh=False, latent_dropout=False, forward_bf16=False,
+                 gemm_split=None):
         """forward_bf16 (not a reference key; BASELINE config 5): hidden-layer forward GEMMs on bf16 MFMA with fp32
-        accumulation; backward, master weights and Adam stay fp32."""
+        accumulation; backward, master weights and Adam stay fp32.
+        gemm_split (not a reference key; opt-in, default from the environment variable DSDF_GEMM_SPLIT=1): the fused kernels'
+        hidden-layer GEMMs on the bf16 matrix pipe with every fp32 operand cut into three bf16 terms -- fp32 accuracy (the
+        same parity tolerances), 2.7 x the MFMA rate (include/dsdf.h DsdfNet.gemm_split)."""
         norm_layers = tuple(norm_layers or ())
         latent_in = tuple(latent_in or ())
         self.latent_size = int(latent_size)
@@ -47,12 +52,18 @@ class NetSpec:
         self.weight_norm = bool(weight_norm)
         self.use_tanh = bool(use_tanh)
         self.forward_bf16 = bool(forward_bf16)
+        self.gemm_split = (os.environ.get("DSDF_GEMM_SPLIT") == "1") if gemm_split is None else bool(gemm_split)
         # variants no shipped spec uses; they run on the layer-by-layer kernels (general mode), never with forward_bf16
         self.xyz_in_all = bool(xyz_in_all)
         self.latent_dropout = bool(latent_dropout)
         layer_norm = (not self.weight_norm) and len(norm_layers) > 0        # deep_sdf_decoder.py:60-65
         if (self.xyz_in_all or self.latent_dropout or layer_norm) and self.forward_bf16:
             raise NotImplementedError("forward_bf16 is not available with xyz_in_all / latent_dropout / LayerNorm")
+        if self.gemm_split and (self.xyz_in_all or self.latent_dropout or layer_norm or self.forward_bf16 or max(self.dims) > 512
+                                or self.latent_size + self.geom_dimension > 512):
+            if gemm_split:      # asked for explicitly
+                raise NotImplementedError("gemm_split needs widths <= 512 and none of forward_bf16 / xyz_in_all / latent_dropout / LayerNorm")
+            self.gemm_split = False   # the environment default does not apply to nets the split kernels do not cover
         d = [self.latent_size + self.geom_dimension] + self.dims + [1]
         self.n_layers = len(d) - 1
         if self.n_layers > _lib.MAX_LAYERS:
@@ -96,7 +107,7 @@ class NetSpec:
         return dict(dims=self.dims, geom_dimension=self.geom_dimension, dropout=self.dropout,
                     dropout_prob=self.dropout_prob, norm_layers=self.norm_layers, latent_in=self.latent_in,
                     weight_norm=self.weight_norm, use_tanh=self.use_tanh, forward_bf16=self.forward_bf16,
-                    xyz_in_all=self.xyz_in_all, latent_dropout=self.latent_dropout)
+                    xyz_in_all=self.xyz_in_all, latent_dropout=self.latent_dropout, gemm_split=self.gemm_split)
 
     def c_struct(self) -> "_lib.DsdfNet":
         n = _lib.DsdfNet()
@@ -117,6 +128,7 @@ class NetSpec:
         n.use_tanh = int(self.use_tanh)
         n.latent_dropout = int(self.latent_dropout)
         n.xyz_in_all = int(self.xyz_in_all)
+        n.gemm_split = int(self.gemm_split)
         return n
 
     @property

@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define DSDF_MAX_LAYERS 16
-#define DSDF_ABI_VERSION 10
+#define DSDF_ABI_VERSION 11
 
 enum {
   DSDF_OK = 0,
@@ -61,6 +61,10 @@ typedef struct DsdfNet {
   uint32_t ln_param_mask;           /* :60-65 (norm_layers WITHOUT weight_norm): bit l: a bn{l} = nn.LayerNorm(out_dim[l]) module exists
                                        (parameters bn{l}.weight, bn{l}.bias right after lin{l}.weight, lin{l}.bias); forward applies it
                                        between the Linear and the ReLU of every HIDDEN layer that has one (:97-103) */
+  int32_t gemm_split;               /* opt-in: the fused kernels' hidden-layer GEMMs (forward and backward dX chain) run on the bf16 matrix
+                                       pipe with every fp32 operand cut into three bf16 terms (6 of the 9 cross products, fp32 accumulate):
+                                       fp32 accuracy (same parity tolerances), 2.7 x the MFMA rate.  Needs every width <= 512; not with
+                                       fwd_bf16 or the variants above.  dW and everything else are unchanged. */
 } DsdfNet;
 
 /* Offsets (in floats) of every parameter tensor inside the decoder arena, named_parameters() order:
