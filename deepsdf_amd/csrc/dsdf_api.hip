@@ -160,6 +160,9 @@ Packed packed_layout(const DsdfNet* n) {
     p.wtf_off[l] = o; o += ntt * p.utf[l] * 512;
     p.wfb_off[l] = o; o += n->fwd_bf16 ? ntw * 32 * 256 : 0;   // 32 phase-major k-unit slots of 1 KiB per n-tile
     p.ws_plane[l] = ntw * p.uf[l] * 512; p.wts_plane[l] = ntt * p.utf[l] * 512;     // (1 KiB = 512 bf16 per tile and k-unit)
+  }
+  o = rup(o, 64);
+  for (int l = 0; l < n->n_layers; ++l) {   // gemm_split: the bf16 planes come LAST, so everything in front keeps its place
     p.ws_off[l] = o;  o += n->gemm_split ? 3 * p.ws_plane[l] / 2 : 0;
     p.wts_off[l] = o; o += n->gemm_split ? 3 * p.wts_plane[l] / 2 : 0;
   }

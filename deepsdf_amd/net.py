@@ -52,7 +52,8 @@ class NetSpec:
         self.weight_norm = bool(weight_norm)
         self.use_tanh = bool(use_tanh)
         self.forward_bf16 = bool(forward_bf16)
-        self.gemm_split = (os.environ.get("DSDF_GEMM_SPLIT") == "1") if gemm_split is None else bool(gemm_split)
+        self.gemm_split = ((os.environ.get("DSDF_GEMM_SPLIT") == "1" and os.environ.get("DSDF_NO_FUSED") != "1")
+                           if gemm_split is None else bool(gemm_split))
         # variants no shipped spec uses; they run on the layer-by-layer kernels (general mode), never with forward_bf16
         self.xyz_in_all = bool(xyz_in_all)
         self.latent_dropout = bool(latent_dropout)
