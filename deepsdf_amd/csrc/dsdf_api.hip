@@ -560,6 +560,7 @@ int run_fused_forward(const DsdfNet* net, const Plan& P, void* ws, const float* 
     FusedLayer& y = a.ly[l];
     y.wf = net->fwd_bf16 ? packed + pk.wfb_off[l] : (net->gemm_split ? packed + pk.ws_off[l] : packed + pk.wf_off[l]);   // (bf16 copy / split planes)
     y.wplane = (int)(pk.ws_plane[l] * 2);   // bytes per plane (gemm_split)
+    y.wf32 = packed + pk.wf_off[l];
     y.bias = params + L.bias_off[l];
     y.out = store_act ? at<float>(ws, P.in_off[l + 1]) : nullptr;
     y.ld_out = P.ld_in[l + 1];
@@ -826,6 +827,7 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     FusedBwdLayer& y = a.ly[cnt++];
     y.wtf = net->gemm_split ? packed + pk.wts_off[l] : packed + pk.wtf_off[l]; y.U = pk.utf[l]; y.K = net->out_dim[l];
     y.wplane = (int)(pk.wts_plane[l] * 2);
+    y.wtf32 = packed + pk.wtf_off[l];
     if (l > 0) {
       const bool skip = (net->skip_mask >> l) & 1;
       y.mask_cols = net->out_dim[l - 1];

@@ -43,6 +43,7 @@ constexpr int FMAXW = 512;       // widest layer the fused kernels handle
 struct FusedLayer {
   const float* wf;       // fragment-ordered B operand (split mode: the three bf16 planes, `wplane` bytes apart)
   int wplane;
+  const float* wf32;     // split mode: the fp32 fragment copy as well (the k-loop takes some n-tiles from it, see fused_kloop_split)
   const float* bias;     // forward only
   float* out; int ld_out;          // global copy of this layer's output (activation for backward / dP for the dW GEMMs)
   int in, out_dim, U;              // K, N, k-units allocated per n-tile in wf
@@ -398,11 +399,21 @@ __device__ __forceinline__ Split3 split8(const float4& q0, const float4& q1) {
   return s;
 }
 
-struct SplitBSet { bf16x8 b[4][3]; };   // weights of k-unit 0 of the NEXT layer (4 n-tiles x 3 planes), requested before the epilogue
-struct SplitBView { __amdgpu_buffer_rsrc_t rsrc; int tbase[4]; int plane; int voff; };   // tbase[ni] = (w + 4 ni) * U; plane: bytes
-__device__ __forceinline__ SplitBView split_bview(const float* ws, int plane, int U, int w, int lane) {
+// Where a wave's n-tiles get their weight terms from: the first SPLIT_NPL(NACT) tiles from the pre-cut planes (6 bytes per value from L2,
+// nothing to compute), the others from the fp32 fragment copy (4 bytes per value, cut in registers like the activations).  All tiles
+// from the planes: 1.5 MB of weights per layer and CU = 31 B/cycle at the MFMA rate -- more than the L2s deliver, 553 us;
+// all tiles cut in registers: 264 VALU instructions per k-unit against 48 MFMAs, the VALU port exactly full, 553 us as well.  Half and
+// half keeps both under their limits.
+#ifndef SPLIT_PLANE_TILES
+#define SPLIT_PLANE_TILES 2
+#endif
+__host__ __device__ constexpr int split_npl(int nact) { return nact < SPLIT_PLANE_TILES ? nact : SPLIT_PLANE_TILES; }
+struct SplitBSet { bf16x8 b[4][3]; float4 f[4][2]; };   // weights of k-unit 0 of the NEXT layer, requested before the epilogue
+struct SplitBView { __amdgpu_buffer_rsrc_t rsrc, rsrc32; int tbase[4]; int plane; int voff; };   // tbase[ni] = (w + 4 ni) * U; plane: bytes
+__device__ __forceinline__ SplitBView split_bview(const float* ws, int plane, const float* wf32, int U, int w, int lane) {
   SplitBView v;
   v.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ws, 0, 0x7FFFFFFF, 0x00020000);
+  v.rsrc32 = __builtin_amdgcn_make_buffer_rsrc((void*)wf32, 0, 0x7FFFFFFF, 0x00020000);
   const int wsc = __builtin_amdgcn_readfirstlane(w);
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) v.tbase[ni] = (wsc + 4 * ni) * U;
@@ -415,85 +426,129 @@ __device__ __forceinline__ bf16x8 split_bload(const SplitBView& B, int ni, int u
   const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(B.rsrc, B.voff, pl * B.plane + ((B.tbase[ni] + u) << 10), 0);
   return __builtin_bit_cast(bf16x8, r);
 }
-__device__ __forceinline__ void split_prefetch_b(SplitBSet& P, const float* ws, int plane, int U, int w, int lane, int nact, int nu) {
-  if (nu <= 0) return;
-  const SplitBView B = split_bview(ws, plane, U, w, lane);
+__device__ __forceinline__ float4 split_bload32(const SplitBView& B, int ni, int u, int half) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(B.rsrc32, B.voff + 1024 * half, (B.tbase[ni] + u) * 2048, 0);
+  return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+}
+template <int NACT>
+__device__ __forceinline__ void split_load_unit(bf16x8 (&b)[4][3], float4 (&f)[4][2], const SplitBView& B, int u) {
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni)
-    if (ni < nact) {
+  for (int ni = 0; ni < NACT; ++ni) {
+    if (ni < split_npl(NACT)) {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) P.b[ni][pl] = split_bload(B, ni, 0, pl);
+      for (int pl = 0; pl < 3; ++pl) b[ni][pl] = split_bload(B, ni, u, pl);
+    } else {
+      f[ni][0] = split_bload32(B, ni, u, 0);
+      f[ni][1] = split_bload32(B, ni, u, 1);
     }
+  }
+}
+__device__ __forceinline__ void split_prefetch_b(SplitBSet& P, const float* ws, int plane, const float* wf32, int U, int w, int lane, int nact,
+                                                 int nu) {
+  if (nu <= 0) return;
+  const SplitBView B = split_bview(ws, plane, wf32, U, w, lane);
+  switch (nact) {
+    case 4: split_load_unit<4>(P.b, P.f, B, 0); break;
+    case 3: split_load_unit<3>(P.b, P.f, B, 0); break;
+    case 2: split_load_unit<2>(P.b, P.f, B, 0); break;
+    case 1: split_load_unit<1>(P.b, P.f, B, 0); break;
+    default: break;
+  }
 }
 
+// Software pipeline: while the 12 NACT MFMAs of k-unit u run, the operands of unit u+1 (loaded one step earlier) are cut into their bf16
+// terms and the loads of unit u+2 go out; sched_group_barrier pins the interleave (a lone in-order wave that does its ~180 VALU
+// instructions in one block lets the MFMA pipe run dry meanwhile: 49 % MFMA-busy before).
+#ifndef SPLIT_SCHED
+#define SPLIT_SCHED 0      // lab: 1 = pin the MFMA / VALU / load interleave with sched_group_barrier (measured slower: 544 against 504 us)
+#endif
 template <int NACT>
 __device__ __forceinline__ void fused_kloop_split(f32x16 (&acc)[2][4], const float* ap, const SplitBView& bv, int nu, SplitBSet& PB) {
-  bf16x8 b0[NACT][3], b1[NACT][3], b2[NACT][3];
-  float4 a0[4], a1[4], a2[4];   // [m-tile + 2 * half]: 4 consecutive k of rows fr and 32 + fr
+  struct Raw { float4 a[4]; bf16x8 b[4][3]; float4 f[4][2]; };       // one k-unit as it comes from LDS / L2
+  struct Cut { Split3 sa[2]; Split3 sb[NACT]; };                     // ... and as the MFMAs take it
+  constexpr int NPL = split_npl(NACT);
+  Raw r0, r1;
+  Cut c0, c1;
   const int ulast = nu - 1;
-  auto loadB = [&](bf16x8 (&b)[NACT][3], int u) __attribute__((always_inline)) {
-#pragma unroll
-    for (int ni = 0; ni < NACT; ++ni)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) b[ni][pl] = split_bload(bv, ni, u, pl);
+  auto load = [&](Raw& r, int u) __attribute__((always_inline)) {
+    split_load_unit<NACT>(r.b, r.f, bv, u);
+    r.a[0] = *reinterpret_cast<const float4*>(ap + 16 * u);
+    r.a[1] = *reinterpret_cast<const float4*>(ap + 32 * FLD + 16 * u);
+    r.a[2] = *reinterpret_cast<const float4*>(ap + 16 * u + 4);
+    r.a[3] = *reinterpret_cast<const float4*>(ap + 32 * FLD + 16 * u + 4);
   };
-  auto readA = [&](float4 (&a)[4], int u) __attribute__((always_inline)) {
-    a[0] = *reinterpret_cast<const float4*>(ap + 16 * u);
-    a[1] = *reinterpret_cast<const float4*>(ap + 32 * FLD + 16 * u);
-    a[2] = *reinterpret_cast<const float4*>(ap + 16 * u + 4);
-    a[3] = *reinterpret_cast<const float4*>(ap + 32 * FLD + 16 * u + 4);
+  auto cut = [&](Cut& c, const Raw& r) __attribute__((always_inline)) {
+    c.sa[0] = split8(r.a[0], r.a[2]);
+    c.sa[1] = split8(r.a[1], r.a[3]);
+#pragma unroll
+    for (int ni = 0; ni < NACT; ++ni) {
+      if (ni < NPL) { c.sb[ni].h = r.b[ni][0]; c.sb[ni].m = r.b[ni][1]; c.sb[ni].l = r.b[ni][2]; }
+      else c.sb[ni] = split8(r.f[ni][0], r.f[ni][1]);
+    }
   };
   // 6 passes over the 2 x NACT accumulators: consecutive MFMAs never touch the same accumulator; small terms first
-  auto mma = [&](const float4 (&a)[4], const bf16x8 (&b)[NACT][3]) __attribute__((always_inline)) {
-    Split3 sa[2];
-    sa[0] = split8(a[0], a[2]);
-    sa[1] = split8(a[1], a[3]);
-#define SPLIT_PASS(AX, PL)                                                                                     \
-    _Pragma("unroll") for (int ni = 0; ni < NACT; ++ni) {                                                      \
-      acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[0].AX, b[ni][PL], acc[0][ni], 0, 0, 0);          \
-      acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[1].AX, b[ni][PL], acc[1][ni], 0, 0, 0);          \
+  auto mma = [&](const Cut& c) __attribute__((always_inline)) {
+#define SPLIT_PASS(AX, BX)                                                                                       \
+    _Pragma("unroll") for (int ni = 0; ni < NACT; ++ni) {                                                        \
+      acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.sa[0].AX, c.sb[ni].BX, acc[0][ni], 0, 0, 0);        \
+      acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.sa[1].AX, c.sb[ni].BX, acc[1][ni], 0, 0, 0);        \
     }
-    SPLIT_PASS(l, 0) SPLIT_PASS(h, 2) SPLIT_PASS(m, 1) SPLIT_PASS(m, 0) SPLIT_PASS(h, 1) SPLIT_PASS(h, 0)
+    SPLIT_PASS(l, h) SPLIT_PASS(h, l) SPLIT_PASS(m, m) SPLIT_PASS(m, h) SPLIT_PASS(h, m) SPLIT_PASS(h, h)
 #undef SPLIT_PASS
   };
+  auto interleave = [&]() __attribute__((always_inline)) {
+#if SPLIT_SCHED
+    constexpr int NM = 12 * NACT, NVM = 3 * NPL + 2 * (NACT - NPL), NVAL = 44 * (2 + NACT - NPL);   // MFMAs, loads, cut instructions per step
+    constexpr int VPM = (NVAL + NM - 1) / NM;
 #pragma unroll
-  for (int ni = 0; ni < NACT; ++ni)
+    for (int q = 0; q < NM; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);     // VALU
+      if (q % 4 == 1 && q / 4 < NVM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // VMEM read
+      if (q % 4 == 3 && q / 4 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
+    }
+#endif
+  };
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) b0[ni][pl] = PB.b[ni][pl];     // unit 0 came with the cross-layer prefetch
-  loadB(b1, min(1, ulast));
-  readA(a0, 0);
-  int u = 0;
-  for (; u + 2 < nu; u += 3) {
-    loadB(b2, u + 2);
-    readA(a1, u + 1);
-    mma(a0, b0);
-    loadB(b0, min(u + 3, ulast));
-    readA(a2, u + 2);
-    mma(a1, b1);
-    loadB(b1, min(u + 4, ulast));
-    readA(a0, min(u + 3, ulast));
-    mma(a2, b2);
+  for (int ni = 0; ni < NACT; ++ni) {     // the weights of unit 0 came with the cross-layer prefetch
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) r0.b[ni][pl] = PB.b[ni][pl];
+    r0.f[ni][0] = PB.f[ni][0]; r0.f[ni][1] = PB.f[ni][1];
   }
-  if (u < nu) {
-    if (u + 1 < nu) readA(a1, u + 1);
-    mma(a0, b0);
+  r0.a[0] = *reinterpret_cast<const float4*>(ap);
+  r0.a[1] = *reinterpret_cast<const float4*>(ap + 32 * FLD);
+  r0.a[2] = *reinterpret_cast<const float4*>(ap + 4);
+  r0.a[3] = *reinterpret_cast<const float4*>(ap + 32 * FLD + 4);
+  load(r1, min(1, ulast));
+  cut(c0, r0);
+  for (int u = 0; u < nu; u += 2) {
+    load(r0, min(u + 2, ulast));     // unit u+2 -> the raw set unit u came from
+    cut(c1, r1);                     // unit u+1
+    mma(c0);                         // unit u
+    interleave();
+    if (u + 1 >= nu) break;
+    load(r1, min(u + 3, ulast));
+    cut(c0, r0);                     // unit u+2
+    mma(c1);                         // unit u+1
+    interleave();
   }
-  if (u + 1 < nu) mma(a1, b1);
 }
 
 // what a body needs from the k-loop, in either mode: the carried prefetch set, the prefetch, the loop
 template <bool SPLIT> struct KlSets { typedef FusedBSets type; };
 template <> struct KlSets<true> { typedef SplitBSet type; };
 template <bool SPLIT>
-__device__ __forceinline__ void kl_prefetch(typename KlSets<SPLIT>::type& PB, const float* wf, int wplane, int U, int w, int lane, int nact, int nu) {
-  if constexpr (SPLIT) split_prefetch_b(PB, wf, wplane, U, w, lane, nact, nu);
+__device__ __forceinline__ void kl_prefetch(typename KlSets<SPLIT>::type& PB, const float* wf, int wplane, const float* wf32, int U, int w, int lane,
+                                            int nact, int nu) {
+  if constexpr (SPLIT) split_prefetch_b(PB, wf, wplane, wf32, U, w, lane, nact, nu);
   else fused_prefetch_b(PB, wf, U, w, lane, nact, nu);
 }
 template <bool SPLIT>
-__device__ __forceinline__ void fused_kloop_dispatch(f32x16 (&acc)[2][4], const float* ap, const float* wf, int wplane, int U, int w, int lane,
-                                                     int nu, int nact, typename KlSets<SPLIT>::type& PB) {
+__device__ __forceinline__ void fused_kloop_dispatch(f32x16 (&acc)[2][4], const float* ap, const float* wf, int wplane, const float* wf32, int U,
+                                                     int w, int lane, int nu, int nact, typename KlSets<SPLIT>::type& PB) {
   if constexpr (SPLIT) {
-    const SplitBView bv = split_bview(wf, wplane, U, w, lane);
+    const SplitBView bv = split_bview(wf, wplane, wf32, U, w, lane);
     switch (nact) {
       case 4: fused_kloop_split<4>(acc, ap, bv, nu, PB); break;
       case 3: fused_kloop_split<3>(acc, ap, bv, nu, PB); break;
@@ -556,7 +611,7 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
 
   typename KlSets<SPLIT>::type PB;
   const int lfirst = (segm && p.n_hidden > 1) ? 1 : 0;   // first layer with an MFMA pass (segment mode: layer 0 has none)
-  kl_prefetch<SPLIT>(PB, p.ly[lfirst].wf, p.ly[lfirst].wplane, p.ly[lfirst].U, w, lane, fused_nact(p.ly[lfirst].out_dim, w), (p.ly[lfirst].in + 15) >> 4);
+  kl_prefetch<SPLIT>(PB, p.ly[lfirst].wf, p.ly[lfirst].wplane, p.ly[lfirst].wf32, p.ly[lfirst].U, w, lane, fused_nact(p.ly[lfirst].out_dim, w), (p.ly[lfirst].in + 15) >> 4);
   if (segm) {
     if (tid < FROWS) {
       float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -620,10 +675,10 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
     }
     const float* ap = S + fr * FLD + 8 * fh;
     if (nu > 0) {
-      fused_kloop_dispatch<SPLIT>(acc, ap, L.wf, L.wplane, L.U, w, lane, nu, fused_nact(L.out_dim, w), PB);
+      fused_kloop_dispatch<SPLIT>(acc, ap, L.wf, L.wplane, L.wf32, L.U, w, lane, nu, fused_nact(L.out_dim, w), PB);
       if (l + 1 < p.n_hidden) {   // next layer's first weights travel while this layer's epilogue runs
         const FusedLayer& Ln = p.ly[l + 1];
-        kl_prefetch<SPLIT>(PB, Ln.wf, Ln.wplane, Ln.U, w, lane, fused_nact(Ln.out_dim, w), (Ln.in + 15) >> 4);
+        kl_prefetch<SPLIT>(PB, Ln.wf, Ln.wplane, Ln.wf32, Ln.U, w, lane, fused_nact(Ln.out_dim, w), (Ln.in + 15) >> 4);
       }
     }
 #ifdef DSDF_LAB
@@ -1036,6 +1091,7 @@ __global__ __launch_bounds__(256, 1) void fused_forward_bf16_kernel(const FusedF
 struct FusedBwdLayer {
   const float* wtf; int U;         // fragment-ordered W^T (n = in index, k = out index); split mode: three bf16 planes
   int wplane;                      //   bytes per plane
+  const float* wtf32;              //   and the fp32 fragment copy
   int K;                           // out_l
   int ncols;                       // output columns to compute (mask_cols + dz_cols)
   int mask_cols; float mask_scale; const uint32_t* maskbits;
@@ -1235,7 +1291,7 @@ __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float
     fused_zero_pad(S, H.in_last);
   }
   typename KlSets<SPLIT>::type PB;
-  if (p.n_layers > 0) kl_prefetch<SPLIT>(PB, p.ly[0].wtf, p.ly[0].wplane, p.ly[0].U, w, lane, fused_nact(p.ly[0].ncols, w), (p.ly[0].K + 15) >> 4);
+  if (p.n_layers > 0) kl_prefetch<SPLIT>(PB, p.ly[0].wtf, p.ly[0].wplane, p.ly[0].wtf32, p.ly[0].U, w, lane, fused_nact(p.ly[0].ncols, w), (p.ly[0].K + 15) >> 4);
   __syncthreads();
 
   for (int i = 0; i < p.n_layers; ++i) {
@@ -1251,10 +1307,10 @@ __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float
     const float* ap = S + fr * FLD + 8 * fh;
     uint4 mq = make_uint4(0u, 0u, 0u, 0u);
     if (L.maskbits != nullptr) mq = *reinterpret_cast<const uint4*>(L.maskbits + ((size_t)blockIdx.x * 256 + tid) * 4);
-    fused_kloop_dispatch<SPLIT>(acc, ap, L.wtf, L.wplane, L.U, w, lane, nu, fused_nact(L.ncols, w), PB);
+    fused_kloop_dispatch<SPLIT>(acc, ap, L.wtf, L.wplane, L.wtf32, L.U, w, lane, nu, fused_nact(L.ncols, w), PB);
     if (i + 1 < p.n_layers) {
       const FusedBwdLayer& Ln = p.ly[i + 1];
-      kl_prefetch<SPLIT>(PB, Ln.wtf, Ln.wplane, Ln.U, w, lane, fused_nact(Ln.ncols, w), (Ln.K + 15) >> 4);
+      kl_prefetch<SPLIT>(PB, Ln.wtf, Ln.wplane, Ln.wtf32, Ln.U, w, lane, fused_nact(Ln.ncols, w), (Ln.K + 15) >> 4);
     }
     __syncthreads();
     if (L.xsum != nullptr) fused_bwd_epilogue<true>(acc, S, L, w, fr, fh, row0, p.N, mq, xs);
