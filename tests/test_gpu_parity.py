@@ -223,6 +223,52 @@ def test_full_size_step_vs_oracle():
         assert rel_err(tr.lat.cpu(), st64.latents) <= PARAM_TOL
 
 
+def test_gemm_split_full_size_step_and_decode_vs_oracle():
+    """NetworkSpecs gemm_split (opt-in): the fused kernels' hidden GEMMs as 6 bf16 MFMAs on 3-way split fp32 operands.  Claimed to
+    be fp32-accurate, so it gets the fp32 tests' tolerances against the float64 oracle: two optimiser steps of config 2 at full size
+    (loss 1e-5, gradients 1e-4, post-Adam state), the forward on 70001 points (1e-5, and no ROW further than 1e-5 of the range), and
+    bit-identical reruns."""
+    from deepsdf_amd.engine import Engine
+    L, B, S = 256, 64, 256
+    net = orc.make_net(L, **BIG)
+    spec = spec_from_meta(dict(L=L, net_specs=dict(BIG, gemm_split=True)))
+    assert spec.gemm_split and spec.c_struct().gemm_split == 1
+    params = orc.init_params(net, 5)
+    gen = torch.Generator().manual_seed(6)
+    lat0 = torch.randn(B, L, generator=gen) / math.sqrt(L)
+    lat0[3] *= 2.5 / lat0[3].norm()
+    st64 = orc.TrainState.create({k: v.double() for k, v in params.items()}, lat0.double())
+    tr = HipTrainer(spec, params, lat0)
+    for step in range(2):
+        idx, xyz, gt = _safe_batch(net, st64, B, S, 100 + step, 0.1, 1.0, 4242)
+        r64 = orc.train_step(net, st64, idx, xyz.double(), gt.double(), delta=0.1, code_bound=1.0, epoch=57, seed=4242)
+        rh = tr.step(idx, xyz, gt, delta=0.1, code_bound=1.0, code_reg=True, lam=1e-4, epoch=57, lr=(5e-4, 1e-3), seed=4242)
+        assert abs(rh["loss"] - r64["loss"]) <= 1e-5 * abs(r64["loss"])
+        worst = max(rel_err(rh["grads"][k], r64["grads"][k]) for k in r64["grads"])
+        print(f"gemm_split step {step}: max grad rel err vs fp64 truth {worst:.2e}")
+        for k in r64["grads"]:
+            assert rel_err(rh["grads"][k], r64["grads"][k]) <= GRAD_TOL, (step, k)
+        assert rel_err(rh["dlat"], r64["dlat"]) <= GRAD_TOL
+        P = tr.params()
+        for k in st64.params:
+            assert rel_err(P[k], st64.params[k]) <= PARAM_TOL, (step, k)
+        assert rel_err(tr.lat.cpu(), st64.latents) <= PARAM_TOL
+    # forward alone, ragged size, both entry points; run-to-run bits
+    eng = Engine(spec)
+    eng.load_params(params)
+    n = 70001
+    z = torch.randn(L, generator=gen) / math.sqrt(L)
+    xyz = torch.rand(n, 3, generator=gen) * 2 - 1
+    x = torch.cat([z.expand(n, -1), xyz], 1)
+    yo = orc.decoder_forward(net, {k: v.double() for k, v in params.items()}, x.double(), training=False)[0].reshape(-1)
+    for name, fn in (("decode_latent", lambda: eng.decode_latent(z.cuda(), xyz.cuda())), ("decode", lambda: eng.decode(x.cuda()))):
+        runs = [fn().cpu().reshape(-1).clone() for _ in range(3)]
+        assert torch.equal(runs[1], runs[0]) and torch.equal(runs[2], runs[0]), name
+        worst_row = float((runs[0].double() - yo).abs().max() / yo.abs().max())
+        print(f"gemm_split {name}: rel err {rel_err(runs[0], yo):.2e}, worst row {worst_row:.2e} of the range")
+        assert rel_err(runs[0], yo) <= FWD_TOL and worst_row <= 1e-5, name
+
+
 def test_full_size_properties():
     """Size-independent properties at 16384 pts: bit-exact determinism, and batch_split=4 == unsplit."""
     L, B, S = 256, 64, 256
