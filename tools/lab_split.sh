@@ -1,8 +1,8 @@
-# lab: the fused kernels in split mode (DSDF_GEMM_SPLIT=1) against the fp32-MFMA build, per library variant
+# lab: the step with NetworkSpecs gemm_split (bench.py --config f32split) against the fp32-MFMA build, per library variant
 R=$GRAFT_REPO_ROOT; cd $R
 for so in deepsdf_amd/libdsdf_hip.so $(ls tools/lab/variants/*.so 2>/dev/null); do
-  for sp in 0 1; do
-    DSDF_LIB_PATH=$R/$so DSDF_GEMM_SPLIT=$sp python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-pmc --no-extras 2>/dev/null | tail -n 1 | python3 -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('$so split=$sp:', round(d['ms_per_step'],4), {k: round(v['avg_us'],1) for k,v in d['roofline']['kernels'].items()})"
+  for cfg in fp32 f32split; do
+    DSDF_LIB_PATH=$R/$so python3 bench.py --config $cfg --steps 100 --warmup 10 --no-cpu-baseline --no-pmc --no-extras 2>/dev/null | tail -n 1 | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('$so $cfg:', round(d['ms_per_step'],4), {k: round(v['avg_us'],1) for k,v in d['roofline']['kernels'].items()})"
   done
 done
