@@ -17,6 +17,7 @@ Beside the contract's line (value / ms_per_step over the barrier-bracketed timed
   cpu_baseline    the step in stock torch ops (oracle/torch_native.py) on this host: all cores and one core
   config.one_scene_ms_per_step   the locality extreme B=1 x S=16384
   config.inference_forward       --config bf16 only: the bf16 forward alone (one code x the step's points)
+  config.gemm_split              headline config only: ms/step of the same workload with the opt-in gemm_split
 """
 import argparse
 import ctypes as C
@@ -303,6 +304,29 @@ def main():
         torch.cuda.synchronize()
         one_scene = 1e3 * (time.perf_counter() - t1) / 100
 
+    # ---- headline config only: the same step with NetworkSpecs gemm_split (opt-in), so that the record carries both ----
+    split_extra = None
+    if rank == 0 and world == 1 and headline and args.config == "fp32" and not args.no_extras:
+        seng = Engine(NetSpec(L, gemm_split=True, **NET), dev)
+        seng.init_like_reference(torch.Generator().manual_seed(0))
+        slat = lat.clone()
+        sfused = FusedTrainStep(seng, slat, clamp_dist=0.1, code_reg=True, code_reg_lambda=1e-4, code_bound=1.0, grad_clip=None, seed=3)
+        sstep = lambda i: sfused(batches[i % len(batches)]["scenes"], S, batches[i % len(batches)]["xyz"], batches[i % len(batches)]["gt"],  # noqa: E731
+                                 1, 5e-4, 1e-3, batch_split=1, n_norm=n_global)
+        for i in range(20):
+            sstep(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(100):
+            sstep(i)
+        torch.cuda.synchronize()
+        sms = 1e3 * (time.perf_counter() - t1) / 100
+        split_extra = dict(ms_per_step=sms, value=n_local / (sms * 1e-3),
+                           note="NOT the headline: the same workload with NetworkSpecs gemm_split = true (the fused kernels' hidden GEMMs as 6 "
+                                "bf16 MFMAs on 3-way split fp32 operands, fp32 accumulate; same parity tolerances) -- `bench.py --config f32split` "
+                                "is the full line")
+        del seng, sfused
+
     # ---- config 5 only: its INFERENCE forward alone (one code x the step's points: dsdf_decode_latent = hoist + the 8-wave kernel) ----
     bf16_fwd = None
     if rank == 0 and world == 1 and bf16 and not args.no_extras:
@@ -370,6 +394,8 @@ def main():
                "points_per_step_per_gpu": n_local, "headline_config": headline and args.config == "fp32", "parallelism": f"dp{world}", "final_loss": loss}
         if bf16_fwd is not None:
             cfg["inference_forward"] = bf16_fwd
+        if split_extra is not None:
+            cfg["gemm_split"] = split_extra
         if one_scene is not None:
             cfg["one_scene_ms_per_step"] = one_scene
             cfg["one_scene_value"] = 16384 / (one_scene * 1e-3)
