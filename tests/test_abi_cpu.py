@@ -110,6 +110,19 @@ def test_argument_errors_are_reported_before_any_launch(lib):
     assert lib.dsdf_packed_floats(C.byref(wide), C.byref(n)) == -1 and b"fwd_bf16" in lib.dsdf_last_error()
     net = NetSpec(8, [64, 64], 3).c_struct()
     assert lib.dsdf_decode_latent(C.byref(net), None, None, None, None, 10, None, None, 0, None) == -1
+    # gemm_split: widths <= 512, not together with the bf16 forward or the layer-by-layer variants; its planes enlarge `packed`
+    sp = NetSpec(8, [64, 64], 3, gemm_split=True).c_struct()
+    plain = NetSpec(8, [64, 64], 3, gemm_split=False).c_struct()
+    n2 = C.c_int64()
+    assert lib.dsdf_packed_floats(C.byref(sp), C.byref(n)) == 0 and lib.dsdf_packed_floats(C.byref(plain), C.byref(n2)) == 0
+    assert n.value > n2.value
+    sp.fwd_bf16 = 1
+    assert lib.dsdf_packed_floats(C.byref(sp), C.byref(n)) == -1 and b"gemm_split" in lib.dsdf_last_error()
+    import pytest
+    with pytest.raises(NotImplementedError):
+        NetSpec(8, [640, 640], 3, gemm_split=True)
+    with pytest.raises(NotImplementedError):
+        NetSpec(8, [64, 64], 3, gemm_split=True, forward_bf16=True)
 
 
 def test_warm_own_code_bound_is_inside_the_text_section(tmp_path):
