@@ -457,6 +457,7 @@ def test_fused_and_layered_paths_agree_on_ragged_batches(monkeypatch):
     outs = {}
     for mode in ("0", "1"):
         monkeypatch.setenv("DSDF_NO_FUSED", mode)
+        spec = spec_from_meta(dict(L=L, net_specs=BIG))   # (after the switch: the DSDF_GEMM_SPLIT default of a lab run does not apply to the layered path)
         tr = HipTrainer(spec, params, lat0)
         outs[mode] = tr.step(idx, xyz, gt, delta=0.1, code_bound=1.0, code_reg=True, lam=1e-4, epoch=300, lr=(5e-4, 1e-3),
                              batch_split=3, seed=77, want_y=True)
