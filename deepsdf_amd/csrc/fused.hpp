@@ -21,9 +21,11 @@
 // arrangement can hide the epilogues; they can only be short.  Per-load address arithmetic lives on the scalar unit
 // (FusedBView: buffer resource + SGPR tile/unit offsets; the epilogues' buffer stores with scalar row offsets).
 // Kernels: fused_forward_kernel (inference / module path), fused_backward_kernel (module path), fused_fwd_bwd_kernel
-// (training: both bodies in one launch, the last hidden activation stays in the slab), fused_forward_bf16_kernel and
-// fused_fwd_bf16_bwd_kernel (BASELINE config 5: bf16 forward body, fp32 backward body).  Segment mode (FusedSeg) hoists the
-// per-scene latent products out of the per-point work, in both precisions.
+// (training: both bodies in one launch, the last hidden activation stays in the slab); their *_split_kernel twins run the same
+// bodies with the k-loop of DsdfNet.gemm_split (fused_kloop_split: the fp32 products as 6 bf16 MFMAs on 3-way cut operands, fp32
+// accurate -- bf16 MFMAs do NOT block the VALU, so the cut runs in their shadow); fused_forward_bf16_kernel and
+// fused_fwd_bf16_bwd_kernel (BASELINE config 5, training form: bf16 forward body, fp32 backward body; the inference form is
+// fused_bf16x8.hpp).  Segment mode (FusedSeg) hoists the per-scene latent products out of the per-point work, in all of them.
 #pragma once
 #include <type_traits>
 #include <utility>
