@@ -160,12 +160,13 @@ def main():
     ap.add_argument("--scenes-per-batch", type=int, default=64,
                     help="NOT the headline config: scale the batch (x --samples) to see other batch shapes")
     ap.add_argument("--samples", type=int, default=256, help="samples per scene (headline: 256)")
-    ap.add_argument("--config", choices=["fp32", "bf16", "f32split"], default="fp32",
+    ap.add_argument("--config", choices=["fp32", "bf16", "f32split", "bf16split"], default="fp32",
                     help="fp32 = BASELINE configs[1] (the headline, v_mfma_f32_32x32x2_f32); bf16 = configs[4]: the same workload with the "
                          "hidden-layer forward GEMMs on bf16 inputs / fp32 accumulate (v_mfma_f32_32x32x16_bf16), backward, dW and Adam in "
                          "fp32; f32split = the headline workload with NetworkSpecs gemm_split: the fused kernels' hidden GEMMs on the bf16 "
                          "matrix pipe with every fp32 operand cut into three bf16 terms (6 MFMAs per product, fp32 accumulate: fp32 accuracy, "
-                         "the fp32 parity tolerances; dW, Adam and everything else unchanged) -- opt-in, NOT the headline")
+                         "the fp32 parity tolerances; dW, Adam and everything else unchanged) -- opt-in, NOT the headline; bf16split = configs[4] with "
+                         "gemm_split: the bf16 forward as it is, the backward dX chain in split mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event instrumented pass")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (HBM traffic, MFMA counters)")
@@ -194,8 +195,8 @@ def main():
     pmc_res, pmc_thread = {}, None
     want_pmc = rank == 0 and world == 1 and not args.no_pmc and "ROCPROFILER" not in " ".join(os.environ.keys()).upper()
 
-    bf16 = args.config == "bf16"
-    split = args.config == "f32split"
+    bf16 = args.config in ("bf16", "bf16split")
+    split = args.config in ("f32split", "bf16split")
     spec = NetSpec(L, forward_bf16=bf16, gemm_split=split, **NET)
     eng = Engine(spec, dev)
     eng.init_like_reference(torch.Generator().manual_seed(0))      # identical on every rank (replicated decoder)
@@ -403,7 +404,8 @@ def main():
             "metric": "SDF point-samples/sec per training step (8x512 decoder, 16384 pts)", "value": value,
             "unit": "point-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16-fwd/f32" if bf16 else ("f32 (hidden GEMMs of the fused kernels: 3 bf16 terms per operand, 6 bf16 MFMAs per product, "
+            "dtype": ("bf16-fwd/f32 (backward dX GEMMs: 3 bf16 terms per operand, 6 bf16 MFMAs per product, fp32 accumulate)" if bf16 and split
+                      else "bf16-fwd/f32") if bf16 else ("f32 (hidden GEMMs of the fused kernels: 3 bf16 terms per operand, 6 bf16 MFMAs per product, "
                                                    "fp32 accumulate)" if split else "f32"), "data": "synthetic", "config": cfg, "step_time_ms": step_stats,
             "roofline": roofline, "cpu_baseline": cpu}))
 

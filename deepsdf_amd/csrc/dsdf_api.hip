@@ -111,8 +111,8 @@ int validate(const DsdfNet* n) {
   if ((n->latent_dropout || n->xyz_in_all || n->ln_param_mask) && n->fwd_bf16)
     return fail(DSDF_E_INVALID, "fwd_bf16 is not available with latent_dropout / xyz_in_all / LayerNorm");
   if (n->gemm_split) {
-    if (n->fwd_bf16 || n->latent_dropout || n->xyz_in_all || n->ln_param_mask)
-      return fail(DSDF_E_INVALID, "gemm_split is not available with fwd_bf16 / latent_dropout / xyz_in_all / LayerNorm");
+    if (n->latent_dropout || n->xyz_in_all || n->ln_param_mask)
+      return fail(DSDF_E_INVALID, "gemm_split is not available with latent_dropout / xyz_in_all / LayerNorm");
     for (int l = 0; l < n->n_layers; ++l)
       if (n->in_dim[l] > 512 || (l < n->n_layers - 1 && n->out_dim[l] > 512))
         return fail(DSDF_E_INVALID, "gemm_split needs every layer width <= 512 (layer %d: %d -> %d)", l, n->in_dim[l], n->out_dim[l]);
@@ -854,7 +854,8 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     (void)wmac;
     if (fwd != nullptr) {
       ProfScope ps(DSDF_PROF_FUSED_FWD_BWD, 4.0 * (double)n * amac, st);   // forward + dX chain
-      if (net->fwd_bf16) hipLaunchKernelGGL(fused_fwd_bf16_bwd_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
+      if (net->fwd_bf16 && net->gemm_split) hipLaunchKernelGGL(fused_fwd_bf16_bwd_split_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
+      else if (net->fwd_bf16) hipLaunchKernelGGL(fused_fwd_bf16_bwd_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
       else if (net->gemm_split) hipLaunchKernelGGL(fused_fwd_bwd_split_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
       else hipLaunchKernelGGL(fused_fwd_bwd_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
       LAUNCH_OK("fused_fwd_bwd_kernel");

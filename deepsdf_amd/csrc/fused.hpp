@@ -1380,4 +1380,19 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_bf16_bwd_kernel(const FusedF
   fused_backward_body(b, S, xs, hred, hsc, true);
 }
 
+// ... and with the backward dX chain in split mode (config 5 + gemm_split): bf16 forward, fp32-accurate backward on the bf16 pipe (same LDS plan as above).
+__global__ __launch_bounds__(256, 1) void fused_fwd_bf16_bwd_split_kernel(const FusedFwdArgs f, const FusedBwdArgs b) {
+  __shared__ __attribute__((aligned(16))) float S[FROWS * FLD];
+  __shared__ float4 xs[FROWS];
+  __shared__ float4 scratch[FHOIST * FMAXW + FHOIST * FMAXW / 4];
+  float (*hu)[FMAXW] = reinterpret_cast<float (*)[FMAXW]>(scratch);
+  float4 (*hwx)[FMAXW] = reinterpret_cast<float4 (*)[FMAXW]>(scratch + FHOIST * FMAXW / 4);
+  float (*hred)[2 * FMAXW] = reinterpret_cast<float (*)[2 * FMAXW]>(scratch);
+  float (*hsc)[2] = reinterpret_cast<float (*)[2]>(scratch + 4 * 2 * FMAXW / 4);
+  fused_forward_bf16_body(f, S, xs, hu, hwx);
+  __syncthreads();
+  // (the backward body refills xs with the UNROUNDED xyz: the fp32 backward / dW use the fp32 layer inputs)
+  fused_backward_body<true>(b, S, xs, hred, hsc, true);
+}
+
 }  // namespace dsdf

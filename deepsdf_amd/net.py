@@ -60,10 +60,10 @@ class NetSpec:
         layer_norm = (not self.weight_norm) and len(norm_layers) > 0        # deep_sdf_decoder.py:60-65
         if (self.xyz_in_all or self.latent_dropout or layer_norm) and self.forward_bf16:
             raise NotImplementedError("forward_bf16 is not available with xyz_in_all / latent_dropout / LayerNorm")
-        if self.gemm_split and (self.xyz_in_all or self.latent_dropout or layer_norm or self.forward_bf16 or max(self.dims) > 512
+        if self.gemm_split and (self.xyz_in_all or self.latent_dropout or layer_norm or max(self.dims) > 512
                                 or self.latent_size + self.geom_dimension > 512):
             if gemm_split:      # asked for explicitly
-                raise NotImplementedError("gemm_split needs widths <= 512 and none of forward_bf16 / xyz_in_all / latent_dropout / LayerNorm")
+                raise NotImplementedError("gemm_split needs widths <= 512 and none of xyz_in_all / latent_dropout / LayerNorm")
             self.gemm_split = False   # the environment default does not apply to nets the split kernels do not cover
         d = [self.latent_size + self.geom_dimension] + self.dims + [1]
         self.n_layers = len(d) - 1

@@ -116,13 +116,15 @@ def test_argument_errors_are_reported_before_any_launch(lib):
     n2 = C.c_int64()
     assert lib.dsdf_packed_floats(C.byref(sp), C.byref(n)) == 0 and lib.dsdf_packed_floats(C.byref(plain), C.byref(n2)) == 0
     assert n.value > n2.value
-    sp.fwd_bf16 = 1
+    sp.fwd_bf16 = 1                      # together with the bf16 forward: allowed (the backward chain is the split one)
+    assert lib.dsdf_packed_floats(C.byref(sp), C.byref(n)) == 0
+    sp.fwd_bf16, sp.latent_dropout = 0, 1
     assert lib.dsdf_packed_floats(C.byref(sp), C.byref(n)) == -1 and b"gemm_split" in lib.dsdf_last_error()
     import pytest
     with pytest.raises(NotImplementedError):
         NetSpec(8, [640, 640], 3, gemm_split=True)
     with pytest.raises(NotImplementedError):
-        NetSpec(8, [64, 64], 3, gemm_split=True, forward_bf16=True)
+        NetSpec(8, [64, 64], 3, gemm_split=True, latent_dropout=True)
 
 
 def test_warm_own_code_bound_is_inside_the_text_section(tmp_path):

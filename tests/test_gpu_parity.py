@@ -399,7 +399,8 @@ def test_segment_mode_odd_shapes_vs_oracle(name):
             assert rel_err(tr.lat.cpu(), st64.latents) <= ptol, (step, kw)
 
 
-def test_config5_bf16_forward_vs_oracle_and_fp32():
+@pytest.mark.parametrize("split", [False, True], ids=["fp32_backward", "split_backward"])
+def test_config5_bf16_forward_vs_oracle_and_fp32(split):
     """BASELINE config 5: hidden-layer forward GEMMs with bf16 inputs / fp32 accumulate (v_mfma_f32_32x32x16_bf16), backward and
     Adam in fp32, on the 8x512 decoder at 16384 points.  Compared with (a) the oracle's bf16 emulation (same rounding
     points; what differs is the accumulation order and the ~1e-7 differences that decide a few bf16 roundings) and (b) the
@@ -408,7 +409,7 @@ def test_config5_bf16_forward_vs_oracle_and_fp32():
     L, B, S = 256, 64, 256
     kw = dict(BIG)
     net = orc.make_net(L, forward_bf16=True, **kw)
-    spec = spec_from_meta(dict(L=L, net_specs=dict(kw, forward_bf16=True)))
+    spec = spec_from_meta(dict(L=L, net_specs=dict(kw, forward_bf16=True, gemm_split=split)))   # split: the backward dX chain in split mode
     spec32 = spec_from_meta(dict(L=L, net_specs=kw))
     params = orc.init_params(net, 5)
     lat0 = torch.randn(B, L, generator=torch.Generator().manual_seed(6)) / math.sqrt(L)
