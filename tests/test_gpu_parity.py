@@ -21,9 +21,20 @@ TRAIN_CASES = ["g1a_tiny_full", "g1b_lastnorm_tanh", "g1c_plain_clip", "g2_8x512
 
 @pytest.mark.parametrize("name", TRAIN_CASES)
 def test_golden_train_cases(name):
+    _golden_train_case(name, gemm_split=False)
+
+
+@pytest.mark.parametrize("name", ["g1a_tiny_full", "g1b_lastnorm_tanh", "g2_8x512_slice", "g3b_dropout_8x512", "g4_batch_split2"])
+def test_golden_train_cases_gemm_split(name):
+    """The reference-generated goldens with NetworkSpecs gemm_split (the fused kernels' GEMMs as 6 bf16 MFMAs on 3-way cut fp32
+    operands): the same tolerances."""
+    _golden_train_case(name, gemm_split=True)
+
+
+def _golden_train_case(name, gemm_split):
     g = Golden(name)
     m = g.meta
-    spec = spec_from_meta(m)
+    spec = spec_from_meta(dict(m, net_specs=dict(m["net_specs"], gemm_split=gemm_split)))
     net = orc.make_net(m["L"], **m["net_specs"])
     params = g.group("params0") if m["store"] == "full" else orc.init_params(net, m["seed"])
     tr = HipTrainer(spec, params, g.get("lat0/w"))
