@@ -910,7 +910,9 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
   // workgroup per CU (measured: 16384 points, 1168 role blocks on 16 workgroups, dW time unchanged); larger batches put
   // the roles on the critical path (65536 points: -5 %), so they get their own (wide) launch there
   static const bool no_ride = [] { const char* e = getenv("DSDF_NO_RIDE"); return e && e[0] == '1'; }();   // A/B switch
-  const bool post_rides = segmode && want_dw && cus - dw_busy >= 8 && P.nwg <= cus && !no_ride;
+  // (gemm_split: the dW items finish in ~60 % of the time the riding roles need on the 16 spare workgroups -- they would be the
+  // launch's tail, 462 us against 227; there the roles go out as a launch of their own, 18 us)
+  const bool post_rides = segmode && want_dw && cus - dw_busy >= 8 && P.nwg <= cus && !no_ride && !net->gemm_split;
   if (segmode && !post_rides) {
     hipLaunchKernelGGL(post_bwd_kernel, dim3((unsigned)(q.rr_n + q.dw_n + lat_n)), dim3(256), 0, st, q);
     LAUNCH_OK("post_bwd_kernel");
@@ -934,7 +936,10 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     memset(&none, 0, sizeof(none));
     int grid = dw_busy < 1 ? 1 : dw_busy;
     ProfScope ps(DSDF_PROF_DW_STREAM, fl, st);
-    if (post_rides) hipLaunchKernelGGL(dw_stream_kernel, dim3(cus), dim3(256), 0, st, d, q, lat_n, dw_busy);
+    if (net->gemm_split) {
+      if (post_rides) hipLaunchKernelGGL(dw_stream_split_kernel, dim3(cus), dim3(256), 0, st, d, q, lat_n, dw_busy);
+      else hipLaunchKernelGGL(dw_stream_split_kernel, dim3(grid), dim3(256), 0, st, d, none, 0, grid);
+    } else if (post_rides) hipLaunchKernelGGL(dw_stream_kernel, dim3(cus), dim3(256), 0, st, d, q, lat_n, dw_busy);
     else hipLaunchKernelGGL(dw_stream_kernel, dim3(grid), dim3(256), 0, st, d, none, 0, grid);
     LAUNCH_OK("dw_stream_kernel");
   }

@@ -162,12 +162,142 @@ __device__ __forceinline__ void dw_item(const DwLayer& L, int split, int m0, int
     }
 }
 
+// ---- split mode (DsdfNet.gemm_split, fused.hpp fused_kloop_split): 6 bf16 MFMAs on 3-way cut fp32 operands per tile product -------
+// v_mfma_f32_32x32x16_bf16 wants 8 consecutive k (= POINTS here) of one column per lane, and the operands are k-major: a lane takes its
+// 8 points x 4 consecutive columns per operand and 16-point step; component j of the 8 vectors IS the fragment of tile j.  At 2.7 x the
+// MFMA rate the register ring of dw_item cannot cover the HBM latency any more (two attempts: 1315 us spilling, 447 us with two steps in
+// flight), so the prefetch ring lives in LDS: the 4 waves of a workgroup own a 2 x 2 block of tiles of one split, i.e.
+// TWO 128-column panels of each operand, and stream them with direct-to-LDS loads (buffer_load_dwordx4 ... lds: no registers in flight)
+// into a ring of DWS_RING steps of 32 KB; one barrier per step publishes a step and frees the slot of the previous one.  Rows past the
+// item's last point read as zero through the buffer bounds check (row offset in the VECTOR offset).  Accumulators as in dw_item<4>.
+constexpr int DWS_RING = 4;
+constexpr int DWS_SLOT = 2 * 16 * 256;      // floats per ring slot: A panel [16 points][256 columns], then the B panel
+
+__device__ __forceinline__ Split3 split8v(const float (&x)[8]) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  uint32_t hw[4], mw[4], lw[4];
+#pragma unroll
+  for (int pr = 0; pr < 4; ++pr) {
+    float r[2], t[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float v = x[2 * pr + e];
+      r[e] = v - __uint_as_float(__float_as_uint(v) & 0xFFFF0000u);
+      t[e] = r[e] - __uint_as_float(__float_as_uint(r[e]) & 0xFFFF0000u);
+    }
+    hw[pr] = __builtin_amdgcn_perm(__float_as_uint(x[2 * pr + 1]), __float_as_uint(x[2 * pr]), 0x07060302u);
+    mw[pr] = __builtin_amdgcn_perm(__float_as_uint(r[1]), __float_as_uint(r[0]), 0x07060302u);
+    lw[pr] = __builtin_amdgcn_perm(__float_as_uint(t[1]), __float_as_uint(t[0]), 0x07060302u);
+  }
+  Split3 s;
+  s.h = __builtin_bit_cast(bf16x8, (u32x4){hw[0], hw[1], hw[2], hw[3]});
+  s.m = __builtin_bit_cast(bf16x8, (u32x4){mw[0], mw[1], mw[2], mw[3]});
+  s.l = __builtin_bit_cast(bf16x8, (u32x4){lw[0], lw[1], lw[2], lw[3]});
+  return s;
+}
+
+// the workgroup's block: row tiles tmb, tmb + 1 and column tiles tnb, tnb + 1 of `split`; wave w takes (tmb + (w >> 1), tnb + (w & 1))
+__device__ __forceinline__ void dw_block_split(const DwLayer& L, int split, int tmb, int tnb, int kbeg, int kend, int w, int lane, float* ring) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int npts = kend - kbeg, nsteps = (npts + 15) >> 4;      // steps of 16 points (uniform over the workgroup)
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(L.dp + (size_t)kbeg * L.ld_dp), 0, npts * L.ld_dp * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(L.act + (size_t)kbeg * L.ld_act), 0, npts * L.ld_act * 4, 0x00020000);
+  // producer side: this wave brings rows 4w .. 4w+3 of every step, one load instruction = one 256-column row of a panel (lane l:
+  // columns 4l .. 4l+3 -> the row lands contiguously at the LDS pointer)
+  const int pva = (tmb * 128 + 4 * lane) * 4, pvb = (tnb * 128 + 4 * lane) * 4;
+  auto issue = [&](int st) __attribute__((always_inline)) {
+    float* slot = ring + (st % DWS_RING) * DWS_SLOT;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row = 4 * w + rr, pt = 16 * st + row;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(slot + row * 256), 16, pt * L.ld_dp * 4 + pva, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(slot + 4096 + row * 256), 16, pt * L.ld_act * 4 + pvb, 0, 0, 0);
+    }
+  };
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+  for (int st = 0; st < DWS_RING - 1; ++st) issue(st);      // (steps past the end: every row out of range, zeros land in LDS)
+  const int ca = (w >> 1) * 128 + 4 * fr, cb = 4096 + (w & 1) * 128 + 4 * fr;
+  for (int st = 0; st < nsteps; ++st) {
+    // this wave's loads of step st are the oldest 8 of the 8 (DWS_RING - 1) in flight
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (((8 * (DWS_RING - 2)) & 15)) | ((((8 * (DWS_RING - 2)) >> 4) & 3) << 14));   // vmcnt(16), nothing else
+    __builtin_amdgcn_s_barrier();          // step st is complete in LDS; everybody is done reading step st - 1  (the bare barrier:
+                                           // __syncthreads()' fence makes the compiler wait for ALL loads in flight, vmcnt(0))
+    issue(st + DWS_RING - 1);              // ... whose slot takes step st + DWS_RING - 1
+    // The fragment reads are inline asm ON PURPOSE: the compiler's wait-count pass cannot tell the ring slots apart and puts
+    // s_waitcnt vmcnt(0) in front of any ds_read it sees -- i.e. it waits for the loads just issued, and the ring is worth nothing.
+    // (Inline asm hides hazards from it as well, cf. fused_bf16x8's history: the lgkmcnt wait is part of the asm.)
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 a[8], b[8];
+    {
+      typedef __attribute__((address_space(3))) const float* lds_cf;
+      const float* slot = ring + (st % DWS_RING) * DWS_SLOT;
+      const uint32_t aa = (uint32_t)(uintptr_t)(lds_cf)(slot + 8 * fh * 256 + ca), ab = (uint32_t)(uintptr_t)(lds_cf)(slot + 8 * fh * 256 + cb);
+      asm volatile(
+          "ds_read_b128 %0, %16\n ds_read_b128 %1, %16 offset:1024\n ds_read_b128 %2, %16 offset:2048\n ds_read_b128 %3, %16 offset:3072\n"
+          "ds_read_b128 %4, %16 offset:4096\n ds_read_b128 %5, %16 offset:5120\n ds_read_b128 %6, %16 offset:6144\n ds_read_b128 %7, %16 offset:7168\n"
+          "ds_read_b128 %8, %17\n ds_read_b128 %9, %17 offset:1024\n ds_read_b128 %10, %17 offset:2048\n ds_read_b128 %11, %17 offset:3072\n"
+          "ds_read_b128 %12, %17 offset:4096\n ds_read_b128 %13, %17 offset:5120\n ds_read_b128 %14, %17 offset:6144\n ds_read_b128 %15, %17 offset:7168\n"
+          "s_waitcnt lgkmcnt(0)"
+          : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7]),
+            "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(b[4]), "=&v"(b[5]), "=&v"(b[6]), "=&v"(b[7])
+          : "v"(aa), "v"(ab)
+          : "memory");
+    }
+    Split3 sa[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float x[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x[k] = i == 0 ? a[k].x : (i == 1 ? a[k].y : (i == 2 ? a[k].z : a[k].w));
+      sa[i] = split8v(x);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float x[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x[k] = j == 0 ? b[k].x : (j == 1 ? b[k].y : (j == 2 ? b[k].z : b[k].w));
+      const Split3 sb = split8v(x);
+#define DW_PASS(AX, BX)                                                                                                     \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                          \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[i].AX, sb.BX, acc[i][j], 0, 0, 0);
+      DW_PASS(l, h) DW_PASS(h, l) DW_PASS(m, m) DW_PASS(m, h) DW_PASS(h, m) DW_PASS(h, h)
+#undef DW_PASS
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the loads issued past the last step have landed ...
+  __syncthreads();                         // ... before anybody reuses the ring
+  // epilogue: acc[i][j][reg] = dW[m0 + 4 (crow(reg) + 4 fh) + i][n0 + 4 fr + j]  ->  one 16-byte store per (i, reg)
+  const int m0 = (tmb + (w >> 1)) * 128, n0 = (tnb + (w & 1)) * 128;
+  float* slab = L.slabs + (size_t)split * L.slab;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)slab, 0, L.M * L.ldc * 4, 0x00020000);
+  const int n = n0 + 4 * fr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) {
+      const int m = m0 + 4 * (crow(rg) + 4 * fh) + i;       // rows >= M fall outside the descriptor and are dropped
+      const uint32_t voff = n < L.ldc ? (uint32_t)((m * L.ldc + n) * 4) : 0x7FFFFFFFu;   // ldc % 4 == 0
+      u32x4 v = {__float_as_uint(acc[i][0][rg]), __float_as_uint(acc[i][1][rg]), __float_as_uint(acc[i][2][rg]),
+                 __float_as_uint(acc[i][3][rg])};
+      __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, 0, 0);
+    }
+}
+
 // `busy_wg` workgroups (= ceil(items / 4)) stream the dW tiles; the launch covers the whole chip, and the workgroups beyond
 // them -- the items never fill it exactly (96 tiles x 10 splits = 960 of 1024 waves for the 8x512 net) -- work through
 // the post-backward roles of kernels.hpp (head partials, x0 columns of dW, per-segment latent gradient) meanwhile, so
 // those cost no launch of their own on the critical path.  post.rr_n + post.dw_n + post_lat_n == 0: nothing to do.
-__global__ __launch_bounds__(256, 1) void dw_stream_kernel(const DwArgs p, const PostBwdArgs post, const int post_lat_n,
-                                                           const int busy_wg) {
+template <bool SPLIT>
+__device__ __forceinline__ void dw_stream_body(const DwArgs& p, const PostBwdArgs& post, const int post_lat_n, const int busy_wg, float* ring) {
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: item, K range and the
   const int fr = lane & 31, fh = lane >> 5;                                                  // ring's bounds checks stay scalar
   const int lwg = xcd_remap(blockIdx.x, gridDim.x);
@@ -181,7 +311,24 @@ __global__ __launch_bounds__(256, 1) void dw_stream_kernel(const DwArgs p, const
   }
   const int nwaves = busy_wg * 4;
   const int wave = lwg * 4 + w;
-  for (int item = wave; item < p.n_full; item += nwaves) {
+  for (int item = wave; item - w < p.n_full; item += nwaves) {     // (item - w: the workgroup's first item -- uniform trip count)
+    if constexpr (SPLIT) {
+      // the workgroup's 4 items as ONE 2 x 2 block of tiles of one split: then the operand panels go through the LDS ring
+      const int item0 = item - w;
+      int l0 = 0;
+      while (l0 + 1 < p.n_layers && item0 >= p.ly[l0 + 1].full0) ++l0;
+      const DwLayer& L0 = p.ly[l0];
+      const int tf0 = L0.tiles_m * L0.nfull_n, local0 = item0 - L0.full0;
+      const bool block = item0 + 3 < p.n_full && (l0 + 1 >= p.n_layers || item0 + 3 < p.ly[l0 + 1].full0) && !(L0.tiles_m & 1) &&
+                         !(L0.nfull_n & 1) && !(local0 & 3) && !(tf0 & 3);
+      if (block) {
+        const int split = local0 / tf0, b = (local0 - split * tf0) >> 2, nbn = L0.nfull_n >> 1;
+        const int kbeg = split * L0.kchunk;
+        dw_block_split(L0, split, 2 * (b / nbn), 2 * (b % nbn), kbeg, min(p.N, kbeg + L0.kchunk), w, lane, ring);
+        continue;
+      }
+    }
+    if (item >= p.n_full) continue;
     int l = 0;
     while (l + 1 < p.n_layers && item >= p.ly[l + 1].full0) ++l;
     const DwLayer& L = p.ly[l];
@@ -220,6 +367,18 @@ __global__ __launch_bounds__(256, 1) void dw_stream_kernel(const DwArgs p, const
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256, 1) void dw_stream_kernel(const DwArgs p, const PostBwdArgs post, const int post_lat_n,
+                                                           const int busy_wg) {
+  dw_stream_body<false>(p, post, post_lat_n, busy_wg, nullptr);
+}
+// DsdfNet.gemm_split: blocks of full-width items on the bf16 pipe (dw_block_split); everything else (items that do not form a 2 x 2
+// block, narrow edge items, the riding roles) as above.  A kernel of its own so that the fp32 kernel keeps its register allocation.
+__global__ __launch_bounds__(256, 1) void dw_stream_split_kernel(const DwArgs p, const PostBwdArgs post, const int post_lat_n,
+                                                                 const int busy_wg) {
+  __shared__ __attribute__((aligned(16))) float ring[DWS_RING * DWS_SLOT];     // 128 KB
+  dw_stream_body<true>(p, post, post_lat_n, busy_wg, ring);
 }
 
 }  // namespace dsdf
