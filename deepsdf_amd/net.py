@@ -38,7 +38,7 @@ class NetSpec:
         """forward_bf16 (not a reference key; BASELINE config 5): hidden-layer forward GEMMs on bf16 MFMA with fp32
         accumulation; backward, master weights and Adam stay fp32.
         gemm_split (not a reference key; opt-in, default from the environment variable DSDF_GEMM_SPLIT=1): the fused kernels'
-        hidden-layer GEMMs on the bf16 matrix pipe with every fp32 operand cut into three bf16 terms -- fp32 accuracy (the
+        hidden-layer GEMMs (forward, backward, dW) on the bf16 matrix pipe with every fp32 operand cut into three bf16 terms -- fp32 accuracy (the
         same parity tolerances), 2.7 x the MFMA rate (include/dsdf.h DsdfNet.gemm_split)."""
         norm_layers = tuple(norm_layers or ())
         latent_in = tuple(latent_in or ())

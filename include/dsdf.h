@@ -61,11 +61,11 @@ typedef struct DsdfNet {
   uint32_t ln_param_mask;           /* :60-65 (norm_layers WITHOUT weight_norm): bit l: a bn{l} = nn.LayerNorm(out_dim[l]) module exists
                                        (parameters bn{l}.weight, bn{l}.bias right after lin{l}.weight, lin{l}.bias); forward applies it
                                        between the Linear and the ReLU of every HIDDEN layer that has one (:97-103) */
-  int32_t gemm_split;               /* opt-in: the fused kernels' hidden-layer GEMMs (forward and backward dX chain) run on the bf16 matrix
+  int32_t gemm_split;               /* opt-in: the hidden-layer GEMMs of the three MFMA-bound kernels (forward, backward dX chain, dW) run on the bf16 matrix
                                        pipe with every fp32 operand cut into three bf16 terms (6 of the 9 cross products, fp32 accumulate):
                                        fp32 accuracy (same parity tolerances), 2.7 x the MFMA rate.  Needs every width <= 512; not with the
                                        variants above.  Together with fwd_bf16: the bf16 forward as it is, the backward dX chain in split
-                                       mode.  dW and everything else are unchanged. */
+                                       and dW in split mode.  Everything else is unchanged. */
 } DsdfNet;
 
 /* Offsets (in floats) of every parameter tensor inside the decoder arena, named_parameters() order:
