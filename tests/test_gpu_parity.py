@@ -280,6 +280,36 @@ def test_gemm_split_full_size_step_and_decode_vs_oracle():
         assert rel_err(runs[0], yo) <= FWD_TOL and worst_row <= 1e-5, name
 
 
+@pytest.mark.parametrize("split", [True, False], ids=["split", "fp32mfma"])
+@pytest.mark.parametrize("ragged", [False, True], ids=["segments", "ragged"])
+def test_gemm_split_256_wide_net_vs_oracle(ragged, split):
+    """gemm_split on a net whose weight-gradient tiles form exactly ONE 2 x 2 block per layer and split (4 x 256, skip at layer 2), in
+    segment mode and through the general path (x0 gathered, its columns inside the dW GEMMs; the K-split chunks are not multiples of the
+    dW kernel's 16-point step either way), beside the fp32-MFMA kernels on the same batch: the fp32 tolerances."""
+    L, B, S = 61, 12, 192
+    kw = dict(dims=[256] * 4, dropout=[0, 1, 2, 3], dropout_prob=0.2, norm_layers=[0, 1, 2, 3], latent_in=[2], weight_norm=True,
+              geom_dimension=3)
+    net = orc.make_net(L, **kw)
+    spec = spec_from_meta(dict(L=L, net_specs=dict(kw, gemm_split=split)))
+    params = orc.init_params(net, 17)
+    lat0 = torch.randn(B, L, generator=torch.Generator().manual_seed(18)) / math.sqrt(L)
+    st64 = orc.TrainState.create({k: v.double() for k, v in params.items()}, lat0.double())
+    tr = HipTrainer(spec, params, lat0)
+    for step in range(2):
+        idx, xyz, gt = _safe_batch(net, st64, B, S, 900 + step, 0.1, 1.0, 55)
+        r64 = orc.train_step(net, st64, idx, xyz.double(), gt.double(), delta=0.1, code_bound=1.0, epoch=130, seed=55)
+        rh = tr.step(idx, xyz, gt, delta=0.1, code_bound=1.0, code_reg=True, lam=1e-4, epoch=130, lr=(5e-4, 1e-3), seed=55,
+                     **(dict(force_ragged=True) if ragged else {}))
+        assert abs(rh["loss"] - r64["loss"]) <= 1e-5 * abs(r64["loss"]), step
+        print(f"step {step}: worst gradient rel err {max(rel_err(rh['grads'][k], r64['grads'][k]) for k in r64['grads']):.2e}")
+        for k in r64["grads"]:
+            assert rel_err(rh["grads"][k], r64["grads"][k]) <= GRAD_TOL, (step, k)
+        assert rel_err(rh["dlat"], r64["dlat"]) <= GRAD_TOL, step
+        P = tr.params()
+        for k in st64.params:
+            assert rel_err(P[k], st64.params[k]) <= 5e-5, (step, k)      # (small net: Adam's eps-sized entries, as in the odd-shapes test)
+
+
 def test_full_size_properties():
     """Size-independent properties at 16384 pts: bit-exact determinism, and batch_split=4 == unsplit."""
     L, B, S = 256, 64, 256
