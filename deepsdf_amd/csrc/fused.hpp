@@ -463,7 +463,7 @@ __device__ __forceinline__ void split_prefetch_b(SplitBSet& P, const float* ws, 
 // terms and the loads of unit u+2 go out; sched_group_barrier pins the interleave (a lone in-order wave that does its ~180 VALU
 // instructions in one block lets the MFMA pipe run dry meanwhile: 49 % MFMA-busy before).
 #ifndef SPLIT_SCHED
-#define SPLIT_SCHED 0      // lab: 1 = pin the MFMA / VALU / load interleave with sched_group_barrier (measured slower: 544 against 504 us)
+#define SPLIT_SCHED 0      // lab: 1 = pin the MFMA / VALU / load interleave with sched_group_barrier (measured slower: 544 against 505 us), 2 = MFMA / VALU groups only (530)
 #endif
 template <int NACT>
 __device__ __forceinline__ void fused_kloop_split(f32x16 (&acc)[2][4], const float* ap, const SplitBView& bv, int nu, SplitBSet& PB) {
@@ -507,8 +507,8 @@ __device__ __forceinline__ void fused_kloop_split(f32x16 (&acc)[2][4], const flo
     for (int q = 0; q < NM; ++q) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA
       __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);     // VALU
-      if (q % 4 == 1 && q / 4 < NVM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // VMEM read
-      if (q % 4 == 3 && q / 4 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
+      if (SPLIT_SCHED == 1 && q % 4 == 1 && q / 4 < NVM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // VMEM read
+      if (SPLIT_SCHED == 1 && q % 4 == 3 && q / 4 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
     }
 #endif
   };
