@@ -246,7 +246,7 @@ __device__ __forceinline__ void dw_block_split(const DwLayer& L, int split, int 
           "ds_read_b128 %4, %16 offset:4096\n ds_read_b128 %5, %16 offset:5120\n ds_read_b128 %6, %16 offset:6144\n ds_read_b128 %7, %16 offset:7168\n"
           "ds_read_b128 %8, %17\n ds_read_b128 %9, %17 offset:1024\n ds_read_b128 %10, %17 offset:2048\n ds_read_b128 %11, %17 offset:3072\n"
           "ds_read_b128 %12, %17 offset:4096\n ds_read_b128 %13, %17 offset:5120\n ds_read_b128 %14, %17 offset:6144\n ds_read_b128 %15, %17 offset:7168\n"
-          "s_waitcnt lgkmcnt(0)"
+          "s_waitcnt lgkmcnt(8)"     // the A fragments are there; the B reads stay in flight while A is cut (second wait below)
           : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7]),
             "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(b[4]), "=&v"(b[5]), "=&v"(b[6]), "=&v"(b[7])
           : "v"(aa), "v"(ab)
@@ -260,6 +260,8 @@ __device__ __forceinline__ void dw_block_split(const DwLayer& L, int split, int 
       for (int k = 0; k < 8; ++k) x[k] = i == 0 ? a[k].x : (i == 1 ? a[k].y : (i == 2 ? a[k].z : a[k].w));
       sa[i] = split8v(x);
     }
+    // (the operands tie the B registers to this wait: nothing that reads them can be scheduled in front of it)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float x[8];
