@@ -26,7 +26,6 @@ import math
 import os
 import statistics
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -35,10 +34,11 @@ from deepsdf_amd import dist  # noqa: E402  (first: HSA_*/NCCL_* defaults must b
 
 import torch  # noqa: E402
 
+INIT_STEPS = 40
 PEAK_TFLOPS = 157.3          # fp32 MFMA dense peak, MI355X_MICROARCH.md "Peak FP32 (matrix)"
 NET = dict(dims=[512] * 8, dropout=list(range(8)), dropout_prob=0.2, norm_layers=list(range(8)), latent_in=[4],
            xyz_in_all=False, use_tanh=False, latent_dropout=False, weight_norm=True, geom_dimension=3)
-L = 256                      # 64 scenes x 256 samples = 16384 pts/step
+HEADLINE = dict(code_length=256, scenes_per_batch=64, samples=256)     # 64 scenes x 256 samples = 16384 pts/step
 
 
 def synth_batches(n_batches, scene_lo, scene_hi, device, seed, scenes_per_batch, samples):
@@ -74,53 +74,48 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline():
+def cpu_baseline(L, B, S, headline):
     """The reference's CPU path restated in stock torch ops (oracle/torch_native.py: F.linear + autograd + nn.Embedding(max_norm)
-    + torch.optim.Adam, hash dropout masks injected) timed on this host on a bounded sample of the SAME workload:
-      k = all threads: 3 warm-up + 10 timed full 16384-pt optimiser steps, median;
-      k = 1 thread:    1 warm-up + 3 timed steps of a 4096-pt quarter batch (same scenes / net; per-point cost is what is reported).
+    + torch.optim.Adam, hash dropout masks injected) timed on this host on a bounded sample of the SAME workload (full 16384-pt
+    config-2 optimiser steps), with NO child process alive (the PMC passes have been joined before this is called):
+      scan   k in {1, 8, 16, 32, 64 (= one socket of the 2 x 64-core box), all hardware threads}: 1 warm-up + 3 timed steps each, median;
+      value  the best count of the scan re-timed: 3 warm-up + 10 timed steps, median   (BASELINE.md section 5 protocol: k = 1 and
+             k = all are always reported; torch's CPU GEMMs + autograd do not scale to both sockets, so "all" is not the best).
     The explicit-algebra oracle (hand-derived backward; the parity checker) is timed beside it for reference."""
     from oracle import deepsdf_oracle as orc
     from oracle.torch_native import NativeStep
-    B, S = 64, 256
+    if not headline:       # other batch shapes (--scenes-per-batch / --samples / --code-length): the same scenes, at most ~16384 points
+        S = max(2, min(S, 16384 // B))      # per CPU step (per-point cost is what is reported), and a shorter scan
     net = orc.make_net(L, **NET)
     params = orc.init_params(net, 0)
     gen = torch.Generator().manual_seed(1)
     lat = torch.randn(B, L, generator=gen) / math.sqrt(L)
     b = synth_batches(1, 0, B, "cpu", 7, B, S)[0]
     n_all = torch.get_num_threads()
+    counts = (1, 8, 16, 32, 64, n_all) if headline else (1, 32, n_all)
 
-    def time_native(idx, xyz, gt, warm, timed):
+    def time_native(warm, timed):
         nat = NativeStep(net, params, lat, code_bound=1.0)
-        masks = orc.dropout_masks(net, 0, 0, idx.numel())
+        masks = orc.dropout_masks(net, 0, 0, b["idx"].numel())
         ts = []
         for i in range(warm + timed):
             t0 = time.perf_counter()
-            nat.step(idx, xyz, gt, delta=0.1, epoch=1, masks=masks)
+            nat.step(b["idx"], b["xyz_cpu"], b["gt_cpu"], delta=0.1, epoch=1, masks=masks)
             if i >= warm:
                 ts.append(time.perf_counter() - t0)
         return statistics.median(ts)
 
-    # thread-count scan: torch's CPU GEMMs + autograd do NOT scale to every core of a two-socket host (128 threads ran the
-    # step 4x SLOWER than 16 on the EPYC 9575F box), so the baseline is quoted at the best count found, not at "all"
+    pts = B * S
     scan = {}
     try:
-        for k in sorted({c for c in (8, 16, 32, 64, n_all) if c <= n_all}):
+        for k in sorted({c for c in counts if c <= n_all}):
             torch.set_num_threads(k)
-            scan[k] = time_native(b["idx"], b["xyz_cpu"], b["gt_cpu"], 1, 2)
+            scan[k] = time_native(1, 3)
         k_best = min(scan, key=scan.get)
         torch.set_num_threads(k_best)
-        t_all = time_native(b["idx"], b["xyz_cpu"], b["gt_cpu"], 3, 10)
-        q = slice(0, 16 * S)                                     # 16 scenes x 256 = 4096 points
-        torch.set_num_threads(1)
-        t_one = time_native(b["idx"][q], b["xyz_cpu"][q], b["gt_cpu"][q], 1, 3)
-    finally:
-        torch.set_num_threads(n_all)
-    st = orc.TrainState.create({k: v.clone() for k, v in params.items()}, lat.clone())
-    masks = [orc.dropout_masks(net, 0, 0, b["idx"].numel())]
-    kw = dict(delta=0.1, code_bound=1.0, epoch=1, masks_per_chunk=masks)
-    torch.set_num_threads(k_best)
-    try:
+        t_best = time_native(3, 10)
+        st = orc.TrainState.create({k: v.clone() for k, v in params.items()}, lat.clone())
+        kw = dict(delta=0.1, code_bound=1.0, epoch=1, masks_per_chunk=[orc.dropout_masks(net, 0, 0, b["idx"].numel())])
         orc.train_step(net, st, b["idx"], b["xyz_cpu"], b["gt_cpu"], **kw)
         ts = []
         for _ in range(3):
@@ -129,14 +124,16 @@ def cpu_baseline():
             ts.append(time.perf_counter() - t0)
     finally:
         torch.set_num_threads(n_all)
-    return dict(value=B * S / t_all, unit="point-samples/s", cores=k_best, kind="port", cpu_model=cpu_model(), host_threads=n_all,
-                thread_scan_pts_per_s={str(k): B * S / t for k, t in scan.items()},
+    at = lambda k: dict(value=pts / scan[k], cores=k, ms_per_step=1e3 * scan[k]) if k in scan else None   # noqa: E731
+    return dict(value=pts / t_best, unit="point-samples/s", cores=k_best, kind="port", cpu_model=cpu_model(), host_threads=n_all,
+                thread_scan_pts_per_s={str(k): pts / t for k, t in scan.items()},
                 sample=f"oracle/torch_native.py (stock torch ops + autograd + torch.optim.Adam = the op sequence the reference runs on "
-                       f"a CPU), fp32, {k_best} threads (best of the scan {sorted(scan)} on a {n_all}-thread host): median of 10 full "
-                       f"16384-pt config-2 optimiser steps after 3 warm-up ({1e3 * t_all:.0f} ms/step)",
-                k1=dict(value=16 * S / t_one, cores=1, ms_per_step=1e3 * t_one,
-                        sample="same step, 1 thread, 4096-pt quarter batch: median of 3 steps after 1 warm-up"),
-                oracle_explicit=dict(value=B * S / statistics.median(ts), cores=k_best,
+                       f"a CPU), fp32, {k_best} threads (the best of the scan {sorted(scan)} on a {n_all}-thread host; scan points: "
+                       f"median of 3 full steps after 1 warm-up): median of 10 full {pts}-pt optimiser steps ({B} scenes x {S} samples, L={L}"
+                       f"{', = config 2' if headline else ''}) after 3 warm-up ({1e3 * t_best:.0f} ms/step); no other process of this bench alive "
+                       f"meanwhile",
+                k1=at(1), k64=at(64), kall=at(n_all),
+                oracle_explicit=dict(value=pts / statistics.median(ts), cores=k_best,
                                      sample="oracle/deepsdf_oracle.py train_step (hand-derived backward, the parity checker), "
                                             "median of 3 full steps"))
 
@@ -160,6 +157,9 @@ def main():
     ap.add_argument("--scenes-per-batch", type=int, default=64,
                     help="NOT the headline config: scale the batch (x --samples) to see other batch shapes")
     ap.add_argument("--samples", type=int, default=256, help="samples per scene (headline: 256)")
+    ap.add_argument("--code-length", type=int, default=256,
+                    help="CodeLength L (headline: 256).  NOT the headline otherwise: the reference's shipped 8x512 experiments use 2 and 16 "
+                         "with --scenes-per-batch 10 --samples 16000 (experiments/double_lattice_3D/specs.json:9-38, simple_geom/specs.json:20)")
     ap.add_argument("--config", choices=["fp32", "bf16", "f32split", "bf16split"], default="fp32",
                     help="fp32 = BASELINE configs[1] (the headline, v_mfma_f32_32x32x2_f32); bf16 = configs[4]: the same workload with the "
                          "hidden-layer forward GEMMs on bf16 inputs / fp32 accumulate (v_mfma_f32_32x32x16_bf16), backward, dW and Adam in "
@@ -178,21 +178,17 @@ def main():
     from deepsdf_amd.net import NetSpec
     from deepsdf_amd.train import FusedTrainStep
 
-    B, S = args.scenes_per_batch, args.samples
-    headline = (B, S) == (64, 256)
+    B, S, L = args.scenes_per_batch, args.samples, args.code_length
+    headline = dict(code_length=L, scenes_per_batch=B, samples=S) == HEADLINE
     # rehearsal knobs (1-GPU box): DSDF_DIST_BACKEND=gloo + DSDF_SINGLE_DEVICE=1 run several ranks on ONE card to exercise
     # the multi-process logic; the driver's real multi-GPU runs use neither (backend nccl = RCCL, one rank per GPU)
-    rank, local, world = dist.init(backend=os.environ.get("DSDF_DIST_BACKEND"))
-    if os.environ.get("DSDF_SINGLE_DEVICE") == "1":
-        local = 0
+    rank, local, world = dist.init()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    # the PMC child passes start NOW (rank 0, N = 1): they share the card with the first seconds of this process's own
-    # initialisation only through the driver's queue, and finish while the CPU baseline runs; they never overlap the timed region
-    pmc_res, pmc_thread = {}, None
+    pmc_res = {}
     want_pmc = rank == 0 and world == 1 and not args.no_pmc and "ROCPROFILER" not in " ".join(os.environ.keys()).upper()
 
     bf16 = args.config in ("bf16", "bf16split")
@@ -215,8 +211,9 @@ def main():
         fused(b["scenes"], s, b["xyz"], b["gt"], 1, 5e-4, 1e-3, batch_split=1, n_norm=n_norm)
 
     # initialisation, not part of the contract's W warm-up steps: the first ~100 launches of a process load the code objects
-    # and grow the runtime's kernarg / signal pools (one-off stalls of 80-90 ms were observed as late as the 4th step)
-    for i in range(40):
+    # and grow the runtime's kernarg / signal pools (one-off stalls of 80-90 ms were observed as late as the 4th step).
+    # Reported in the line as `init_steps` (untimed, like `warmup`).
+    for i in range(INIT_STEPS):
         step(i)
     torch.cuda.synchronize()
     for i in range(args.warmup):
@@ -307,7 +304,8 @@ def main():
 
     # ---- headline config only: the same step with NetworkSpecs gemm_split (opt-in), so that the record carries both ----
     split_extra = None
-    if rank == 0 and world == 1 and headline and args.config == "fp32" and not args.no_extras:
+    if rank == 0 and world == 1 and args.config == "fp32" and not args.no_extras:
+        n_it = max(10, min(100, (100 * 16384) // n_local))
         seng = Engine(NetSpec(L, gemm_split=True, **NET), dev)
         seng.init_like_reference(torch.Generator().manual_seed(0))
         slat = lat.clone()
@@ -318,10 +316,10 @@ def main():
             sstep(i)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for i in range(100):
+        for i in range(n_it):
             sstep(i)
         torch.cuda.synchronize()
-        sms = 1e3 * (time.perf_counter() - t1) / 100
+        sms = 1e3 * (time.perf_counter() - t1) / n_it
         split_extra = dict(ms_per_step=sms, value=n_local / (sms * 1e-3),
                            note="NOT the headline: the same workload with NetworkSpecs gemm_split = true (the fused kernels' hidden GEMMs as 6 "
                                 "bf16 MFMAs on 3-way split fp32 operands, fp32 accumulate; same parity tolerances) -- `bench.py --config f32split` "
@@ -347,16 +345,14 @@ def main():
                         note="HIP events around 100 calls of Engine.decode_latent (seg_hoist_kernel + fused_forward_bf16x8_kernel + the "
                              "host-side launch path); the kernel alone: profiles/r02_bf16_decode_kernel_stats.csv")
 
-    # ---- PMC child passes (GPU, child processes) run WHILE the CPU baseline runs (host cores); both after all GPU timing ----
+    # ---- PMC child passes (GPU, child processes), THEN the CPU baseline on an otherwise idle host; both after all GPU timing ----
     if want_pmc:
-        extra = ["--scenes-per-batch", str(B), "--samples", str(S), "--config", args.config]
-        pmc_thread = threading.Thread(target=pmc_children, args=(pmc_res, extra), daemon=True)
-        pmc_thread.start()
+        extra = ["--scenes-per-batch", str(B), "--samples", str(S), "--config", args.config, "--code-length", str(L)]
+        pmc_children(pmc_res, extra)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not bf16:
-        cpu = cpu_baseline()
-    if pmc_thread is not None:
-        pmc_thread.join(timeout=600)
+        torch.cuda.synchronize()
+        cpu = cpu_baseline(L, B, S, headline)
     if roofline is not None:
         dom = roofline["kernel"]
         if split:      # the profiling class keeps its name; the launched kernel is the split twin
@@ -388,7 +384,7 @@ def main():
                              f"Adam fp32; {n_local} pts/step ({B} scenes x {S} samples)" if bf16 else
                              f"configs[1] with NetworkSpecs gemm_split (opt-in): the fused forward/backward GEMMs as 6 bf16 MFMAs on 3-way "
                              f"split fp32 operands; {n_local} pts/step ({B} scenes x {S} samples)" if split else
-                             f"configs[1]: {B} synthetic sphere-SDF scenes, latent_dim=256, 8x512 decoder + layer-4 skip, "
+                             f"{'configs[1]' if headline else 'NOT the headline (configs[1] at another batch shape / code length)'}: {B} synthetic sphere-SDF scenes, latent_dim={L}, 8x512 decoder + layer-4 skip, "
                              f"weight-norm, dropout 0.2, {n_local} pts/step ({B} scenes x {S} samples), fp32") if world == 1 else
                             f"configs[2]: {total_scenes} scenes sharded over {world} ranks, {n_local} pts/step/rank, RCCL all-reduce of "
                             "decoder grads (asynchronous, latent Adam under it)"),
@@ -402,12 +398,13 @@ def main():
             cfg["one_scene_value"] = 16384 / (one_scene * 1e-3)
         print(json.dumps({
             "metric": "SDF point-samples/sec per training step (8x512 decoder, 16384 pts)", "value": value,
-            "unit": "point-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "point-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "init_steps": INIT_STEPS,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("bf16-fwd/f32 (backward dX GEMMs: 3 bf16 terms per operand, 6 bf16 MFMAs per product, fp32 accumulate)" if bf16 and split
                       else "bf16-fwd/f32") if bf16 else ("f32 (hidden GEMMs of the fused kernels: 3 bf16 terms per operand, 6 bf16 MFMAs per product, "
                                                    "fp32 accumulate)" if split else "f32"), "data": "synthetic", "config": cfg, "step_time_ms": step_stats,
             "roofline": roofline, "cpu_baseline": cpu}))
+    dist.shutdown()
 
 
 if __name__ == "__main__":

@@ -6,7 +6,7 @@ import os
 from .build import LIB
 
 MAX_LAYERS = 16
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class DsdfNet(C.Structure):
@@ -81,6 +81,7 @@ PROTOTYPES = {
     "dsdf_gemm_tn": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _SZ, _P],
     "dsdf_dropout_mask": [C.c_uint32, _F, _I64, _I64, _I64, _P, _P],
     "dsdf_decode_latent": [_NET, _P, _P, _P, _P, _I64, _P, _P, _SZ, _P],
+    "dsdf_decode_latent_supported": [_NET],
     "dsdf_sample_batch": [_P, C.c_int32, _P, _P, _P, _P, _P, _I64, _I64, C.c_uint64, _P, _P, _P],
 }
 

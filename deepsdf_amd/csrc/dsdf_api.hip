@@ -93,6 +93,8 @@ int validate(const DsdfNet* n) {
   if (n->n_layers < 2 || n->n_layers > DSDF_MAX_LAYERS) return fail(DSDF_E_INVALID, "n_layers %d out of range", n->n_layers);
   const int W0 = n->latent_size + n->geom_dim;
   if (n->latent_size < 0 || n->geom_dim < 1) return fail(DSDF_E_INVALID, "bad latent_size/geom_dim");
+  // the d/d(xyz) scratch of an xyz_in_all net (module_backward with d_input, the tangent pass) is laid out [N][4]
+  if (n->xyz_in_all && n->geom_dim > 4) return fail(DSDF_E_INVALID, "xyz_in_all needs geom_dim <= 4 (got %d)", n->geom_dim);
   if (n->in_dim[0] != W0) return fail(DSDF_E_INVALID, "in_dim[0] %d != latent_size+geom_dim %d", n->in_dim[0], W0);
   if (n->out_dim[n->n_layers - 1] != 1) return fail(DSDF_E_INVALID, "last layer must have out_dim 1");
   if (n->skip_mask & 1u) return fail(DSDF_E_INVALID, "latent_in may not contain layer 0");
@@ -1096,13 +1098,22 @@ int dsdf_decode(const DsdfNet* net, const float* packed, const float* params, co
   return launch_last<LAST_FWD>(a, blocks, st);
 }
 
+static bool decode_latent_ok(const DsdfNet* net) {
+  return fused_enabled() && fused_eligible(net) && net->geom_dim <= FGEO && net->latent_size <= HOIST_MAXL &&
+         net->latent_size >= 1 && net->n_layers >= 3;
+}
+
+int dsdf_decode_latent_supported(const DsdfNet* net) {
+  TRY(validate(net));
+  return decode_latent_ok(net) ? 1 : 0;
+}
+
 int dsdf_decode_latent(const DsdfNet* net, const float* packed, const float* params, const float* latent, const float* xyz,
                        int64_t n, float* sdf_out, void* ws, size_t ws_bytes, void* stream) {
   TRY(check_common(net, packed, params, ws));
   if (n == 0) return 0;
   if (!latent || !xyz || !sdf_out || n < 0) return fail(DSDF_E_INVALID, "bad latent/xyz/sdf_out");
-  if (!fused_enabled() || !fused_eligible(net) || net->geom_dim > FGEO || net->latent_size > HOIST_MAXL ||
-      net->latent_size < 1 || net->n_layers < 3)
+  if (!decode_latent_ok(net))
     return fail(DSDF_E_INVALID, "dsdf_decode_latent needs the fused forward (widths <= 512, geom_dim <= 4): use dsdf_decode");
   Plan P = make_plan(net, n, 0, true);
   const size_t need = P.total > 16384 ? P.total : 16384;

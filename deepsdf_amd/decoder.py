@@ -56,7 +56,13 @@ class _DecoderBwdFn(torch.autograd.Function):
     """The backward pass as a differentiable function of the incoming gradient: d_input = J^T dy is LINEAR in dy, so its
     own backward is the forward-mode tangent J u (dsdf_module_jvp).  This is what makes the double-backward trick of
     ``torch.autograd.functional.jvp`` work through the decoder (deep_sdf/mesh.py:420).  Parameter gradients are returned
-    but not differentiable a second time."""
+    but not differentiable a second time.
+
+    LIMIT (by design): d_input is differentiable with respect to dy ONLY.  The second-order terms through tanh / the weights --
+    what a gradient-penalty or eikonal loss on d sdf / d xyz followed by .backward() would need -- are not produced: the
+    reference never asks for them (its only second-order use is the jvp trick above), and autograd gives a Function no way
+    to tell "dy's gradient only" from "everything" at backward time, so such a use cannot be refused here either.  Use the
+    TorchScript export twin (Decoder.export_torchscript, stock torch ops) for losses of that kind."""
 
     @staticmethod
     def forward(ctx, dec, dy, token, n, training, need_x):

@@ -24,17 +24,36 @@ def env_world():
 
 
 def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment.  Returns (rank, local_rank, world)."""
+    """Initialise torch.distributed from the torchrun environment.  Returns (rank, local_rank, world).
+
+    Rehearsal knobs for a ONE-GPU box (tests/test_gpu_dist.py; the driver's multi-GPU runs use neither):
+    DSDF_DIST_BACKEND=gloo selects the transport when the caller names none, DSDF_SINGLE_DEVICE=1 puts every rank on
+    device 0 (returned as local_rank), so that bench.py, the trainer and the tests' worker share one definition."""
     rank, local, world = env_world()
+    if os.environ.get("DSDF_SINGLE_DEVICE") == "1":
+        local = 0
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("DSDF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
+
+
+def replicas_identical(flat):
+    """True iff every rank holds bit-identical contents of `flat` (MAX and MIN over ranks of the raw bit patterns agree).
+    The data-parallel step keeps decoder replicas identical by construction (same reduced gradient, same deterministic
+    Adam); the trainer checks it before every checkpoint, so a diverged replica is an error, not a silently saved rank 0."""
+    if not is_multi():
+        return True
+    bits = flat.detach().contiguous().view(torch.int32)
+    hi, lo = bits.clone(), bits.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    return bool(torch.equal(hi, lo))
 
 
 def owned_scenes(num_scenes, rank, world):
@@ -68,6 +87,14 @@ def is_multi():
 def barrier():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def shutdown():
+    """Leave the process group in step (barrier) and tear it down; a no-op for a single process."""
+    if dist.is_available() and dist.is_initialized():
+        if dist.get_world_size() > 1:
+            dist.barrier()
+        dist.destroy_process_group()
 
 
 def max_over_ranks(value, device):

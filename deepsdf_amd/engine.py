@@ -138,6 +138,13 @@ class Engine:
                                             ws.numel(), _stream()))
         return out.view(n, 1)
 
+    def decode_latent_supported(self):
+        """Whether decode_latent takes this net (dsdf_decode_latent_supported: the library's own condition)."""
+        rc = self.lib.dsdf_decode_latent_supported(C.byref(self.cnet))
+        if rc < 0:
+            _lib.check(rc)
+        return rc == 1
+
     def decode_latent(self, latent, xyz, max_chunk=1 << 20):
         """decode_sdf with ONE code for every query point: latent [L] (or [1, L]), xyz [n, G] -> sdf [n, 1].  The [n, L+G]
         input is never materialised (dsdf_decode_latent: the latent's products are hoisted out of the per-point work)."""
@@ -234,12 +241,12 @@ class Engine:
         cfg.training, cfg.frozen_decoder = int(training), 0
         for l in range(_lib.MAX_LAYERS):
             cfg.dropout_key[l] = dropout_layer_key(seed, self.step, l)
-        self.step += 1
-        ad = _lib.DsdfAdamCfg(self.step, float(lr_decoder), float(lr_latent), betas[0], betas[1], eps, None)
+        ad = _lib.DsdfAdamCfg(self.step + 1, float(lr_decoder), float(lr_latent), betas[0], betas[1], eps, None)
         _lib.check(self.lib.dsdf_train_step(
             C.byref(self.cnet), _ptr(self.packed), _ptr(self.params), _ptr(self.grads), _ptr(self.exp_avg),
             _ptr(self.exp_avg_sq), _ptr(latents), latents.shape[0], _ptr(dlat), _ptr(lat_m), _ptr(lat_v), C.byref(b),
             C.byref(cfg), C.byref(ad), _ptr(self.loss if loss_out is None else loss_out), None, _ptr(ws), ws.numel(), _stream()))
+        self.step += 1                # only once the call was accepted: a rejected step must not advance Adam's bias correction
         self.weights_dirty = False
 
     def grad_norm(self, max_norm):
@@ -258,13 +265,13 @@ class Engine:
 
     def adam_step(self, latents, dlat, lat_m, lat_v, lr_decoder, lr_latent, *, clip=False, betas=(0.9, 0.999), eps=1e-8):
         """Adam on the decoder arena (+ the latent table unless `latents` is None) and weight re-materialisation."""
-        self.step += 1
-        cfg = _lib.DsdfAdamCfg(self.step, float(lr_decoder), float(lr_latent), betas[0], betas[1], eps,
+        cfg = _lib.DsdfAdamCfg(self.step + 1, float(lr_decoder), float(lr_latent), betas[0], betas[1], eps,
                                (self.clip.data_ptr() + 4) if clip else None)
         nlat = latents.numel() if latents is not None else 0
         _lib.check(self.lib.dsdf_adam_step(C.byref(self.cnet), _ptr(self.params), _ptr(self.grads), _ptr(self.exp_avg),
                                            _ptr(self.exp_avg_sq), _ptr(latents), _ptr(dlat), _ptr(lat_m), _ptr(lat_v),
                                            nlat, C.byref(cfg), _ptr(self.packed), _stream()))
+        self.step += 1
         self.weights_dirty = False
 
 

@@ -58,6 +58,8 @@ class NetSpec:
         self.xyz_in_all = bool(xyz_in_all)
         self.latent_dropout = bool(latent_dropout)
         layer_norm = (not self.weight_norm) and len(norm_layers) > 0        # deep_sdf_decoder.py:60-65
+        if self.xyz_in_all and self.geom_dimension > 4:      # the kernels' d/d(xyz) scratch rows hold 4 floats
+            raise NotImplementedError("xyz_in_all needs geom_dimension <= 4")
         if (self.xyz_in_all or self.latent_dropout or layer_norm) and self.forward_bf16:
             raise NotImplementedError("forward_bf16 is not available with xyz_in_all / latent_dropout / LayerNorm")
         if self.gemm_split and (self.xyz_in_all or self.latent_dropout or layer_norm or max(self.dims) > 512

@@ -205,11 +205,12 @@ class EpochStats:
         self.events = [torch.cuda.Event(), torch.cuda.Event()]
         self.pending = None                                  # slot of the epoch not consumed yet
 
-    def push(self, epoch, loss_buf, latents):
+    def push(self, epoch, loss_buf, latents, lat_mag=None):
+        """lat_mag: the mean latent magnitude when the caller already has it (world > 1: the mean over ALL ranks' rows)."""
         slot = epoch & 1
         d = self.dev[slot]
         d[:self.steps].copy_(loss_buf[:self.steps])
-        d[self.steps] = torch.mean(torch.norm(latents.detach(), dim=1))
+        d[self.steps] = torch.mean(torch.norm(latents.detach(), dim=1)) if lat_mag is None else lat_mag
         d[self.steps + 1:].copy_(torch.stack(torch._foreach_norm([p.data for p in self.params])))
         self.host[slot].copy_(d, non_blocking=True)
         self.events[slot].record()
@@ -389,6 +390,12 @@ def main_function(experiment_directory, continue_from, batch_split):
 
     def save_all(name, epoch):
         full_lat, full_m, full_v = gather_latents(lat), gather_latents(fused.lat_m), gather_latents(fused.lat_v)
+        if world > 1:      # rank 0's decoder is what gets saved: it must BE every rank's decoder (bit for bit)
+            for what, arena in (("parameters", eng.params), ("exp_avg", eng.exp_avg), ("exp_avg_sq", eng.exp_avg_sq)):
+                if not dist.replicas_identical(arena):
+                    raise RuntimeError("data-parallel replicas diverged: decoder {} differ between ranks at epoch {}".format(
+                        what, epoch))
+            logging.info("epoch {}: decoder replicas bit-identical on {} ranks".format(epoch, world))
         if rank != 0:
             return
         save_model(experiment_directory, name, decoder, epoch)
@@ -490,10 +497,14 @@ def main_function(experiment_directory, continue_from, batch_split):
 
             fused(scenes_dev, 2 * int(num_samp_per_scene / 2), xyz, sdf_gt, epoch, lr0, lr1,
                   batch_split=batch_split, n_norm=n_norm, under_allreduce=prefetch, loss_out=loss_buf[it:it + 1])
+        lat_mag = None
         if world > 1:
             torch.distributed.all_reduce(loss_buf)           # per-rank partial losses share the global normaliser
+            mag = torch.stack([torch.norm(lat.detach(), dim=1).sum(), torch.full((), float(n_local), device=device)])
+            torch.distributed.all_reduce(mag)                # mean code magnitude over the WHOLE table (:548-552), not this shard's
+            lat_mag = mag[0] / mag[1]
         stats.pop(loss_log, lat_mag_log, param_mag_log)      # the PREVIOUS epoch's values (its copy finished long ago)
-        stats.push(epoch, loss_buf, lat)                     # this epoch's: asynchronous, consumed one epoch later
+        stats.push(epoch, loss_buf, lat, lat_mag)            # this epoch's: asynchronous, consumed one epoch later
         end = time.time()
         tot_time = time.time() - start_train
         avg = tot_time / (epoch - start_epoch + 1)
@@ -513,3 +524,5 @@ def main_function(experiment_directory, continue_from, batch_split):
             save_all("latest.pth", epoch)
             if rank == 0:
                 save_logs(experiment_directory, loss_log, lr_log, timing_log, lat_mag_log, param_mag_log, epoch)
+    if world > 1:
+        dist.shutdown()

@@ -38,11 +38,10 @@ def decode_sdf(decoder, latent_vector, queries):
     grad = torch.is_grad_enabled() and (latent_vector.requires_grad or queries.requires_grad
                                         or any(p.requires_grad for p in dec.parameters()))
     spec = getattr(dec, "spec", None)
-    if (spec is not None and not grad and not dec.training and latent_vector.numel() == spec.latent_size and queries.is_cuda
-            and spec.geom_dimension <= 4 and max(spec.dims) <= 512 and len(spec.dims) >= 2
-            and not spec.xyz_in_all and not spec.latent_dropout):
+    if spec is not None and not grad and not dec.training and latent_vector.numel() == spec.latent_size and queries.is_cuda:
         eng = dec._engine_for(queries.device)
-        eng.weights_dirty = True   # parameters may have been changed by any optimizer since the last call
-        return eng.decode_latent(latent_vector, queries)
+        if eng.decode_latent_supported():      # the library's own condition (variants / wide nets take the module path below)
+            eng.weights_dirty = True           # parameters may have been changed by any optimizer since the last call
+            return eng.decode_latent(latent_vector, queries)
     inputs = torch.cat([latent_vector.expand(queries.shape[0], -1), queries], 1)
     return decoder(inputs)

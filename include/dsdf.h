@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define DSDF_MAX_LAYERS 16
-#define DSDF_ABI_VERSION 11
+#define DSDF_ABI_VERSION 12
 
 enum {
   DSDF_OK = 0,
@@ -141,6 +141,11 @@ int dsdf_decode(const DsdfNet* net, const float* packed, const float* params, co
  * geom_dim <= 4, at least two hidden layers), otherwise DSDF_E_INVALID: use dsdf_decode. */
 int dsdf_decode_latent(const DsdfNet* net, const float* packed, const float* params, const float* latent, const float* xyz,
                        int64_t n, float* sdf_out, void* ws, size_t ws_bytes, void* stream);
+/* [host] 1 if dsdf_decode_latent accepts this net (in this process: the DSDF_NO_FUSED switch counts), 0 if the caller has
+ * to build the [n, L+G] input and use dsdf_decode (variants on the layer-by-layer kernels: xyz_in_all, latent_dropout,
+ * LayerNorm; widths > 512; geom_dim > 4; fewer than two hidden layers), < 0 for an invalid net.  The ONE definition of
+ * that condition: deep_sdf.utils.decode_sdf (deep_sdf/utils.py:54-65) asks it instead of restating it. */
+int dsdf_decode_latent_supported(const DsdfNet* net);
 
 /* ---- module path: Decoder.forward / autograd backward on an explicit input (plugin seam,
  * train_deep_sdf.py:275,514).  forward keeps activations in ws; backward consumes them. */

@@ -504,8 +504,9 @@ def step_gradients(net: Net, params, latents, indices, xyz, sdf_gt, *, delta, co
 def train_step(net: Net, st: TrainState, indices, xyz, sdf_gt, *, delta, code_bound, code_reg=True,
                code_reg_lambda=1e-4, epoch=1, lr_decoder=5e-4, lr_latent=1e-3, batch_split=1,
                grad_clip=None, training=True, seed=0, masks_per_chunk=None):
-    """Full optimiser step incl. --batch_split accumulation.  Returns dict(loss, grads, dlat)."""
+    """Full optimiser step incl. --batch_split accumulation.  Returns dict(loss, grads, dlat, grad_norm, y [N, 1])."""
     N = xyz.shape[0]
+    ys = []
     xs, is_, ts = torch.chunk(xyz, batch_split), torch.chunk(indices, batch_split), torch.chunk(sdf_gt, batch_split)
     tot_g = None
     tot_dlat = torch.zeros_like(st.latents)
@@ -524,6 +525,7 @@ def train_step(net: Net, st: TrainState, indices, xyz, sdf_gt, *, delta, code_bo
                            code_bound=code_bound, code_reg=code_reg, code_reg_lambda=code_reg_lambda,
                            epoch=epoch, n_norm=N, training=training, masks=masks, latent_mask=lmask)
         loss += float(r["loss"])
+        ys.append(r["y"])
         tot_dlat += r["dlat"]
         if tot_g is None:
             tot_g = r["grads"]
@@ -538,7 +540,7 @@ def train_step(net: Net, st: TrainState, indices, xyz, sdf_gt, *, delta, code_bo
     for k in st.params:
         adam_update_(st.params[k], tot_g[k].reshape(st.params[k].shape), st.m[k], st.v[k], st.step, lr_decoder)
     adam_update_(st.latents, tot_dlat, st.m_lat, st.v_lat, st.step, lr_latent)
-    return dict(loss=loss, grads=tot_g, dlat=tot_dlat, grad_norm=gnorm)
+    return dict(loss=loss, grads=tot_g, dlat=tot_dlat, grad_norm=gnorm, y=torch.cat(ys))
 
 
 # --------------------------------------------------------------------------------------------

@@ -19,9 +19,7 @@ def main(work_dir):
     from deepsdf_amd.net import NetSpec
     from deepsdf_amd.train import FusedTrainStep
 
-    rank, local, world = dist.init(backend=os.environ.get("DSDF_DIST_BACKEND"))
-    if os.environ.get("DSDF_SINGLE_DEVICE") == "1":
-        local = 0
+    rank, local, world = dist.init()          # reads the rehearsal knobs itself
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     case = torch.load(os.path.join(work_dir, "case.pt"), weights_only=True)

@@ -469,6 +469,51 @@ def case_checkpoint_layout(Decoder, name):
     print("wrote", name)
 
 
+def case_sample_counts(name):
+    """G12: the per-scene subsampling COUNT RULE of the reference's own loader (deep_sdf/data.py:74-110, unpack_sdf_samples:
+    half of the subsample from each sign, a shortfall of one sign taken from the other, NaN rows dropped first, torch.randperm
+    = without replacement, positives then negatives).  The reference function is CALLED here on synthetic .npz files whose rows
+    carry their own identity (x = row index within its sign, sdf = +/-(index + 1)); what it returned is stored as counts.
+    Pins f1's count rule: oracle.sample_rows / deepsdf_amd.data._balanced_counts / DeviceSampleCache.sample must reproduce them."""
+    import tempfile
+    ref_trainer_module()
+    rdata = sys.modules["deep_sdf"].data
+    assert os.path.realpath(rdata.__file__).startswith(REF)
+    cases = [dict(id="balanced", n_pos=500, n_neg=700, nan_pos=0, nan_neg=0, subsample=256, dtype="float32"),
+             dict(id="positive_shortfall", n_pos=40, n_neg=900, nan_pos=0, nan_neg=0, subsample=256, dtype="float32"),
+             dict(id="negative_shortfall", n_pos=900, n_neg=17, nan_pos=0, nan_neg=0, subsample=256, dtype="float64"),
+             dict(id="odd_subsample", n_pos=300, n_neg=310, nan_pos=0, nan_neg=0, subsample=255, dtype="float32"),
+             dict(id="exactly_half", n_pos=128, n_neg=128, nan_pos=0, nan_neg=0, subsample=256, dtype="float32"),
+             dict(id="nan_rows_make_a_shortfall", n_pos=100, n_neg=400, nan_pos=70, nan_neg=5, subsample=128, dtype="float64"),
+             dict(id="both_signs_short", n_pos=40, n_neg=50, nan_pos=0, nan_neg=0, subsample=256, dtype="float32")]
+    out = []
+    with tempfile.TemporaryDirectory() as d:
+        for c in cases:
+            def rows(n, n_nan, sign):
+                i = np.arange(n, dtype=np.float64)
+                r = np.stack([i, np.zeros(n), np.full(n, float(sign)), sign * (i + 1)], 1)
+                r[:n_nan, 3] = np.nan                     # the first n_nan rows are NaN samples (remove_nans drops them)
+                return r.astype(c["dtype"])
+            f = os.path.join(d, c["id"] + ".npz")
+            np.savez(f, pos=rows(c["n_pos"], c["nan_pos"], 1), neg=rows(c["n_neg"], c["nan_neg"], -1))
+            torch.manual_seed(1)
+            s = rdata.unpack_sdf_samples(f, 3, c["subsample"])
+            sd = s[:, 3]
+            n_p = int((sd > 0).sum())
+            pos_first = bool((sd[:n_p] > 0).all() and (sd[n_p:] < 0).all())
+            ids_p, ids_n = s[:n_p, 0].long().tolist(), s[n_p:, 0].long().tolist()
+            full = rdata.unpack_sdf_samples(f, 3)          # subsample=None: everything, NaN rows removed
+            out.append(dict(c, rows_returned=int(s.shape[0]), pos_rows=n_p, neg_rows=int(s.shape[0]) - n_p,
+                            positives_then_negatives=pos_first, dtype_returned=str(s.dtype).replace("torch.", ""),
+                            without_replacement=len(set(ids_p)) == len(ids_p) and len(set(ids_n)) == len(ids_n),
+                            nan_rows_never_drawn=bool(min(ids_p, default=10**9) >= c["nan_pos"] and min(ids_n, default=10**9) >= c["nan_neg"]),
+                            rows_without_subsample=int(full.shape[0])))
+    with open(os.path.join(HERE, name + ".json"), "w") as f:
+        json.dump({"cases": out, "source": "reference deep_sdf.data.unpack_sdf_samples (imported, container only), geom_dimension 3"},
+                  f, indent=1)
+    print("wrote", name)
+
+
 def main():
     torch.set_num_threads(4)
     Decoder = ref_decoder_cls()
@@ -515,7 +560,8 @@ def main():
     case_forward_eval(Decoder, "g8_eval_6x128", L=1, net_specs=dict(
         dims=[128] * 6, dropout=list(range(8)), dropout_prob=0.2, norm_layers=list(range(8)), latent_in=[2],
         xyz_in_all=False, use_tanh=False, latent_dropout=False, weight_norm=True, geom_dimension=3), N=100, seed=82)
-    case_reference_run("g10_reference_run")          # LAST: it puts the reference's deep_sdf package into sys.modules
+    case_reference_run("g10_reference_run")          # (from here on the reference's deep_sdf package is in sys.modules)
+    case_sample_counts("g12_sample_counts")
 
 
 if __name__ == "__main__":
@@ -536,5 +582,7 @@ if __name__ == "__main__":
         torch.set_num_threads(4)                      # as main(): the run is bit-reproducible for a fixed thread count
         case_lr("g5_lr_schedules")
         case_reference_run("g10_reference_run")
+    elif "--sample-counts-only" in sys.argv:
+        case_sample_counts("g12_sample_counts")
     else:
         main()

@@ -35,6 +35,24 @@ def rel_err(a, b):
     return float((a - b).norm() / max(float(b.norm()), 1e-30))
 
 
+def worst_elem(a, b):
+    """element-wise worst case max|a-b| / max|b| in float64: what a norm-wise bound cannot see (a handful of corrupted rows or
+    entries among millions -- the 8-wave bf16 kernel's register-reuse race of round 2 passed every norm-wise test)."""
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
+
+
+def g12_scene_file(path, c):
+    """The synthetic .npz of one G12 case (tests/golden/make_golden.py:case_sample_counts): a row carries its own identity,
+    x = index within its sign, z = sign, sdf = +/-(index + 1); the first nan_* rows of a sign are NaN samples."""
+    def rows(n, n_nan, sign):
+        i = np.arange(n, dtype=np.float64)
+        r = np.stack([i, np.zeros(n), np.full(n, float(sign)), sign * (i + 1)], 1)
+        r[:n_nan, 3] = np.nan
+        return r.astype(c["dtype"])
+    np.savez(path, pos=rows(c["n_pos"], c["nan_pos"], 1), neg=rows(c["n_neg"], c["nan_neg"], -1))
+
+
 def sphere_npz(path, k, n=6000):
     """Synthetic scene k (sphere SDF) in the on-disk format of sdf_sampler/sdf_sampler.py:146: pos / neg [*, 4]."""
     g = np.random.default_rng(1234 + k)

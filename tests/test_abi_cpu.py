@@ -110,6 +110,26 @@ def test_argument_errors_are_reported_before_any_launch(lib):
     assert lib.dsdf_packed_floats(C.byref(wide), C.byref(n)) == -1 and b"fwd_bf16" in lib.dsdf_last_error()
     net = NetSpec(8, [64, 64], 3).c_struct()
     assert lib.dsdf_decode_latent(C.byref(net), None, None, None, None, 10, None, None, 0, None) == -1
+    # dsdf_decode_latent_supported is the ONE definition of "the single-code decode takes this net" (decode_sdf asks it)
+    big = NetSpec(256, [512] * 8, 3, dropout=list(range(8)), dropout_prob=0.2, norm_layers=list(range(8)), latent_in=[4], weight_norm=True)
+    assert lib.dsdf_decode_latent_supported(C.byref(big.c_struct())) == 1
+    assert lib.dsdf_decode_latent_supported(C.byref(net)) == 1
+    for kw in (dict(norm_layers=[0, 1], weight_norm=False),             # LayerNorm
+               dict(xyz_in_all=True), dict(latent_dropout=True)):       # the other two layer-by-layer variants
+        assert lib.dsdf_decode_latent_supported(C.byref(NetSpec(8, [64, 64], 3, **kw).c_struct())) == 0, kw
+    assert lib.dsdf_decode_latent_supported(C.byref(NetSpec(8, [640, 640], 3).c_struct())) == 0       # wider than the fused kernels
+    assert lib.dsdf_decode_latent_supported(C.byref(NetSpec(8, [64], 3).c_struct())) == 0             # one hidden layer
+    assert lib.dsdf_decode_latent_supported(C.byref(NetSpec(8, [64, 64], 5).c_struct())) == 0         # geom_dim > 4
+    broken = NetSpec(8, [64, 64], 3).c_struct()
+    broken.in_dim[1] = 63
+    assert lib.dsdf_decode_latent_supported(C.byref(broken)) == -1 and b"in_dim" in lib.dsdf_last_error()
+    # an xyz_in_all net's d/d(xyz) scratch rows hold 4 floats: more geometry columns are refused, on both sides of the ABI
+    x5 = NetSpec(8, [64, 64], 4, xyz_in_all=True).c_struct()
+    x5.geom_dim, x5.in_dim[0] = 5, 13
+    x5.in_dim[1], x5.out_dim[0] = 64, 59
+    assert lib.dsdf_packed_floats(C.byref(x5), C.byref(n)) == -1 and b"xyz_in_all needs geom_dim" in lib.dsdf_last_error()
+    with pytest.raises(NotImplementedError, match="geom_dimension <= 4"):
+        NetSpec(8, [64, 64], 5, xyz_in_all=True)
     # gemm_split: widths <= 512, not together with the bf16 forward or the layer-by-layer variants; its planes enlarge `packed`
     sp = NetSpec(8, [64, 64], 3, gemm_split=True).c_struct()
     plain = NetSpec(8, [64, 64], 3, gemm_split=False).c_struct()
@@ -120,7 +140,6 @@ def test_argument_errors_are_reported_before_any_launch(lib):
     assert lib.dsdf_packed_floats(C.byref(sp), C.byref(n)) == 0
     sp.fwd_bf16, sp.latent_dropout = 0, 1
     assert lib.dsdf_packed_floats(C.byref(sp), C.byref(n)) == -1 and b"gemm_split" in lib.dsdf_last_error()
-    import pytest
     with pytest.raises(NotImplementedError):
         NetSpec(8, [640, 640], 3, gemm_split=True)
     with pytest.raises(NotImplementedError):

@@ -117,3 +117,34 @@ def test_sample_batch_matches_the_oracle_permutation():
     assert not torch.equal(a, cache.sample(ids, 64, generator=torch.Generator().manual_seed(3))[0])   # the draw counter advances
     with pytest.raises(ValueError, match="fewer than"):
         cache.sample(torch.tensor([3]), 512)
+
+
+def test_device_sampler_reproduces_the_reference_count_rule(tmp_path):
+    """Golden G12 (counts the REFERENCE's unpack_sdf_samples returned, deep_sdf/data.py:74-110) through the product's loader +
+    sampling kernel: DeviceSampleCache.from_files (NaN rows filtered, float64 files) -> dsdf_sample_batch.  Per scene: the
+    reference's number of positives, then its number of negatives, no row twice, no NaN row."""
+    import json, os
+    from deepsdf_amd.data import DeviceSampleCache
+    from tests.golden_io import GOLDEN, g12_scene_file
+    g12 = json.load(open(os.path.join(GOLDEN, "g12_sample_counts.json")))["cases"]
+    d = os.path.join(str(tmp_path), "SdfSamples")
+    os.makedirs(d)
+    for c in g12:
+        g12_scene_file(os.path.join(d, c["id"] + ".npz"), c)
+    cache = DeviceSampleCache.from_files(str(tmp_path), [c["id"] + ".npz" for c in g12], 3, "cuda")
+    for k, c in enumerate(g12):
+        assert (cache.n_pos[k], cache.n_neg[k]) == (c["n_pos"] - c["nan_pos"], c["n_neg"] - c["nan_neg"]), c["id"]
+        if cache.n_pos[k] + cache.n_neg[k] < 2 * (c["subsample"] // 2):
+            with pytest.raises(ValueError, match="fewer than"):     # the reference returns a short, un-collatable sample here
+                cache.sample(torch.tensor([k]), c["subsample"])
+            continue
+        xyz, sdf = cache.sample(torch.tensor([k]), c["subsample"], key=1234 + k)
+        xyz, sdf = xyz.cpu(), sdf.cpu()
+        assert sdf.shape[0] == c["rows_returned"] and not bool(torch.isnan(sdf).any()), c["id"]
+        n_p = int((sdf > 0).sum())
+        assert (n_p, sdf.shape[0] - n_p) == (c["pos_rows"], c["neg_rows"]), c["id"]
+        assert bool((sdf[:n_p] > 0).all()) and bool((xyz[:n_p, 2] == 1).all()) and bool((xyz[n_p:, 2] == -1).all()), c["id"]
+        ip, iq = xyz[:n_p, 0].long(), xyz[n_p:, 0].long()
+        assert ip.unique().numel() == n_p and iq.unique().numel() == sdf.shape[0] - n_p, c["id"]      # without replacement
+        assert int(ip.min()) >= c["nan_pos"] and int(iq.min()) >= c["nan_neg"], c["id"]              # NaN rows are gone
+        assert torch.equal(sdf[:n_p], ip.float() + 1) and torch.equal(sdf[n_p:], -(iq.float() + 1)), c["id"]   # rows stay intact

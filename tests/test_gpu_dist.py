@@ -123,3 +123,83 @@ def test_two_rank_hip_step_equals_single_process_and_oracle(tmp_path):
             assert rel_err(M[k], o["m"][k]) <= GRAD_TOL, (step, k)
             assert rel_err(P[k], o["params"][k]) <= PARAM_TOL, (step, k)
         assert rel_err(lat_dp, o["lat"]) <= PARAM_TOL, step
+
+
+def _torchrun_two_ranks(script_args, timeout=900):
+    """`python -m torch.distributed.run --nproc-per-node 2 <script_args>` as a FRESH child of the test process, both ranks on
+    the box's one card over gloo (the rehearsal knobs of deepsdf_amd.dist.init).  Returns the merged stdout + stderr."""
+    env = dict(os.environ, DSDF_DIST_BACKEND="gloo", DSDF_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + script_args
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-4000:]
+    return r.stdout
+
+
+def test_bench_runs_at_world_size_two():
+    """bench.py's N > 1 leg (BASELINE configs[2]: 512 scenes sharded, 16384 points per rank and step, all-reduce of the decoder
+    gradients) launched exactly as the driver launches it, at world size 2: ONE JSON line from rank 0 with the contract's keys."""
+    import json
+    out = _torchrun_two_ranks([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                               "--no-cpu-baseline", "--no-pmc"])
+    lines = [ln for ln in out.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, out[-3000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["config"]["workload"].startswith("configs[2]") and rec["config"]["parallelism"] == "dp2"
+    assert rec["config"]["points_per_step_per_gpu"] == 16384
+    assert math.isfinite(rec["config"]["final_loss"]) and rec["config"]["final_loss"] > 0
+    assert rec["value"] > 0 and abs(rec["value"] - 2 * 16384 / (rec["ms_per_step"] * 1e-3)) <= 1e-6 * rec["value"]
+    assert rec["cpu_baseline"] is None                     # rank 0 at N = 1 only
+
+
+def test_trainer_at_world_size_two_checkpoints_and_resumes(tmp_path):
+    """The drop-in trainer (`train_deep_sdf.py -e DIR`) at world size 2 on the 4-scene synthetic set (replaces nn.DataParallel,
+    train_deep_sdf.py:353): the ScenesPerBatch batch is split over the ranks, every rank owns half of the scenes.  Checked:
+    checkpoints hold the FULL latent table and the reference's 2-group optimizer state (train_deep_sdf.py:106-143); the
+    trainer's own replica check passed before every checkpoint (decoder parameters and both Adam moments bit-identical on
+    the two ranks); `-c latest` resumes at world size 2, and the SAME experiment directory then resumes in ONE process."""
+    import json
+    from deepsdf_amd import train
+    from tests.test_gpu_module_trainer import _make_experiment
+    exp = _make_experiment(str(tmp_path), 4, specs_over={"NumEpochs": 2, "SnapshotFrequency": 2, "AdditionalSnapshots": [],
+                                                         "LogFrequency": 1, "SamplesPerScene": 1024})
+    script = os.path.join(ROOT, "train_deep_sdf.py")
+
+    def check(epoch, files):
+        for sub in ("ModelParameters", "OptimizerParameters", "LatentCodes"):
+            assert sorted(os.listdir(os.path.join(exp, sub))) == files, sub
+        lc = torch.load(os.path.join(exp, "LatentCodes", "latest.pth"), weights_only=True)
+        assert lc["epoch"] == epoch and lc["latent_codes"]["weight"].shape == (4, 4)           # all four scenes, both shards
+        assert bool((lc["latent_codes"]["weight"].norm(dim=1) > 0).all())
+        o = torch.load(os.path.join(exp, "OptimizerParameters", "latest.pth"), weights_only=True)["optimizer_state_dict"]
+        assert len(o["param_groups"]) == 2 and o["param_groups"][1]["params"] == [len(o["state"]) - 1]
+        last = o["state"][len(o["state"]) - 1]
+        assert last["exp_avg"].shape == (4, 4) and bool((last["exp_avg"].abs().sum(dim=1) > 0).all())   # every row was trained
+        assert float(last["step"]) == 2.0 * epoch                                                 # 2 steps per epoch on every world size
+        mo = torch.load(os.path.join(exp, "ModelParameters", "latest.pth"), weights_only=True)
+        assert mo["epoch"] == epoch and all(k.startswith("module.") for k in mo["model_state_dict"])
+        logs = torch.load(os.path.join(exp, "Logs.pth"), weights_only=True)
+        assert logs["epoch"] == epoch and len(logs["loss"]) == 2 * epoch and all(math.isfinite(v) for v in logs["loss"])
+        return mo["model_state_dict"], logs
+
+    out = _torchrun_two_ranks([script, "-e", exp])
+    assert "training with 2 GPU(s)" in out and out.count("decoder replicas bit-identical on 2 ranks") >= 2, out[-3000:]
+    sd2, logs2 = check(2, ["2.pth", "latest.pth"])
+    specs = json.load(open(os.path.join(exp, "specs.json")))
+    specs["NumEpochs"], specs["SnapshotFrequency"] = 4, 4
+    json.dump(specs, open(os.path.join(exp, "specs.json"), "w"))
+    out = _torchrun_two_ranks([script, "-e", exp, "-c", "latest"])                # resume at world size 2
+    assert "starting from epoch 3" in out and "decoder replicas bit-identical on 2 ranks" in out, out[-3000:]
+    sd4, logs4 = check(4, ["2.pth", "4.pth", "latest.pth"])
+    assert logs4["loss"][:4] == logs2["loss"]                                     # the first run's log is kept
+    assert max(rel_err(sd4[k], sd2[k]) for k in sd2) > 0                          # and training went on
+    specs["NumEpochs"], specs["SnapshotFrequency"] = 6, 6
+    json.dump(specs, open(os.path.join(exp, "specs.json"), "w"))
+    torch.manual_seed(5)
+    train.main_function(exp, "latest", 1)                                         # the world-2 checkpoint, resumed by ONE process
+    sd6, logs6 = check(6, ["2.pth", "4.pth", "6.pth", "latest.pth"])
+    assert logs6["loss"][:8] == logs4["loss"] and max(rel_err(sd6[k], sd4[k]) for k in sd4) > 0
+    assert sum(logs6["loss"][8:]) / 4 <= 1.5 * sum(logs4["loss"][4:]) / 4         # no restart jump across the world-size change

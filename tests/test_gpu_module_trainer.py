@@ -398,3 +398,32 @@ def test_trainer_runs_a_spec_with_every_decoder_variant(tmp_path):
         y = decode_sdf(dec, lat[1:2], q)
     x = torch.cat([lat[1:2].expand(500, -1), q], 1).cpu()
     assert rel_err(dec.export_torchscript(x[:1])(x).detach(), y.cpu()) <= 1e-5
+
+
+@pytest.mark.parametrize("name", ["g11a_xyz_in_all", "g11b_latent_dropout", "g11c_layer_norm"])
+def test_decode_sdf_on_each_decoder_variant_alone(name):
+    """deep_sdf.utils.decode_sdf (deep_sdf/utils.py:54-65: what meshing and reconstruction call) in eval mode on a decoder that
+    has exactly ONE of the three layer-by-layer variants -- LayerNorm alone used to be sent to dsdf_decode_latent, which refuses
+    every variant.  The library now answers the question itself (dsdf_decode_latent_supported); these nets take the module path."""
+    from deepsdf_amd.decoder import Decoder
+    from deepsdf_amd.utils import decode_sdf
+    g = Golden(name)
+    m = g.meta
+    L = m["L"]
+    net = orc.make_net(L, **m["net_specs"])
+    params = g.group("params0")
+    dec = Decoder(L, **m["net_specs"]).cuda().eval()
+    dec.load_state_dict(params)
+    assert not dec.engine().decode_latent_supported()
+    gen = torch.Generator().manual_seed(6)
+    z = torch.randn(1, L, generator=gen) * 0.3
+    q = torch.rand(777, 3, generator=gen) * 2 - 1
+    with torch.no_grad():
+        y = decode_sdf(dec, z.cuda(), q.cuda())
+    x = torch.cat([z.expand(777, -1), q], 1)
+    yo = orc.decoder_forward(net, {k: v.double() for k, v in params.items()}, x.double(), training=False)[0]
+    assert y.shape == (777, 1) and rel_err(y.cpu(), yo) <= FWD_TOL
+    # and a plain weight-normed decoder does take the single-code entry point
+    g8 = Golden("g8_eval_6x128")
+    plain = Decoder(g8.meta["L"], **g8.meta["net_specs"]).cuda().eval()
+    assert plain.engine().decode_latent_supported()

@@ -7,11 +7,16 @@ import pytest
 import torch
 
 from oracle import deepsdf_oracle as orc
-from tests.golden_io import Golden, rel_err
+from tests.golden_io import Golden, rel_err, worst_elem
 from tests.hip_helpers import HipTrainer, spec_from_meta
 
 pytestmark = pytest.mark.gpu
 FWD_TOL, GRAD_TOL, PARAM_TOL = 1e-5, 1e-4, 1e-5
+# element-wise companions of the norm-wise bounds (worst row of y against max|y|, worst entry of a gradient tensor against that
+# tensor's max|g|): same figures as north_star's tolerances.  Post-Adam parameters: an entry whose gradient is ~Adam's eps
+# (1e-8) moves by lr * g / (|g| + eps), which turns a 1e-11 absolute gradient difference into 5e-7 of parameter -- the entry-wise
+# bound is therefore stated against the step size lr, not against max|p|: no entry may differ by more than 1 % of one Adam step.
+Y_ROW_TOL, GRAD_ELEM_TOL, PARAM_STEP_FRAC = 1e-5, 1e-4, 1e-2
 
 TRAIN_CASES = ["g1a_tiny_full", "g1b_lastnorm_tanh", "g1c_plain_clip", "g2_8x512_slice", "g3a_dropout_tiny",
                "g3b_dropout_8x512", "g4_batch_split2",
@@ -45,11 +50,13 @@ def _golden_train_case(name, gemm_split):
                     seed=m["drop_seed"], want_y=True)
         o = g.group(f"step{si}/out")
         assert rel_err(r["y"], o["y"]) <= FWD_TOL, (name, si, "y")
+        assert worst_elem(r["y"], o["y"]) <= Y_ROW_TOL, (name, si, "y worst row")
         assert abs(r["loss"] - float(o["loss"])) <= 1e-5 * abs(float(o["loss"])) + 1e-9, (name, si, "loss")
         assert rel_err(r["dlat"], g.get(f"step{si}/dlat/w")) <= GRAD_TOL, (name, si, "dlat")
         for k, ref in g.group(f"step{si}/grads").items():
             if m["grad_clip"] is None:
                 assert rel_err(r["grads"][k], ref) <= GRAD_TOL, (name, si, k)
+                assert worst_elem(r["grads"][k], ref) <= GRAD_ELEM_TOL, (name, si, k, "worst entry")
         if m["grad_clip"] is not None:
             assert abs(r["grad_norm"] - float(o["grad_norm"])) <= 1e-4 * float(o["grad_norm"])
         for k, ref in g.group(f"step{si}/grads_fro").items():
@@ -220,7 +227,8 @@ def test_full_size_step_vs_oracle():
         idx, xyz, gt = _safe_batch(net, st64, B, S, 100 + step, 0.1, 1.0, 4242)
         r64 = orc.train_step(net, st64, idx, xyz.double(), gt.double(), delta=0.1, code_bound=1.0, epoch=57, seed=4242)
         r32 = orc.train_step(net, st32, idx, xyz, gt, delta=0.1, code_bound=1.0, epoch=57, seed=4242)
-        rh = tr.step(idx, xyz, gt, delta=0.1, code_bound=1.0, code_reg=True, lam=1e-4, epoch=57, lr=(5e-4, 1e-3), seed=4242)
+        rh = tr.step(idx, xyz, gt, delta=0.1, code_bound=1.0, code_reg=True, lam=1e-4, epoch=57, lr=(5e-4, 1e-3), seed=4242,
+                     want_y=True)
         assert abs(rh["loss"] - r64["loss"]) <= 1e-5 * abs(r64["loss"])
         worst_h = max(rel_err(rh["grads"][k], r64["grads"][k]) for k in r64["grads"])
         worst_o = max(rel_err(r32["grads"][k], r64["grads"][k]) for k in r64["grads"])
@@ -232,6 +240,17 @@ def test_full_size_step_vs_oracle():
         for k in st64.params:
             assert rel_err(P[k], st64.params[k]) <= PARAM_TOL, (step, k)
         assert rel_err(tr.lat.cpu(), st64.latents) <= PARAM_TOL
+        # element-wise: worst ROW of the forward, worst ENTRY of every gradient tensor, worst entry of the post-Adam state
+        y_row = worst_elem(rh["y"], r64["y"])
+        g_el = {k: worst_elem(rh["grads"][k], r64["grads"][k]) for k in r64["grads"]}
+        g_el["latent"] = worst_elem(rh["dlat"], r64["dlat"])
+        p_el = max(float((P[k].double() - st64.params[k]).abs().max()) for k in st64.params) / 5e-4
+        print(f"step {step}: worst y row {y_row:.2e} of max|y|; worst gradient entry {max(g_el.values()):.2e} of its tensor's max "
+              f"({max(g_el, key=g_el.get)}); worst post-Adam parameter entry {p_el:.2e} of one Adam step (lr)")
+        assert y_row <= Y_ROW_TOL, step
+        for k, e in g_el.items():
+            assert e <= GRAD_ELEM_TOL, (step, k, e)
+        assert p_el <= PARAM_STEP_FRAC, step
 
 
 def test_gemm_split_full_size_step_and_decode_vs_oracle():
@@ -539,6 +558,10 @@ def test_empty_and_invalid_batches_are_rejected():
         eng.train_forward_backward(lat, dl, sc, so, xyz, gt, n_norm=0, clamp_dist=0.1, reg_coef=0.0, code_bound=None)
     with pytest.raises(_lib.DsdfError, match="empty batch"):
         eng.train_forward_backward(lat, dl, sc[:0], so[:1], xyz[:0], gt[:0], n_norm=8, clamp_dist=0.1, reg_coef=0.0, code_bound=None)
+    with pytest.raises(_lib.DsdfError, match="n_norm must be positive"):      # the one-call fast path: a rejected step ...
+        eng.train_step(lat, dl, torch.zeros_like(lat), torch.zeros_like(lat), sc, so, xyz, gt, n_norm=0, clamp_dist=0.1, reg_coef=0.0,
+                       code_bound=None, lr_decoder=5e-4, lr_latent=1e-3)
+    assert eng.step == 0                                                        # ... leaves Adam's bias-correction step alone
     with pytest.raises(ValueError, match="expected input"):
         eng.decode(torch.zeros(4, 3, device="cuda"))
     assert eng.decode(torch.zeros(0, 7, device="cuda")).shape == (0, 1)      # empty inference batch is a no-op
@@ -562,6 +585,7 @@ def test_fast_path_train_step_vs_oracle_full_size():
     tr = HipTrainer(spec, params, lat0)
     eng = tr.eng
     grads_before = eng.grads.clone()
+    batches = []
     for step in range(3):
         idx, xyz, gt = _safe_batch(net, st64, B, S, 700 + step, 0.1, 1.0, 99)
         r64 = orc.train_step(net, st64, idx, xyz.double(), gt.double(), delta=0.1, code_bound=1.0, epoch=57, seed=99)
@@ -581,6 +605,18 @@ def test_fast_path_train_step_vs_oracle_full_size():
             assert rel_err(M[k], st64.m[k]) <= GRAD_TOL, (step, k)
             assert rel_err(V[k], st64.v[k]) <= 2 * GRAD_TOL, (step, k)
         print(f"fast path step {step}: worst rel err params {worst['p']:.2e}, exp_avg {worst['m']:.2e}, exp_avg_sq {worst['v']:.2e}")
+        # element-wise: Adam's first moment IS the gradient here (exp_avg = 0.1 g after step 1), so its worst entry gets the
+        # gradient's entry-wise bound; the parameters the Adam-step bound
+        m_el = {k: worst_elem(M[k], st64.m[k]) for k in st64.params}
+        p_el = max(float((P[k].double() - st64.params[k]).abs().max()) for k in st64.params) / 5e-4
+        l_el = float((tr.lat.cpu().double() - st64.latents).abs().max()) / 1e-3
+        print(f"fast path step {step}: worst exp_avg entry {max(m_el.values()):.2e} of its tensor's max ({max(m_el, key=m_el.get)}); "
+              f"worst parameter entry {p_el:.2e}, worst code entry {l_el:.2e} of one Adam step")
+        for k, e in m_el.items():
+            assert e <= GRAD_ELEM_TOL, (step, k, e)
+        assert worst_elem(tr.lat_m.cpu(), st64.m_lat) <= GRAD_ELEM_TOL, step
+        assert p_el <= (step + 1) * PARAM_STEP_FRAC and l_el <= (step + 1) * PARAM_STEP_FRAC, step
+        batches.append((sc, so, xyz.cuda().contiguous(), gt.reshape(-1).cuda().contiguous()))
         assert rel_err(tr.lat.cpu(), st64.latents) <= PARAM_TOL, step
         assert rel_err(tr.lat_m.cpu(), st64.m_lat) <= GRAD_TOL, step
         assert rel_err(tr.lat_v.cpu(), st64.v_lat) <= 2 * GRAD_TOL, step
@@ -589,7 +625,17 @@ def test_fast_path_train_step_vs_oracle_full_size():
     x = torch.cat([st64.latents[idx].float(), xyz], 1)
     yo = orc.decoder_forward(net, st64.params, x.double(), training=False)[0].reshape(-1)
     yh = eng.decode(x.cuda()).cpu().reshape(-1)
-    assert rel_err(yh, yo) <= FWD_TOL
+    assert rel_err(yh, yo) <= FWD_TOL and worst_elem(yh, yo) <= Y_ROW_TOL
+    # the same three calls again from the same initial state: every reduction is fixed-order, so the whole optimiser state
+    # must come out BIT-identical (parameters, both moments, codes and their moments, the re-materialised packed weights)
+    tr2 = HipTrainer(spec, params, lat0)
+    for sc, so, xc, gc in batches:
+        tr2.eng.train_step(tr2.lat, tr2.dlat, tr2.lat_m, tr2.lat_v, sc, so, xc, gc, n_norm=B * S, clamp_dist=0.1,
+                           reg_coef=1e-4 * min(1, 57 / 100), code_bound=1.0, lr_decoder=5e-4, lr_latent=1e-3, seed=99, seg_len=S)
+    for name in ("params", "exp_avg", "exp_avg_sq", "packed", "loss"):
+        assert torch.equal(getattr(tr2.eng, name), getattr(eng, name)), name
+    for name in ("lat", "lat_m", "lat_v", "dlat"):
+        assert torch.equal(getattr(tr2, name), getattr(tr, name)), name
 
 
 @pytest.mark.parametrize("S", [7936, 8000])

@@ -62,6 +62,34 @@ def test_data_pipeline(tmp_path, caplog):
         cache.sample(torch.tensor([0, 1, 0]), 100, generator=g)
 
 
+def test_count_rule_matches_the_reference_loader(tmp_path):
+    """golden G12 holds what the REFERENCE's unpack_sdf_samples (deep_sdf/data.py:74-110) returned for balanced /
+    shortfall / odd / NaN-filtered scenes.  The specification of the device sampler (oracle.sample_rows), the host count
+    rule (data._balanced_counts) and the host mirror of the loader must all reproduce those counts and that order."""
+    from deepsdf_amd import data
+    from oracle import deepsdf_oracle as orc
+    from tests.golden_io import g12_scene_file
+    g12 = json.load(open(os.path.join(GOLDEN, "g12_sample_counts.json")))["cases"]
+    assert {c["id"] for c in g12} >= {"balanced", "positive_shortfall", "negative_shortfall", "odd_subsample", "nan_rows_make_a_shortfall"}
+    for c in g12:
+        assert c["positives_then_negatives"] and c["without_replacement"] and c["nan_rows_never_drawn"], c["id"]
+        vp, vn = c["n_pos"] - c["nan_pos"], c["n_neg"] - c["nan_neg"]          # rows left after remove_nans
+        assert c["rows_without_subsample"] == vp + vn
+        f = os.path.join(str(tmp_path), c["id"] + ".npz")
+        g12_scene_file(f, c)
+        torch.manual_seed(3)
+        s = data.unpack_sdf_samples(f, 3, c["subsample"])                      # the host mirror truncates like the reference
+        assert s.shape[0] == c["rows_returned"] and int((s[:, 3] > 0).sum()) == c["pos_rows"] and s.dtype == torch.float32, c["id"]
+        assert bool((s[:c["pos_rows"], 3] > 0).all()) and not torch.isnan(s).any(), c["id"]
+        if vp + vn < 2 * (c["subsample"] // 2):                                 # the reference silently returns FEWER rows
+            assert c["rows_returned"] == vp + vn                                # (its collate then fails); the device cache raises
+            continue
+        assert data._balanced_counts(vp, vn, c["subsample"]) == (c["pos_rows"], c["neg_rows"]), c["id"]
+        p, q = orc.sample_rows(vp, vn, c["subsample"], 0x5EED, 0)
+        assert (len(p), len(q)) == (c["pos_rows"], c["neg_rows"]), c["id"]
+        assert len(set(p.tolist())) == len(p) and len(set(q.tolist())) == len(q) and int(p.max()) < vp and int(q.max()) < vn
+
+
 def test_sampler_oracle_properties():
     """oracle.sample_perm / sample_rows (the specification of deepsdf_amd/csrc/sample.hpp): a bijection for every length,
     balanced counts with shortfall (deep_sdf/data.py:83-91), different draws for different keys, uniform coverage."""
