@@ -37,6 +37,15 @@ def build_library(force=False, verbose=False):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    # the one inline-asm window that keeps loads in flight across compiler-scheduled code is verified on the code object of
+    # EVERY build, lab flags included (asmcheck.py); a library that violates it is removed, not shipped
+    from . import asmcheck
+    if asmcheck.tools_available():
+        try:
+            asmcheck.check_library(LIB, expect_windows="-DDW_SPLIT_ONE_WAIT=1" not in cmd)
+        except asmcheck.AsmHazard:
+            os.remove(LIB)
+            raise
     return LIB
 
 

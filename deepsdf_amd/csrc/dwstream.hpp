@@ -170,6 +170,9 @@ __device__ __forceinline__ void dw_item(const DwLayer& L, int split, int m0, int
 // TWO 128-column panels of each operand, and stream them with direct-to-LDS loads (buffer_load_dwordx4 ... lds: no registers in flight)
 // into a ring of DWS_RING steps of 32 KB; one barrier per step publishes a step and frees the slot of the previous one.  Rows past the
 // item's last point read as zero through the buffer bounds check (row offset in the VECTOR offset).  Accumulators as in dw_item<4>.
+#ifndef DW_SPLIT_ONE_WAIT
+#define DW_SPLIT_ONE_WAIT 0     // 1: the fragment reads end in ONE wait (no loads in flight across C++ code); measured in DESIGN.md 4.3
+#endif
 constexpr int DWS_RING = 4;
 constexpr int DWS_SLOT = 2 * 16 * 256;      // floats per ring slot: A panel [16 points][256 columns], then the B panel
 
@@ -246,7 +249,11 @@ __device__ __forceinline__ void dw_block_split(const DwLayer& L, int split, int 
           "ds_read_b128 %4, %16 offset:4096\n ds_read_b128 %5, %16 offset:5120\n ds_read_b128 %6, %16 offset:6144\n ds_read_b128 %7, %16 offset:7168\n"
           "ds_read_b128 %8, %17\n ds_read_b128 %9, %17 offset:1024\n ds_read_b128 %10, %17 offset:2048\n ds_read_b128 %11, %17 offset:3072\n"
           "ds_read_b128 %12, %17 offset:4096\n ds_read_b128 %13, %17 offset:5120\n ds_read_b128 %14, %17 offset:6144\n ds_read_b128 %15, %17 offset:7168\n"
+#if DW_SPLIT_ONE_WAIT
+          "s_waitcnt lgkmcnt(0)"     // A/B switch (tools/lab_split.sh): everything has landed when the statement ends
+#else
           "s_waitcnt lgkmcnt(8)"     // the A fragments are there; the B reads stay in flight while A is cut (second wait below)
+#endif
           : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7]),
             "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(b[4]), "=&v"(b[5]), "=&v"(b[6]), "=&v"(b[7])
           : "v"(aa), "v"(ab)
@@ -260,8 +267,14 @@ __device__ __forceinline__ void dw_block_split(const DwLayer& L, int split, int 
       for (int k = 0; k < 8; ++k) x[k] = i == 0 ? a[k].x : (i == 1 ? a[k].y : (i == 2 ? a[k].z : a[k].w));
       sa[i] = split8v(x);
     }
-    // (the operands tie the B registers to this wait: nothing that reads them can be scheduled in front of it)
+#if !DW_SPLIT_ONE_WAIT
+    // (the operands tie the B registers to this wait: nothing that READS them can be scheduled in front of it.  What the operands
+    // cannot express is that b[] is not yet valid between the two statements: a copy / AGPR move / spill of a B register placed
+    // there by the register allocator would read stale data.  deepsdf_amd/asmcheck.py checks every build's code object for exactly
+    // that -- no instruction in the window names a B destination, no scratch traffic -- and deepsdf_amd/build.py refuses the
+    // library otherwise; -DDW_SPLIT_ONE_WAIT=1 is the variant without a window.)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float x[8];

@@ -181,3 +181,27 @@ def test_warm_own_code_bound_is_inside_the_text_section(tmp_path):
         addr, size = funcs[k]
         assert addr + size <= mk, (k, hex(addr + size), hex(mk))
     shutil.rmtree(str(tmp_path), ignore_errors=True)
+
+
+def test_split_wait_window_of_the_dw_split_kernel_is_clean():
+    """dwstream.hpp dw_block_split keeps eight ds_read_b128 in flight across compiler-scheduled code (asm statement 1 ends in
+    lgkmcnt(8), statement 2 is the lgkmcnt(0)).  Correct only if nothing in between touches their destination registers -- a
+    register-allocation outcome, so it is checked on the gfx950 code object of the library that was just built (the build does the
+    same and refuses a violating library), and the checker itself is checked on hand-made instruction streams."""
+    from deepsdf_amd import asmcheck
+    from deepsdf_amd.build import LIB
+    reads = [("ds_read_b128", f"v[{16 + 4 * k}:{19 + 4 * k}], v1 offset:{1024 * k}") for k in range(16)]
+    body = [("v_and_b32_e32", "v0, 0xffff0000, v16"), ("v_sub_f32_e32", "v1, v16, v0"), ("v_perm_b32", "v2, v20, v24, s5")]
+    close = [("s_waitcnt", "lgkmcnt(0)")]
+    ok = reads + [("s_waitcnt", "lgkmcnt(8)")] + body + close + [("v_mov_b32_e32", "v3, v48")]
+    assert asmcheck.check_split_wait_windows(ok) == 1                     # reads of A registers (v16..v47) are fine; B = v48..v79
+    for bad in (("v_mov_b32_e32", "v3, v50"), ("v_accvgpr_write_b32", "a7, v79"), ("v_pk_mul_f32", "v[4:5], v[78:79], v[8:9]"),
+                ("scratch_store_dwordx4", "off, v[4:7], off offset:16"), ("v_mov_b32_e32", "v48, v3")):
+        with pytest.raises(asmcheck.AsmHazard):
+            asmcheck.check_split_wait_windows(reads + [("s_waitcnt", "lgkmcnt(8)")] + body + [bad] + close)
+    with pytest.raises(asmcheck.AsmHazard):                                # a window that is never closed
+        asmcheck.check_split_wait_windows(reads + [("s_waitcnt", "lgkmcnt(8)")] + body)
+    assert asmcheck.vgprs("a[0:15], v[4:7], v9, s[0:3], 0xff, v12 offset:16") == {4, 5, 6, 7, 9, 12}
+    if not asmcheck.tools_available() or not os.path.exists(LIB):
+        pytest.skip("ROCm LLVM tools or the built library are not available")
+    assert asmcheck.check_library(LIB) >= 1

@@ -769,3 +769,44 @@ def test_fast_path_with_a_512_scene_table_vs_oracle():
     P = tr.params()
     for k in st64.params:
         assert rel_err(P[k], st64.params[k]) <= PARAM_TOL, k
+
+
+@pytest.mark.parametrize("L", [2, 16])
+def test_shipped_experiment_shapes_vs_oracle(L):
+    """The shapes the reference actually SHIPS for its 8 x 512 experiments: CodeLength 2 (experiments/double_lattice_3D/specs.json:9-38,
+    snappy_and_cylinders) and 16 (simple_geom/specs.json:20, snappy3D, corner_spheres_only), SamplesPerScene 16000, latent_in [4]:
+    the skip layer is 507 / 493 wide and x0 has 5 / 19 columns (the headline's L = 256 makes them 253 / 259).  Two optimiser steps
+    of 2 scenes x 16000 points against the float64 oracle on margin-safe batches, through all four product paths: segment mode
+    (16000 = 250 workgroups per scene) and the general (ragged) path, fp32 MFMA and gemm_split -- the headline's tolerances,
+    norm-wise and element-wise."""
+    B, S = 2, 16000
+    net = orc.make_net(L, **BIG)
+    params = orc.init_params(net, 200 + L)
+    lat0 = torch.randn(B, L, generator=torch.Generator().manual_seed(201 + L)) / math.sqrt(L)
+    lat0[1] *= 1.3 / lat0[1].norm()                          # above CodeBound: the renorm fires
+    st64 = orc.TrainState.create({k: v.double() for k, v in params.items()}, lat0.double())
+    assert net.layers[3].out_dim == 512 - (L + 3) and net.layers[0].in_dim == L + 3
+    paths = {(ragged, split): HipTrainer(spec_from_meta(dict(L=L, net_specs=dict(BIG, gemm_split=split))), params, lat0)
+             for ragged in (False, True) for split in (False, True)}
+    for step in range(2):
+        idx, xyz, gt = _safe_batch(net, st64, B, S, 1200 + 10 * L + step, 0.1, 1.0, 31)
+        r64 = orc.train_step(net, st64, idx, xyz.double(), gt.double(), delta=0.1, code_bound=1.0, epoch=57, seed=31)
+        for (ragged, split), tr in paths.items():
+            tag = (L, step, "ragged" if ragged else "segments", "gemm_split" if split else "fp32mfma")
+            rh = tr.step(idx, xyz, gt, delta=0.1, code_bound=1.0, code_reg=True, lam=1e-4, epoch=57, lr=(5e-4, 1e-3), seed=31,
+                         want_y=True, **(dict(force_ragged=True) if ragged else {}))
+            assert abs(rh["loss"] - r64["loss"]) <= 1e-5 * abs(r64["loss"]), tag
+            assert rel_err(rh["y"], r64["y"]) <= FWD_TOL and worst_elem(rh["y"], r64["y"]) <= Y_ROW_TOL, tag
+            g_rel = {k: rel_err(rh["grads"][k], r64["grads"][k]) for k in r64["grads"]}
+            g_el = {k: worst_elem(rh["grads"][k], r64["grads"][k]) for k in r64["grads"]}
+            P = tr.params()
+            p_rel = max(rel_err(P[k], st64.params[k]) for k in st64.params)
+            p_el = max(float((P[k].double() - st64.params[k]).abs().max()) for k in st64.params) / 5e-4
+            print(f"{tag}: gradients rel {max(g_rel.values()):.2e} / worst entry {max(g_el.values()):.2e} ({max(g_el, key=g_el.get)}); "
+                  f"y worst row {worst_elem(rh['y'], r64['y']):.2e}; params rel {p_rel:.2e} / worst entry {p_el:.2e} of an Adam step; "
+                  f"codes rel {rel_err(tr.lat.cpu(), st64.latents):.2e}")
+            for k in r64["grads"]:
+                assert g_rel[k] <= GRAD_TOL and g_el[k] <= GRAD_ELEM_TOL, (tag, k, g_rel[k], g_el[k])
+            assert rel_err(rh["dlat"], r64["dlat"]) <= GRAD_TOL and worst_elem(rh["dlat"], r64["dlat"]) <= GRAD_ELEM_TOL, tag
+            assert p_rel <= PARAM_TOL and p_el <= (step + 1) * PARAM_STEP_FRAC, tag
+            assert rel_err(tr.lat.cpu(), st64.latents) <= PARAM_TOL, tag
