@@ -312,7 +312,7 @@ def main():
         sfused = FusedTrainStep(seng, slat, clamp_dist=0.1, code_reg=True, code_reg_lambda=1e-4, code_bound=1.0, grad_clip=None, seed=3)
         sstep = lambda i: sfused(batches[i % len(batches)]["scenes"], S, batches[i % len(batches)]["xyz"], batches[i % len(batches)]["gt"],  # noqa: E731
                                  1, 5e-4, 1e-3, batch_split=1, n_norm=n_global)
-        for i in range(20):
+        for i in range(INIT_STEPS + args.warmup):     # its kernels are new to the process: the same initialisation as the headline's
             sstep(i)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -320,7 +320,14 @@ def main():
             sstep(i)
         torch.cuda.synchronize()
         sms = 1e3 * (time.perf_counter() - t1) / n_it
-        split_extra = dict(ms_per_step=sms, value=n_local / (sms * 1e-3),
+        sev = [torch.cuda.Event(enable_timing=True) for _ in range(n_it + 1)]
+        sev[0].record()
+        for i in range(n_it):
+            sstep(i)
+            sev[i + 1].record()
+        torch.cuda.synchronize()
+        sts = sorted(sev[i].elapsed_time(sev[i + 1]) for i in range(n_it))
+        split_extra = dict(ms_per_step=sms, value=n_local / (sms * 1e-3), steps=n_it, step_time_ms_median=sts[n_it // 2],
                            note="NOT the headline: the same workload with NetworkSpecs gemm_split = true (the fused kernels' hidden GEMMs as 6 "
                                 "bf16 MFMAs on 3-way split fp32 operands, fp32 accumulate; same parity tolerances) -- `bench.py --config f32split` "
                                 "is the full line")

@@ -109,3 +109,96 @@ def check_library(lib, expect_windows=True):
 if __name__ == "__main__":
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdsdf_hip.so")
     print(f"{KERNEL}: {check_library(lib, expect_windows='--allow-none' not in sys.argv)} split-wait window(s) clean")
+
+
+# ---- second audit: MFMA source registers overwritten by a later load (fused_bf16x8.hpp, two waves per SIMD) -----------------
+# Measured on MI355X (profiles/r02_lab_bf16x8_race.log): with two waves per SIMD, a ds_read / buffer_load that the register
+# allocator gave the registers an MFMA issued JUST BEFORE it reads as srcA / srcB produced run-to-run differences in 3 % of the
+# rows.  The k-loop was rewritten so that a step's loads only replace what the PREVIOUS step consumed and are issued after the
+# step's own MFMAs.  That is a property of the emitted code, so it is measured on the code object: for every load with a VGPR
+# destination, the number of OTHER MFMAs issued between the last MFMA that reads one of those registers as srcA / srcB and the
+# load, over every path (loop back-edges included).
+def disassemble_with_addresses(co, name_part):
+    syms = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "-sW", co], capture_output=True, text=True, check=True).stdout
+    names = sorted({f.split()[7] for f in syms.splitlines() if len(f.split()) >= 8 and f.split()[3] == "FUNC" and name_part in f.split()[7]})
+    if len(names) != 1:
+        raise AsmHazard(f"expected exactly one function matching {name_part!r} in the code object, found {names}")
+    out = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", f"--disassemble-symbols={names[0]}", co],
+                         capture_output=True, text=True, check=True).stdout
+    base, ins = None, []
+    for line in out.splitlines():
+        m = re.match(r"^([0-9a-f]+) <", line)
+        if m and base is None:
+            base = int(m.group(1), 16)
+        m = re.match(r"^\s+([a-z_0-9]+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):(.*)$", line)
+        if m:
+            tgt = re.search(r"<[^>]*\+0x([0-9a-f]+)>", m.group(4))
+            ins.append(dict(op=m.group(1), args=m.group(2), addr=int(m.group(3), 16),
+                            target=(base + int(tgt.group(1), 16)) if tgt and base is not None else None))
+    return ins
+
+
+def mfma_src_reuse_distances(ins, limit=12, fall_through_only=False):
+    """{load index: MFMAs issued strictly between the last MFMA reading one of the load's destination VGPRs as srcA/srcB and
+    the load} for every ds_read* / buffer_load* / global_load* with a VGPR destination that has such a reader within `limit`
+    MFMAs on some path.  Paths follow fall-through and branch edges backwards (loop back-edges included);
+    fall_through_only: fall-through edges alone (every conditional branch not taken) -- paths that exist whatever the branch
+    conditions are, where the full set also contains paths the program's own guards exclude."""
+    by_addr = {x["addr"]: i for i, x in enumerate(ins)}
+    preds = [[] for _ in ins]
+    for i, x in enumerate(ins):
+        uncond = x["op"] in ("s_branch", "s_endpgm", "s_setpc_b64")
+        if i + 1 < len(ins) and not uncond:
+            preds[i + 1].append(i)
+        if not fall_through_only and x["op"].startswith(("s_branch", "s_cbranch")) and x["target"] in by_addr:
+            preds[by_addr[x["target"]]].append(i)
+    src_ab, acc_regs = {}, set()
+    for i, x in enumerate(ins):
+        if x["op"].startswith("v_mfma"):
+            ops = [o.strip() for o in x["args"].split(",")]
+            src_ab[i] = vgprs(ops[1]) | vgprs(ops[2])
+            acc_regs |= vgprs(ops[0])
+    out = {}
+    for i, x in enumerate(ins):
+        if not x["op"].startswith(("ds_read", "buffer_load", "global_load")) or " lds" in (" " + x["args"]):
+            continue
+        dest = vgprs(x["args"].split(",")[0])
+        if not dest:
+            continue
+        best, seen, stack = None, set(), [(p, 0) for p in preds[i]]
+        while stack:
+            j, n = stack.pop()
+            if (j, n) in seen or n > limit:
+                continue
+            seen.add((j, n))
+            if j in src_ab:
+                if src_ab[j] & dest:
+                    best = n if best is None else min(best, n)
+                    continue
+                n += 1
+            elif ins[j]["op"].startswith("v_") and vgprs(",".join(ins[j]["args"].split(",")[1:])) & acc_regs:
+                continue          # a VALU instruction READING an MFMA result (epilogue arithmetic, bf8_drain's v_readfirstlane): it
+                                  # completes only after the MFMA that writes the register, and the matrix pipe is in-order
+            elif vgprs(ins[j]["args"].split(",")[0]) & dest and not ins[j]["op"].startswith(("v_cmp", "s_", "ds_write", "buffer_store", "global_store")):
+                continue          # an earlier WRITER of the same register on this path: what it overwrote is no longer the MFMA's operand
+            stack.extend((p, n) for p in preds[j])
+        if best is not None:
+            out[i] = best
+    return out
+
+
+def check_mfma_src_reuse(lib, kernel="fused_forward_bf16x8_kernel", min_distance=1):
+    """Raises AsmHazard if, on a fall-through path, some load in `kernel` overwrites srcA/srcB registers of an MFMA with fewer than
+    `min_distance` other MFMAs issued in between (the signature of the first 8-wave k-loop: 46 such loads; the rewritten loop: none);
+    returns (smallest distance found, number of load/MFMA pairs looked at)."""
+    with tempfile.TemporaryDirectory(prefix="dsdf_asmcheck_") as d:
+        ins = disassemble_with_addresses(extract_code_object(lib, d), kernel)
+    dist = mfma_src_reuse_distances(ins, fall_through_only=True)
+    if not dist:
+        return None, 0
+    worst = min(dist.values())
+    if worst < min_distance:
+        bad = [f"{ins[i]['op']} {ins[i]['args']} @ {ins[i]['addr']:#x} (distance {n})" for i, n in dist.items() if n < min_distance]
+        raise AsmHazard(f"{kernel}: {len(bad)} load(s) overwrite MFMA source registers after fewer than {min_distance} other MFMAs: "
+                        + "; ".join(bad[:4]))
+    return worst, len(dist)

@@ -43,6 +43,7 @@ def build_library(force=False, verbose=False):
     if asmcheck.tools_available():
         try:
             asmcheck.check_library(LIB, expect_windows="-DDW_SPLIT_ONE_WAIT=1" not in cmd)
+            asmcheck.check_mfma_src_reuse(LIB, min_distance=2)      # fused_bf16x8.hpp: a step is >= 2 MFMAs (one n-tile per wave)
         except asmcheck.AsmHazard:
             os.remove(LIB)
             raise

@@ -65,12 +65,30 @@ __device__ __forceinline__ Bf8View bf8_view(const __bf16* wfb, int ntiles, int t
 // runs the same pattern bit-reproducibly), but here 3 % of the rows came out different from run to run, always rows 48-63 of a
 // workgroup (the late columns of the LAST MFMA of a group).  So a step's loads are issued AFTER its MFMAs, they only ever replace
 // what the step BEFORE consumed, and the fragments the step itself consumed are kept live (empty asm) until those loads are out:
-// the allocator cannot hand their registers to a load before a full step (4 MFMAs, >= 128 cycles) has passed.
+// the allocator cannot hand their registers to a load before a full step (2 NT MFMAs) has passed.
+// Code-object evidence (tools/lab/mfma_reuse_audit.py = deepsdf_amd/asmcheck.py mfma_src_reuse_distances, on the rebuilt first version
+// 5f67ff3 and on this one): v1 has 24 ds_read_b128 and 22 buffer_load_dwordx4 whose destination is srcA / srcB of the MFMA issued
+// straight in front of them (no other MFMA, no branch in between); this version has none.  What it still has are the GUARDED steps
+// (bubbles at the phase boundary, items past the end): their MFMAs are skipped but their loadB is not, so a dropped (out-of-range,
+// i.e. immediately returning) load lands in the ring slot the LAST real step's MFMAs read with no MFMA in between.  Those steps
+// do not issue loads that would be dropped anyway, and first read the last accumulator on the VALU (bf8_drain: the read completes
+// only when the MFMA that writes it has finished, and an MFMA that has finished has read its sources) -- what is left in them are
+// real weight loads of the next phase (a full L2 round trip behind an MFMA that is already done).  asmcheck.check_mfma_src_reuse
+// enforces the first property on every build: on no straight-line path may a load overwrite srcA / srcB of an MFMA with fewer than
+// one other MFMA in between.
 template <int NT>
 __device__ __forceinline__ void bf8_keep(const bf16x8 (&a)[2], const bf16x8 (&b)[2]) {
   asm volatile("" ::"v"(a[0]), "v"(a[1]));
 #pragma unroll
   for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(b[j]));
+}
+// A compiler-emitted VALU read (v_readfirstlane) of the accumulator the step's LAST MFMA writes: the compiler pads the MFMA-result ->
+// VALU-read hazard itself (an inline-asm v_mov would not be padded), so the read completes only when that MFMA -- and, the matrix pipe
+// being in-order, every MFMA before it -- is done.
+template <int NT>
+__device__ __forceinline__ void bf8_drain(const f32x16 (&acc)[2][2]) {
+  const int done = __builtin_amdgcn_readfirstlane(__float_as_int(acc[1][NT - 1][15]));
+  asm volatile("" ::"s"(done));
 }
 // One pass over ALL k-units of a layer: first those of phase `first`, then the others.  (No per-workgroup rotation of the unit order
 // as in the fp32 kernel: the two sets are half a layer apart anyway, and the cursor arithmetic it needs costs more scalar
@@ -94,14 +112,19 @@ __device__ __forceinline__ void bf8_kloop(f32x16 (&acc)[2][2], const __bf16* ap,
   int bn = 0, ak = 0;
   const int base0 = first * BF8_HALF, base1 = (1 - first) * BF8_HALF - c0;
   auto slot_of = [&](int k) __attribute__((always_inline)) { return k + (k >= c0 ? base1 : base0); };   // k-th unit of the sequence (0 .. T-1)
-  auto loadB = [&](bf16x8 (&dst)[2]) __attribute__((always_inline)) {   // item bn: a unit, a bubble, or past the end (the last two: dropped)
+  // item bn: a unit, a bubble, or past the end.  The last two load nothing: in the steady-state steps as a DROPPED load (vector offset
+  // out of range -- no branch in the loop body; it returns at once, which is harmless there because the step's own MFMAs sit between
+  // the MFMAs that read the slot and this write); in the guarded steps (skipc), whose own MFMAs may be missing, not issued at all.
+  auto loadB = [&](bf16x8 (&dst)[2], auto skipc) __attribute__((always_inline)) {
     const bool real = (bn < c0 || bn >= P) && bn < N;
     const int sl = slot_of(bn < c0 ? bn : bn - P + c0);
     const int vo = real ? B.voff : (int)0xFFFFFF00u;    // past num_records by any reading of the range check
+    if (!decltype(skipc)::value || real) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(B.rsrc, vo, (B.tb[j] + sl) << 10, 0);
-      dst[j] = __builtin_bit_cast(bf16x8, r);
+      for (int j = 0; j < NT; ++j) {
+        const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(B.rsrc, vo, (B.tb[j] + sl) << 10, 0);
+        dst[j] = __builtin_bit_cast(bf16x8, r);
+      }
     }
     ++bn;
   };
@@ -123,9 +146,10 @@ __device__ __forceinline__ void bf8_kloop(f32x16 (&acc)[2][2], const __bf16* ap,
     constexpr int q = decltype(qc)::value;
     constexpr bool GUARD = decltype(guardc)::value;
     if (!GUARD || n < lim_mma) mma(a[q % 3], ring[q]);
-    __builtin_amdgcn_sched_barrier(0);
+    else bf8_drain<NT>(acc);                                   // no MFMA in this step: the last real step's MFMAs have read their
+    __builtin_amdgcn_sched_barrier(0);                         // sources before this step's loads overwrite them
     if (!GUARD || n + 2 < lim_pre) readA(a[(q + 2) % 3]);      // rows of item n+2 -> the buffer step n-1 consumed
-    loadB(ring[(q + R - 1) % R]);                              // weights of item n+R-1 -> the slot step n-1 consumed
+    loadB(ring[(q + R - 1) % R], guardc);                      // weights of item n+R-1 -> the slot step n-1 consumed
     __builtin_amdgcn_sched_barrier(0);
     bf8_keep<NT>(a[q % 3], ring[q]);
     __builtin_amdgcn_sched_barrier(0);
@@ -135,7 +159,7 @@ __device__ __forceinline__ void bf8_kloop(f32x16 (&acc)[2][2], const __bf16* ap,
                    [&](auto qc) __attribute__((always_inline)) { step(s + decltype(qc)::value, qc, guardc, lim_mma, lim_pre); });
   };
 #pragma unroll
-  for (int q = 0; q < R - 1; ++q) loadB(ring[q]);
+  for (int q = 0; q < R - 1; ++q) loadB(ring[q], std::false_type{});
   int s = 0;
   if (BAR) {
     if (0 < c0) readA(a[0]);
@@ -153,11 +177,10 @@ __device__ __forceinline__ void bf8_kloop(f32x16 (&acc)[2][2], const __bf16* ap,
   if (s < N) chunk(s, std::true_type{}, N, N + 2);   // tail (reading ahead past the end is harmless)
   // leaving: whatever comes next (the epilogue's table reads) loads into fresh registers at once -- wait until the LAST MFMA has
   // written back (a VALU read of its result), only then let go of the fragment registers
-  float done;
-  asm volatile("v_mov_b32 %0, %1" : "=v"(done) : "v"(acc[1][NT - 1][15]));
+  const int done = __builtin_amdgcn_readfirstlane(__float_as_int(acc[1][NT - 1][15]));   // (compiler-emitted: it pads the MFMA -> VALU hazard)
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int q = 0; q < 3; ++q) asm volatile("" ::"v"(a[q][0]), "v"(a[q][1]), "v"(done));
+  for (int q = 0; q < 3; ++q) asm volatile("" ::"v"(a[q][0]), "v"(a[q][1]), "s"(done));
 #pragma unroll
   for (int q = 0; q < R; ++q)
 #pragma unroll

@@ -205,3 +205,28 @@ def test_split_wait_window_of_the_dw_split_kernel_is_clean():
     if not asmcheck.tools_available() or not os.path.exists(LIB):
         pytest.skip("ROCm LLVM tools or the built library are not available")
     assert asmcheck.check_library(LIB) >= 1
+
+
+def test_bf16x8_kloop_never_reloads_the_sources_of_the_mfma_in_front():
+    """fused_bf16x8.hpp runs two waves per SIMD; its first k-loop let the register allocator hand a ds_read / buffer_load the registers
+    the MFMA straight in front of it reads as srcA / srcB, and 3 % of the rows differed from run to run (profiles/r02_lab_bf16x8_race.log;
+    on the code object of that version, rebuilt from commit 5f67ff3: 24 + 22 such loads, profiles/r03_bf16x8_reuse_audit.log).  The
+    rewritten loop keeps a full step of MFMAs between an MFMA and any load into its source registers -- a property of the EMITTED code,
+    so it is measured there (the build does the same and refuses a library that violates it); the measure itself is checked on
+    hand-made streams."""
+    from deepsdf_amd import asmcheck
+    from deepsdf_amd.build import LIB
+    mk = lambda op, args, addr, target=None: dict(op=op, args=args, addr=addr, target=target)   # noqa: E731
+    mf = lambda a, acc, sa, sb: mk("v_mfma_f32_32x32x16_bf16", f"v[{acc}:{acc + 15}], v[{sa}:{sa + 3}], v[{sb}:{sb + 3}], v[{acc}:{acc + 15}]", a)   # noqa: E731
+    bad = [mf(0, 0, 100, 104), mk("ds_read_b128", "v[104:107], v9", 8)]                                     # reload right behind the reader
+    assert asmcheck.mfma_src_reuse_distances(bad) == {1: 0}
+    good = [mf(0, 0, 100, 104), mf(8, 16, 108, 112), mf(16, 32, 116, 120), mk("buffer_load_dwordx4", "v[100:103], v9, s[8:11], s2 offen", 24)]
+    assert asmcheck.mfma_src_reuse_distances(good) == {3: 2}
+    drained = [mf(0, 0, 100, 104), mk("v_readfirstlane_b32", "s3, v15", 8), mk("ds_read_b128", "v[104:107], v9", 16)]   # a VALU read of the result
+    assert asmcheck.mfma_src_reuse_distances(drained) == {}
+    loop = [mk("ds_read_b128", "v[104:107], v9", 0), mf(8, 0, 100, 104), mk("s_cbranch_scc1", "65533", 16, target=0)]  # across the back-edge
+    assert asmcheck.mfma_src_reuse_distances(loop) == {0: 0} and asmcheck.mfma_src_reuse_distances(loop, fall_through_only=True) == {}
+    if not asmcheck.tools_available() or not os.path.exists(LIB):
+        pytest.skip("ROCm LLVM tools or the built library are not available")
+    worst, pairs = asmcheck.check_mfma_src_reuse(LIB, min_distance=2)
+    assert worst is not None and worst >= 2 and pairs > 20

@@ -15,8 +15,11 @@ FWD_TOL, GRAD_TOL, PARAM_TOL = 1e-5, 1e-4, 1e-5
 # element-wise companions of the norm-wise bounds (worst row of y against max|y|, worst entry of a gradient tensor against that
 # tensor's max|g|): same figures as north_star's tolerances.  Post-Adam parameters: an entry whose gradient is ~Adam's eps
 # (1e-8) moves by lr * g / (|g| + eps), which turns a 1e-11 absolute gradient difference into 5e-7 of parameter -- the entry-wise
-# bound is therefore stated against the step size lr, not against max|p|: no entry may differ by more than 1 % of one Adam step.
-Y_ROW_TOL, GRAD_ELEM_TOL, PARAM_STEP_FRAC = 1e-5, 1e-4, 1e-2
+# bound is therefore stated against the step size lr, not against max|p|: no entry may differ by more than 0.2 % of one Adam step
+# per step taken (measured on MI355X, profiles/r03_worst_element.log: y rows 2e-7, gradient entries 5e-6, parameter entries 8e-4 of a
+# step).  gemm_split's gradient entries are 7e-6 of their tensor's max instead of 8e-7 (its dropped cross terms scale with the sum of
+# |products|, not with the partial sums), which the eps-sized Adam entries turn into 9e-3 of a step: its own bound, 2 %.
+Y_ROW_TOL, GRAD_ELEM_TOL, PARAM_STEP_FRAC, PARAM_STEP_FRAC_SPLIT = 1e-5, 1e-4, 2e-3, 2e-2
 
 TRAIN_CASES = ["g1a_tiny_full", "g1b_lastnorm_tanh", "g1c_plain_clip", "g2_8x512_slice", "g3a_dropout_tiny",
                "g3b_dropout_8x512", "g4_batch_split2",
@@ -155,6 +158,49 @@ def test_bf16_forward_is_bit_reproducible_and_has_no_outlier_rows():
         worst = float((runs[0] - yo).abs().max() / yo.abs().max())
         print(f"{name}: worst row {worst:.2e} of the output range")
         assert worst <= 3e-3, (name, worst)
+
+
+BF16X8_NETS = {
+    # every wave of the 8-wave kernel holds ONE n-tile in every layer (8 tiles of 32 columns): a k-loop step is 2 MFMAs, the shortest
+    # distance between an MFMA and a load into its source registers the kernel ever runs with
+    "4x256_one_tile_per_wave": dict(L=29, net=dict(dims=[256] * 4, dropout=[0, 1, 2, 3], dropout_prob=0.2, norm_layers=[0, 1, 2, 3],
+                                                   latent_in=[2], weight_norm=True, geom_dimension=3)),
+    # ragged widths, one tile per wave: layers whose last k-unit / last n-tile are partial, waves without a tile in some layers
+    "ragged_narrow": dict(L=11, net=dict(dims=[200, 72, 136, 250], dropout=[], dropout_prob=0.0, norm_layers=[0, 1, 2, 3], latent_in=[3],
+                                         weight_norm=True, geom_dimension=3)),
+    # ragged widths mixing waves with two tiles and waves with one
+    "ragged_wide": dict(L=40, net=dict(dims=[500, 300, 420, 512, 270], dropout=[0, 2], dropout_prob=0.2, norm_layers=[0, 1, 2, 3, 4],
+                                       latent_in=[2], weight_norm=True, geom_dimension=3)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(BF16X8_NETS))
+def test_bf16_8wave_forward_reproducible_on_short_steps_and_ragged_widths(name):
+    """The determinism / outlier pin of the 8-wave bf16 forward on the shapes the g8 net does not have: nets whose waves hold ONE n-tile
+    (a k-loop step of 2 MFMAs instead of 4 -- half the distance between an MFMA and the loads that reuse its source registers) and
+    ragged widths (partial last k-units and n-tiles, guarded tail steps, waves with no tile).  4 runs x 2 entry points, bit-identical,
+    and no row further from the oracle's bf16 emulation than rounding flips explain."""
+    from deepsdf_amd.engine import Engine
+    c = BF16X8_NETS[name]
+    L = c["L"]
+    netb = orc.make_net(L, forward_bf16=True, **c["net"])
+    params = orc.init_params(orc.make_net(L, **c["net"]), 123)
+    engb = Engine(spec_from_meta(dict(L=L, net_specs=dict(c["net"], forward_bf16=True))))
+    engb.load_params(params)
+    gen = torch.Generator().manual_seed(12)
+    z = torch.randn(L, generator=gen) / math.sqrt(L)
+    n = 40003
+    xyz = torch.rand(n, 3, generator=gen) * 2 - 1
+    x = torch.cat([z.expand(n, -1), xyz], 1)
+    yo = orc.decoder_forward(netb, params, x, training=False)[0].reshape(-1)
+    zc, qc, xc = z.cuda(), xyz.cuda(), x.cuda()
+    for entry, fn in (("decode_latent", lambda: engb.decode_latent(zc, qc)), ("decode", lambda: engb.decode(xc))):
+        runs = [fn().cpu().reshape(-1).clone() for _ in range(4)]
+        for k in range(1, 4):
+            assert torch.equal(runs[k], runs[0]), (name, entry, k, int((runs[k] != runs[0]).sum()))
+        worst = float((runs[0] - yo).abs().max() / yo.abs().max())
+        print(f"{name} {entry}: worst row {worst:.2e} of the output range, rel err {rel_err(runs[0], yo):.2e}")
+        assert worst <= 3e-3 and rel_err(runs[0], yo) <= 2e-4, (name, entry, worst)
 
 
 def test_real_weights_known_answer():
@@ -808,5 +854,5 @@ def test_shipped_experiment_shapes_vs_oracle(L):
             for k in r64["grads"]:
                 assert g_rel[k] <= GRAD_TOL and g_el[k] <= GRAD_ELEM_TOL, (tag, k, g_rel[k], g_el[k])
             assert rel_err(rh["dlat"], r64["dlat"]) <= GRAD_TOL and worst_elem(rh["dlat"], r64["dlat"]) <= GRAD_ELEM_TOL, tag
-            assert p_rel <= PARAM_TOL and p_el <= (step + 1) * PARAM_STEP_FRAC, tag
+            assert p_rel <= PARAM_TOL and p_el <= (step + 1) * (PARAM_STEP_FRAC_SPLIT if split else PARAM_STEP_FRAC), tag
             assert rel_err(tr.lat.cpu(), st64.latents) <= PARAM_TOL, tag
