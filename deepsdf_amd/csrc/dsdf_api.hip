@@ -229,13 +229,15 @@ int dw_cols(const DsdfNet* n, int l, bool segmode) {
   if (l == 0) return 0;
   return l == skip_layer(n) ? n->out_dim[l - 1] : n->in_dim[l];
 }
-DwSched dw_schedule(const DsdfNet* n, int64_t N, const int* ld_in, bool segmode) {
+// Layers [l0, l1) only (the others get no items): the two-phase backward of a data-parallel step (DsdfLossCfg.dw_phase) schedules
+// each half of the layers so that it fills the chip by itself.
+DwSched dw_schedule(const DsdfNet* n, int64_t N, const int* ld_in, bool segmode, int l0 = 0, int l1 = DSDF_MAX_LAYERS) {
   DwSched S;
   memset(&S, 0, sizeof(S));
   const int nh = n->n_layers - 1;
   int Tfull = 0;
   for (int l = 0; l < nh; ++l) {
-    const int nc = dw_cols(n, l, segmode);
+    const int nc = (l >= l0 && l < l1) ? dw_cols(n, l, segmode) : 0;
     S.slab[l] = rup((int64_t)n->out_dim[l] * ld_in[l], 64);
     if (nc == 0) { S.last_nj[l] = 4; continue; }   // no items
     S.tiles_m[l] = (n->out_dim[l] + 127) / 128;
@@ -262,6 +264,10 @@ DwSched dw_schedule(const DsdfNet* n, int64_t N, const int* ld_in, bool segmode)
   return S;
 }
 
+// Two-bucket gradient exchange (data parallel): the decoder's layers [k, last] finish first (bucket 0), [0, k) second (bucket 1);
+// k splits the hidden layers in the middle -- for the 8 x 512 net 1.05 M / 0.79 M parameters.
+int dw_bucket_layer(const DsdfNet* n) { return n->n_layers / 2; }
+
 // ---- workspace plan -----------------------------------------------------------------------------
 struct Plan {
   int nl, W0, N, R;
@@ -276,6 +282,8 @@ struct Plan {
   size_t dpl_off[DSDF_MAX_LAYERS], mask_off[DSDF_MAX_LAYERS], cs_off[DSDF_MAX_LAYERS], dwslab_off[DSDF_MAX_LAYERS];
   int nwg;
   DwSched dw;
+  DwSched dwph[2];   // two-phase backward: the schedule of the late layers [dw_k, last) and of the early layers [0, dw_k)
+  int dw_k;          // first layer of the late half (dw_bucket_layer)
   // segment mode: U[R][2][ldu] of the hoisted layers, per-workgroup xyz sums [nwg][4][ldcs] for each of them
   int segmode, ldu, ldh;
   long long hstride;
@@ -358,7 +366,15 @@ Plan make_plan(const DsdfNet* n, int64_t N, int64_t R, bool inference, bool segm
     P.cs_off[l] = take((size_t)P.nwg * P.ldcs * 4);
   }
   P.dw = dw_schedule(n, N, P.ld_in, segmode);
-  for (int l = 0; l < P.nl - 1; ++l) P.dwslab_off[l] = take((size_t)P.dw.nsplit[l] * P.dw.slab[l] * 4);
+  P.dw_k = dw_bucket_layer(n);
+  P.dwph[0] = dw_schedule(n, N, P.ld_in, segmode, P.dw_k, P.nl - 1);
+  P.dwph[1] = dw_schedule(n, N, P.ld_in, segmode, 0, P.dw_k);
+  for (int l = 0; l < P.nl - 1; ++l) {   // slabs sized for whichever schedule splits K finest: the layout does not depend on the phase
+    int ns = P.dw.nsplit[l];
+    for (int t = 0; t < 2; ++t)
+      if (P.dwph[t].nsplit[l] > ns) ns = P.dwph[t].nsplit[l];
+    P.dwslab_off[l] = take((size_t)ns * P.dw.slab[l] * 4);
+  }
   P.segmode = segmode ? 1 : 0;
   if (segmode) {
     P.ldu = P.ldcs;
@@ -809,7 +825,10 @@ struct SegBwd { const FusedSeg* seg; const int64_t* seg_scene; const float* tabl
 int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float* packed, const float* params, int64_t n,
                        int training, float* grads, int accumulate, int ncols_dz, bool* used_dzB, hipStream_t st,
                        bool want_dw, const FusedBwdHead& head, const FuseAdam* fz = nullptr, const SegBwd* sb = nullptr,
-                       const FusedFwdArgs* fwd = nullptr) {   // fwd: the deferred forward of the same points -> one launch for both
+                       const FusedFwdArgs* fwd = nullptr,     // fwd: the deferred forward of the same points -> one launch for both
+                       int phase = 0) {                       // DsdfLossCfg.dw_phase: 1 = all but the early layers' dW + finalize, 2 = only those
+  const DwSched& DS = phase == 0 ? P.dw : P.dwph[phase - 1];
+  auto in_phase = [&](int l) { return phase == 0 || (phase == 1 ? l >= P.dw_k : l < P.dw_k); };
   DsdfParamLayout L;
   param_layout(net, &L);
   const Packed pk = packed_layout(net);
@@ -848,7 +867,7 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     wmac += (double)y.K * y.ncols;
   }
   a.n_layers = cnt;
-  {
+  if (phase != 2) {
     // algorithmic FLOPs of the dX chain (the reference back-propagates through every hidden layer down to x0); the
     // executed count `wmac` is smaller: layer 0's dX and the skip layer's x0 columns come from column sums instead
     double amac = 0;
@@ -870,7 +889,7 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
   }
   const ReduceRowsArgs rr{at<float>(ws, P.part_off), P.nwg, P.ld_part, P.ld_part, at<float>(ws, P.part2_off), LAST_GROUPS};
   const int rr_bx = (P.ld_part + 63) / 64;
-  if (!segmode) {
+  if (!segmode && phase != 2) {
     if (want_dw) {   // second stage of the head's per-workgroup partials
       hipLaunchKernelGGL(reduce_rows_kernel, dim3(rr_bx, LAST_GROUPS), dim3(256), 0, st, rr);
       LAUNCH_OK("reduce_rows_kernel");
@@ -907,32 +926,34 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     lat_n = sb->R * ((net->latent_size + 15) / 16);
   }
   const int cus = chip_waves() / 4;
-  const int dw_busy = want_dw ? ((P.dw.n_full + P.dw.n_narrow + 3) / 4 < cus ? (P.dw.n_full + P.dw.n_narrow + 3) / 4 : cus) : 0;
+  const int dw_items = DS.n_full + DS.n_narrow;
+  const int dw_busy = want_dw ? ((dw_items + 3) / 4 < cus ? (dw_items + 3) / 4 : cus) : 0;
   // the idle workgroups take the role blocks one after the other: that stays inside the dW time for batches of up to one
   // workgroup per CU (measured: 16384 points, 1168 role blocks on 16 workgroups, dW time unchanged); larger batches put
   // the roles on the critical path (65536 points: -5 %), so they get their own (wide) launch there
   static const bool no_ride = [] { const char* e = getenv("DSDF_NO_RIDE"); return e && e[0] == '1'; }();   // A/B switch
   // (gemm_split: the dW items finish in ~60 % of the time the riding roles need on the 16 spare workgroups -- they would be the
   // launch's tail, 462 us against 227; there the roles go out as a launch of their own, 18 us)
-  const bool post_rides = segmode && want_dw && cus - dw_busy >= 8 && P.nwg <= cus && !no_ride && !net->gemm_split;
-  if (segmode && !post_rides) {
+  const bool post_rides = segmode && want_dw && cus - dw_busy >= 8 && P.nwg <= cus && !no_ride && !net->gemm_split && phase != 2 &&
+                          dw_items > 0;
+  if (segmode && !post_rides && phase != 2) {
     hipLaunchKernelGGL(post_bwd_kernel, dim3((unsigned)(q.rr_n + q.dw_n + lat_n)), dim3(256), 0, st, q);
     LAUNCH_OK("post_bwd_kernel");
   }
-  if (want_dw) {   // all dW_l = dP_l^T a_l in one launch
+  if (want_dw && dw_items > 0) {   // all dW_l = dP_l^T a_l (of this phase's layers) in one launch
     DwArgs d;
     memset(&d, 0, sizeof(d));
-    d.n_layers = last; d.n_full = P.dw.n_full; d.n_narrow = P.dw.n_narrow; d.N = (int)n;
+    d.n_layers = last; d.n_full = DS.n_full; d.n_narrow = DS.n_narrow; d.N = (int)n;
     double fl = 0;
     for (int l = 0; l < last; ++l) {
       DwLayer& y = d.ly[l];
       y.dp = at<float>(ws, P.dpl_off[l]); y.ld_dp = P.ld_dp;
       y.act = at<float>(ws, P.in_off[l]); y.ld_act = P.ld_in[l];
-      y.slabs = at<float>(ws, P.dwslab_off[l]); y.slab = P.dw.slab[l];
+      y.slabs = at<float>(ws, P.dwslab_off[l]); y.slab = DS.slab[l];
       y.M = net->out_dim[l]; y.Nc = dw_cols(net, l, segmode); y.ldc = P.ld_in[l];
-      y.tiles_m = P.dw.tiles_m[l]; y.tiles_n = P.dw.tiles_n[l]; y.last_nj = P.dw.last_nj[l]; y.nfull_n = P.dw.nfull_n[l];
-      y.nsplit = P.dw.nsplit[l]; y.kchunk = P.dw.kchunk[l]; y.full0 = P.dw.full0[l]; y.narrow0 = P.dw.narrow0[l];
-      fl += 2.0 * (double)n * y.M * net->in_dim[l];   // algorithmic (segment mode executes fewer: hoisted x0 columns)
+      y.tiles_m = DS.tiles_m[l]; y.tiles_n = DS.tiles_n[l]; y.last_nj = DS.last_nj[l]; y.nfull_n = DS.nfull_n[l];
+      y.nsplit = DS.nsplit[l]; y.kchunk = DS.kchunk[l]; y.full0 = DS.full0[l]; y.narrow0 = DS.narrow0[l];
+      if (in_phase(l)) fl += 2.0 * (double)n * y.M * net->in_dim[l];   // algorithmic (segment mode executes fewer: hoisted x0 columns)
     }
     PostBwdArgs none;
     memset(&none, 0, sizeof(none));
@@ -950,12 +971,13 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     memset(&fa, 0, sizeof(fa));
     int rows = 0;
     for (int l = last; l >= 0; --l) {
+      if (!in_phase(l)) continue;
       FinArgs& f = fa.f[fa.n];
       if (l == last) {
         f.slabs = at<float>(ws, P.part2_off); f.nsplit = LAST_GROUPS; f.slab = P.ld_part; f.ldc = P.ld_part;
         f.colsum = at<float>(ws, P.partdb_off); f.npart = P.nwg; f.ldcs = 1;
       } else {
-        f.slabs = at<float>(ws, P.dwslab_off[l]); f.nsplit = P.dw.nsplit[l]; f.slab = P.dw.slab[l]; f.ldc = P.ld_in[l];
+        f.slabs = at<float>(ws, P.dwslab_off[l]); f.nsplit = DS.nsplit[l]; f.slab = DS.slab[l]; f.ldc = P.ld_in[l];
         if (l == last - 1) { f.colsum = at<float>(ws, P.part2_off) + P.ld_in[last]; f.npart = LAST_GROUPS; f.ldcs = P.ld_part; }
         else { f.colsum = at<float>(ws, P.cs_off[l]); f.npart = P.nwg; f.ldcs = P.ldcs; }
       }
@@ -987,7 +1009,7 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
       ++fa.n;
     }
     fa.row0[fa.n] = rows;
-    if (segmode && sb->scatter != nullptr) {
+    if (segmode && sb->scatter != nullptr && phase != 2) {
       hipLaunchKernelGGL(finalize_scatter_kernel, dim3(rows + sb->R), dim3(256), 0, st, fa, *sb->scatter, rows);
       LAUNCH_OK("finalize_scatter_kernel");
       *sb->scatter_done = true;
@@ -1056,6 +1078,20 @@ int dsdf_workspace_bytes(const DsdfNet* net, int64_t n_points, int64_t n_segment
   const size_t a = make_plan(net, n_points, n_segments, false, false).total;
   const size_t b = make_plan(net, n_points, n_segments, false, true).total;   // segment mode lays the workspace out differently
   *bytes = a > b ? a : b;
+  return 0;
+}
+
+int dsdf_grad_bucket_split(const DsdfNet* net, int32_t* first_late_layer, int64_t* arena_split) {
+  TRY(validate(net));
+  if (!first_late_layer || !arena_split) return fail(DSDF_E_INVALID, "NULL argument");
+  DsdfParamLayout L;
+  param_layout(net, &L);
+  const int k = dw_bucket_layer(net);
+  int64_t o = L.v_off[k];                      // a layer's parameters are one contiguous block: its first offset
+  if (L.bias_off[k] >= 0 && L.bias_off[k] < o) o = L.bias_off[k];
+  if (L.g_off[k] >= 0 && L.g_off[k] < o) o = L.g_off[k];
+  *first_late_layer = k;
+  *arena_split = o;
   return 0;
 }
 
@@ -1340,6 +1376,19 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
   if (ws_bytes < P.total) return fail(DSDF_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, P.total);
   hipStream_t st = (hipStream_t)stream;
   const int Lc = net->latent_size;
+  const int phase = cfg->dw_phase;
+  if (phase < 0 || phase > 2) return fail(DSDF_E_INVALID, "dw_phase %d out of range", phase);
+  if (phase != 0 && (!fusedb || cfg->frozen_decoder || accumulate || fz != nullptr))
+    return fail(DSDF_E_INVALID, "dw_phase needs the fused kernels, a trainable decoder, accumulate = 0 and the two-call path");
+  if (phase == 2) {   // only the weight gradients of the early layers, from what the phase-1 call left in the workspace
+    FusedSeg seg0;
+    memset(&seg0, 0, sizeof(seg0));
+    const FusedBwdHead h0 = make_head(net, P, ws, packed, params, HEAD_TRAIN, cfg->training);
+    const SegBwd sb0{&seg0, b->seg_scene, latent_table, (int)R, nullptr, nullptr};
+    bool used = false;
+    return run_backward_fused(net, P, ws, packed, params, n, cfg->training, grads, 0, segsum ? 0 : Lc, &used, st, true, h0, nullptr,
+                              segsum ? &sb0 : nullptr, nullptr, 2);
+  }
 
   if (cfg->code_bound > 0.f || !accumulate) {   // max-norm renorm of the looked-up rows + zero of the dense latent gradient
     const long long nzero = accumulate ? 0 : (long long)n_scenes * Lc;
@@ -1404,7 +1453,7 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
     const FuseAdam* use = (fz != nullptr && want_dw && !accumulate) ? fz : nullptr;
     const SegBwd sb{&seg, b->seg_scene, latent_table, (int)R, &sc, &scatter_done};
     TRY(run_backward_fused(net, P, ws, packed, params, n, cfg->training, grads, accumulate, segsum ? 0 : Lc, &used_dzB, st, want_dw, h,
-                           use, segsum ? &sb : nullptr, merged ? &fwd_args : nullptr));
+                           use, segsum ? &sb : nullptr, merged ? &fwd_args : nullptr, phase));
     if (use != nullptr && adam_fused) *adam_fused = 1;
   } else {
     TRY(run_backward(net, P, ws, packed, params, n, cfg->training, grads, accumulate, Lc, &used_dzB, st, want_dw, cfg->dropout_key,

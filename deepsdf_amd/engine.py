@@ -204,7 +204,7 @@ class Engine:
     # ---- training --------------------------------------------------------------------------------------------
     def train_forward_backward(self, latents, dlat, seg_scene, seg_offset, xyz, sdf_gt, *, n_norm, clamp_dist,
                                reg_coef, code_bound, training=True, seed=0, row_offset=0, accumulate=False,
-                               sdf_out=None, step=None, seg_len=0, frozen_decoder=False, loss_out=None):
+                               sdf_out=None, step=None, seg_len=0, frozen_decoder=False, loss_out=None, dw_phase=0):
         """One chunk of train_deep_sdf.py:509-533.  Gradients land in self.grads / dlat, loss in self.loss (or in the
         caller's 1-element fp32 device tensor `loss_out`, e.g. a slot of a per-epoch loss buffer: no copy kernel per step)."""
         self._fresh_weights()
@@ -217,6 +217,7 @@ class Engine:
         cfg.code_bound = float(code_bound) if code_bound is not None else -1.0
         cfg.training = int(training)
         cfg.frozen_decoder = int(frozen_decoder)
+        cfg.dw_phase = int(dw_phase)      # 1 / 2: the two halves of a two-bucket data-parallel backward (include/dsdf.h DsdfLossCfg)
         st = self.step if step is None else step
         for l in range(_lib.MAX_LAYERS):
             cfg.dropout_key[l] = dropout_layer_key(seed, st, l)
@@ -224,6 +225,12 @@ class Engine:
             C.byref(self.cnet), _ptr(self.packed), _ptr(self.params), _ptr(latents), latents.shape[0], C.byref(b),
             C.byref(cfg), _ptr(self.grads), _ptr(dlat), _ptr(self.loss if loss_out is None else loss_out), _ptr(sdf_out),
             int(accumulate), _ptr(ws), ws.numel(), _stream()))
+
+    def grad_bucket_split(self):
+        """(first layer of the late bucket, arena offset separating the two gradient buckets): dsdf_grad_bucket_split."""
+        k, off = C.c_int32(), C.c_int64()
+        _lib.check(self.lib.dsdf_grad_bucket_split(C.byref(self.cnet), C.byref(k), C.byref(off)))
+        return int(k.value), int(off.value)
 
     def train_step(self, latents, dlat, lat_m, lat_v, seg_scene, seg_offset, xyz, sdf_gt, *, n_norm, clamp_dist, reg_coef,
                    code_bound, lr_decoder, lr_latent, training=True, seed=0, seg_len=0, betas=(0.9, 0.999), eps=1e-8,

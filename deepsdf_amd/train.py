@@ -240,6 +240,9 @@ class FusedTrainStep:
         self.lat_m, self.lat_v = torch.zeros_like(latents), torch.zeros_like(latents)
         self.clamp_dist, self.code_reg, self.lam = clamp_dist, code_reg, code_reg_lambda
         self.code_bound, self.grad_clip, self.seed = code_bound, grad_clip, seed
+        # DSDF_AR_BUCKETS=2 (data-parallel steps only): the decoder gradient is exchanged in two buckets -- the late layers'
+        # all-reduce runs under the early layers' weight-gradient launch.  Default 1: ONE all-reduce.
+        self.ar_buckets = 2 if os.environ.get("DSDF_AR_BUCKETS") == "2" else 1
 
     def __call__(self, scene_rows, samples_per_scene, xyz, sdf_gt, epoch, lr_decoder, lr_latent, batch_split=1,
                  n_norm=None, under_allreduce=None, loss_out=None):
@@ -280,25 +283,48 @@ class FusedTrainStep:
             if under_allreduce is not None:
                 under_allreduce()
             return
-        row0 = 0
-        for ci, (sc, so, xc, gc) in enumerate(chunks):
+        def fb(ci, sc, so, xc, gc, row0, phase=0):
             self.eng.train_forward_backward(self.lat, self.dlat, sc, so, xc, gc, n_norm=n_norm, clamp_dist=self.clamp_dist,
                                             reg_coef=reg, code_bound=self.code_bound, training=True, seed=self.seed,
-                                            row_offset=row0, accumulate=ci > 0, seg_len=uniform, loss_out=loss_out)
-            row0 += xc.shape[0]
-        # Data parallel (train_deep_sdf.py:353 replaced): ONE sum all-reduce of the decoder-gradient
+                                            row_offset=row0, accumulate=ci > 0, seg_len=uniform, loss_out=loss_out, dw_phase=phase)
+
+        # Data parallel (train_deep_sdf.py:353 replaced): a sum all-reduce of the decoder-gradient
         # arena, issued asynchronously (RCCL runs it on its own stream, ordered after the finalize launch that wrote the
         # arena).  Everything that does not need the reduced gradient is enqueued on the compute stream meanwhile: the Adam
         # update of this rank's latent rows (their gradient is complete and private to the owner rank) and `under_allreduce`
         # (the trainer passes the NEXT batch's sampling kernel).  The decoder's Adam + weight re-materialisation wait for it.
-        work = dist.allreduce_sum_async(self.eng.grads)
-        split_adam = work is not None or (force_dp and self.grad_clip is None)
+        works = None
+        if self.ar_buckets == 2 and len(chunks) == 1 and (dist.is_multi() or force_dp):
+            # two buckets: phase 1 leaves the late layers' gradients in the arena -> their all-reduce starts and runs under
+            # phase 2, the early layers' weight-gradient launch + finalize -> the second bucket follows
+            from ._lib import DsdfError
+            try:
+                fb(0, *chunks[0], 0, phase=1)
+            except DsdfError as e:             # a net the fused kernels do not cover: rejected on the host, nothing was launched
+                if "dw_phase" not in str(e):
+                    raise
+                self.ar_buckets = 1
+            else:
+                if getattr(self, "_bucket_split", None) is None:
+                    self._bucket_split = self.eng.grad_bucket_split()[1]
+                cut = self._bucket_split
+                w0 = dist.allreduce_sum_async(self.eng.grads[cut:])
+                fb(0, *chunks[0], 0, phase=2)
+                works = [w0, dist.allreduce_sum_async(self.eng.grads[:cut])]
+        if works is None:
+            row0 = 0
+            for ci, (sc, so, xc, gc) in enumerate(chunks):
+                fb(ci, sc, so, xc, gc, row0)
+                row0 += xc.shape[0]
+            works = [dist.allreduce_sum_async(self.eng.grads)]
+        works = [w for w in works if w is not None]
+        split_adam = bool(works) or (force_dp and self.grad_clip is None)
         if split_adam:
             self.eng.adam_latents(self.lat, self.dlat, self.lat_m, self.lat_v, lr_latent)
             if under_allreduce is not None:
                 under_allreduce()
-            if work is not None:
-                work.wait()                   # nccl: the compute stream waits for RCCL's stream (no host block)
+            for w in works:
+                w.wait()                      # nccl: the compute stream waits for RCCL's stream (no host block)
         if self.grad_clip is not None:
             self.eng.grad_norm(self.grad_clip)
         if split_adam:

@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define DSDF_MAX_LAYERS 16
-#define DSDF_ABI_VERSION 12
+#define DSDF_ABI_VERSION 13
 
 enum {
   DSDF_OK = 0,
@@ -104,6 +104,13 @@ typedef struct DsdfLossCfg {
   int32_t training;           /* 1: dropout active (decoder.train(), :477) */
   int32_t frozen_decoder;     /* 1: skip the decoder's weight gradients (latent-only optimisation, config 4); grads untouched */
   uint32_t dropout_key[DSDF_MAX_LAYERS]; /* [host-computed] per-layer hash keys (oracle: dropout_layer_key) */
+  int32_t dw_phase;           /* data-parallel steps that exchange the decoder gradient in TWO buckets (replaces nn.DataParallel's
+                                 reduce, train_deep_sdf.py:353): 0 = the whole backward in this call (default); 1 = everything except
+                                 the weight gradients of the early layers [0, k) -- on return (stream order) the arena holds the
+                                 gradients of layers [k, last], whose all-reduce can start; 2 = only the weight gradients of layers
+                                 [0, k), from the activations / dP the phase-1 call left in `ws` (same net, batch and workspace; nothing
+                                 else may touch `ws` in between).  k and the arena offset that separates the two buckets:
+                                 dsdf_grad_bucket_split.  Phases need the fused kernels, a trainable decoder and accumulate = 0. */
 } DsdfLossCfg;
 
 typedef struct DsdfAdamCfg {
@@ -120,6 +127,10 @@ int dsdf_param_layout(const DsdfNet* net, DsdfParamLayout* out);          /* [ho
 int dsdf_packed_floats(const DsdfNet* net, int64_t* n_floats);            /* [host] size of the packed-weight buffer */
 int dsdf_workspace_bytes(const DsdfNet* net, int64_t n_points, int64_t n_segments, size_t* bytes); /* [host] train/module */
 int dsdf_decode_workspace_bytes(const DsdfNet* net, int64_t n_points, size_t* bytes);                /* [host] dsdf_decode */
+
+/* [host] the two gradient buckets of DsdfLossCfg.dw_phase: layers [*first_late_layer, last] form bucket 0 = arena floats
+ * [*arena_split, total), layers [0, *first_late_layer) bucket 1 = arena floats [0, *arena_split). */
+int dsdf_grad_bucket_split(const DsdfNet* net, int32_t* first_late_layer, int64_t* arena_split);
 
 /* ---- weights -------------------------------------------------------------------------------------
  * W = g * v / ||v||_row for weight-normed layers (torch._weight_norm via parametrizations.weight_norm,

@@ -48,6 +48,7 @@ def main(work_dir):
                                  grads=eng.grads.cpu().clone(), lat=lat.cpu().clone(), lat_m=fused.lat_m.cpu().clone(),
                                  lat_v=fused.lat_v.cpu().clone(), step=eng.step))
     out["under_calls"] = len(ran_under)
+    out["ar_buckets"] = fused.ar_buckets
     dist.barrier()
     torch.save(out, os.path.join(work_dir, f"rank{rank}.pt"))
     torch.distributed.destroy_process_group()

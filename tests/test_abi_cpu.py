@@ -48,6 +48,22 @@ def test_layout_and_sizes(lib):
     assert b.value < 200e6
 
 
+def test_gradient_bucket_split(lib):
+    """dsdf_grad_bucket_split: where the two-bucket data-parallel backward (DsdfLossCfg.dw_phase) cuts the layers and the arena."""
+    from deepsdf_amd.net import NetSpec
+    spec = NetSpec(256, [512] * 8, 3, dropout=list(range(8)), dropout_prob=0.2, norm_layers=list(range(8)), latent_in=[4], weight_norm=True)
+    k, off = C.c_int32(), C.c_int64()
+    assert lib.dsdf_grad_bucket_split(C.byref(spec.c_struct()), C.byref(k), C.byref(off)) == 0
+    assert k.value == 4
+    first = min(p.offset for p in spec.params if p.layer == 4)
+    assert off.value == first == sum(p.numel for p in spec.params if p.layer < 4)
+    assert 0.35 < off.value / spec.n_params < 0.65                                  # two buckets of comparable size
+    plain = NetSpec(5, [48] * 3, 3)                                                 # no weight norm: weight first, then bias
+    assert lib.dsdf_grad_bucket_split(C.byref(plain.c_struct()), C.byref(k), C.byref(off)) == 0
+    assert k.value == 2 and off.value == min(p.offset for p in plain.params if p.layer == 2)
+    assert lib.dsdf_grad_bucket_split(C.byref(plain.c_struct()), None, C.byref(off)) == -1
+
+
 def test_invalid_nets_rejected(lib):
     from deepsdf_amd.net import NetSpec
     with pytest.raises(NotImplementedError):

@@ -33,7 +33,12 @@ def _free_port():
     return p
 
 
-def test_two_rank_hip_step_equals_single_process_and_oracle(tmp_path):
+@pytest.mark.parametrize("buckets", [1, 2], ids=["one_allreduce", "two_buckets"])
+def test_two_rank_hip_step_equals_single_process_and_oracle(tmp_path, buckets):
+    """buckets = 2 (DSDF_AR_BUCKETS=2): the decoder gradient travels in two all-reduces, the late layers' under the early layers'
+    weight-gradient launch (DsdfLossCfg.dw_phase 1 / 2).  The K-split of the two half-launches is finer than the single launch's,
+    so the gradients are not bit-equal to the one-bucket run's -- the replicas still are to each other, and both meet the same
+    bounds against the single-process step and the float64 oracle."""
     from deepsdf_amd import dist
     from deepsdf_amd.engine import Engine, make_segments
     world, L, n_scenes, S, seed_base = 2, 256, 8, 256, 100
@@ -67,7 +72,8 @@ def test_two_rank_hip_step_equals_single_process_and_oracle(tmp_path):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), DSDF_DIST_BACKEND="gloo", DSDF_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_PORT=str(port), DSDF_DIST_BACKEND="gloo", DSDF_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   DSDF_AR_BUCKETS=str(buckets))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(tmp_path)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
@@ -84,6 +90,7 @@ def test_two_rank_hip_step_equals_single_process_and_oracle(tmp_path):
     outs = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=True) for r in range(world)]
     assert [(o["lo"], o["hi"]) for o in outs] == shards
     assert all(o["under_calls"] == 2 for o in outs)          # the overlap hook ran once per step
+    assert all(o["ar_buckets"] == buckets for o in outs)     # (2: the phased backward was accepted, no silent fall-back)
 
     # single-process HIP on the concatenated batch: the shards as two accumulated chunks, each with its rank's dropout key
     spec = spec_from_meta(dict(L=L, net_specs=BIG))

@@ -166,10 +166,10 @@ BF16X8_NETS = {
     "4x256_one_tile_per_wave": dict(L=29, net=dict(dims=[256] * 4, dropout=[0, 1, 2, 3], dropout_prob=0.2, norm_layers=[0, 1, 2, 3],
                                                    latent_in=[2], weight_norm=True, geom_dimension=3)),
     # ragged widths, one tile per wave: layers whose last k-unit / last n-tile are partial, waves without a tile in some layers
-    "ragged_narrow": dict(L=11, net=dict(dims=[200, 72, 136, 250], dropout=[], dropout_prob=0.0, norm_layers=[0, 1, 2, 3], latent_in=[3],
+    "ragged_narrow": dict(L=11, net=dict(dims=[200, 72, 136, 252], dropout=[], dropout_prob=0.0, norm_layers=[0, 1, 2, 3], latent_in=[3],
                                          weight_norm=True, geom_dimension=3)),
     # ragged widths mixing waves with two tiles and waves with one
-    "ragged_wide": dict(L=40, net=dict(dims=[500, 300, 420, 512, 270], dropout=[0, 2], dropout_prob=0.2, norm_layers=[0, 1, 2, 3, 4],
+    "ragged_wide": dict(L=40, net=dict(dims=[500, 300, 420, 512, 268], dropout=[0, 2], dropout_prob=0.2, norm_layers=[0, 1, 2, 3, 4],
                                        latent_in=[2], weight_norm=True, geom_dimension=3)),
 }
 
@@ -856,3 +856,62 @@ def test_shipped_experiment_shapes_vs_oracle(L):
             assert rel_err(rh["dlat"], r64["dlat"]) <= GRAD_TOL and worst_elem(rh["dlat"], r64["dlat"]) <= GRAD_ELEM_TOL, tag
             assert p_rel <= PARAM_TOL and p_el <= (step + 1) * (PARAM_STEP_FRAC_SPLIT if split else PARAM_STEP_FRAC), tag
             assert rel_err(tr.lat.cpu(), st64.latents) <= PARAM_TOL, tag
+
+
+PHASE_NETS = {
+    "8x512_headline": dict(L=256, B=64, S=256, net=BIG),
+    "8x512_shipped_L2": dict(L=2, B=4, S=1024, net=BIG),
+    "3x72_noskip": dict(L=7, B=3, S=128, net=dict(dims=[72, 72, 72], dropout=[0, 1], dropout_prob=0.2, norm_layers=[0, 1, 2], latent_in=[],
+                                                    weight_norm=True, geom_dimension=3)),
+    "2x64_skip1": dict(L=9, B=2, S=192, net=dict(dims=[64, 64], dropout=[], dropout_prob=0.0, norm_layers=[0, 1], latent_in=[1],
+                                                  weight_norm=True, geom_dimension=3)),
+}
+
+
+@pytest.mark.parametrize("ragged", [False, True], ids=["segments", "ragged"])
+@pytest.mark.parametrize("name", sorted(PHASE_NETS))
+def test_two_phase_backward_equals_the_single_call(name, ragged):
+    """DsdfLossCfg.dw_phase (the two-bucket gradient exchange of a data-parallel step): phase 1 = forward, backward and the weight
+    gradients of the late layers, phase 2 = the weight gradients of the early layers from what phase 1 left in the workspace.
+    Against the single call on the same batch: loss, forward and latent gradient bit-identical (the same launches produce them),
+    weight gradients equal to summation order (the two half-launches split K finer); after phase 1 alone the late bucket is
+    already final and the early bucket untouched."""
+    c = PHASE_NETS[name]
+    L, B, S = c["L"], c["B"], c["S"]
+    spec = spec_from_meta(dict(L=L, net_specs=c["net"]))
+    params = orc.init_params(orc.make_net(L, **c["net"]), 77)
+    lat0 = torch.randn(B, L, generator=torch.Generator().manual_seed(78)) / math.sqrt(L)
+    idx, xyz, gt = _big_batch(B, S, 79)
+    from deepsdf_amd.engine import make_segments
+    one, two = HipTrainer(spec, params, lat0), HipTrainer(spec, params, lat0)
+    k, cut = one.eng.grad_bucket_split()
+    assert 0 < cut < spec.n_params and 0 < k < spec.n_layers
+    sc, so = make_segments(idx.cuda())
+    xc, gc = xyz.cuda().contiguous(), gt.reshape(-1).cuda().contiguous()
+    kw = dict(n_norm=B * S, clamp_dist=0.1, reg_coef=1e-4, code_bound=1.0, training=True, seed=5, seg_len=0 if ragged else S)
+    y1, y2 = torch.empty(B * S, device="cuda"), torch.empty(B * S, device="cuda")
+    one.eng.train_forward_backward(one.lat, one.dlat, sc, so, xc, gc, sdf_out=y1, **kw)
+    two.eng.grads.fill_(float("nan"))                          # whatever a phase does not write stays NaN
+    two.eng.train_forward_backward(two.lat, two.dlat, sc, so, xc, gc, sdf_out=y2, dw_phase=1, **kw)
+    g_mid = two.eng.grads.clone()
+    assert bool(torch.isnan(g_mid[:cut]).all()) and not bool(torch.isnan(g_mid[cut:]).any())
+    two.eng.train_forward_backward(two.lat, two.dlat, sc, so, xc, gc, dw_phase=2, **kw)
+    assert torch.equal(two.eng.grads[cut:], g_mid[cut:])        # phase 2 leaves the late bucket alone
+    assert torch.equal(y1, y2) and torch.equal(one.eng.loss, two.eng.loss) and torch.equal(one.dlat, two.dlat)
+    assert torch.equal(one.lat, two.lat)                        # (the renorm ran once, in phase 1)
+    g1, g2 = one.eng.named_views(one.eng.grads), two.eng.named_views(two.eng.grads)
+    worst = max(rel_err(g2[n].cpu(), g1[n].cpu()) for n in g1)
+    print(f"{name} {'ragged' if ragged else 'segments'}: two-phase vs single-call weight gradients, worst rel {worst:.2e}")
+    for n in g1:
+        assert rel_err(g2[n].cpu(), g1[n].cpu()) <= 2e-6 and worst_elem(g2[n].cpu(), g1[n].cpu()) <= 1e-5, n
+    # a second two-phase run reproduces the first bit for bit
+    again = HipTrainer(spec, params, lat0)
+    again.eng.train_forward_backward(again.lat, again.dlat, sc, so, xc, gc, dw_phase=1, **kw)
+    again.eng.train_forward_backward(again.lat, again.dlat, sc, so, xc, gc, dw_phase=2, **kw)
+    assert torch.equal(again.eng.grads, two.eng.grads)
+    # phases are refused where they cannot work: gradient accumulation (batch_split chunks), a frozen decoder
+    from deepsdf_amd._lib import DsdfError
+    with pytest.raises(DsdfError, match="dw_phase"):
+        two.eng.train_forward_backward(two.lat, two.dlat, sc, so, xc, gc, dw_phase=1, accumulate=True, **kw)
+    with pytest.raises(DsdfError, match="dw_phase"):
+        two.eng.train_forward_backward(two.lat, two.dlat, sc, so, xc, gc, dw_phase=2, frozen_decoder=True, **kw)
