@@ -376,24 +376,28 @@ __device__ __forceinline__ void fused_kloop(f32x16 (&acc)[2][4], const float* ap
 // in the k-loop too (264 VALU instructions per k-unit against 48 MFMAs = the VALU port exactly full): 553 us against 807.
 // Same accumulator layout as v_mfma_f32_32x32x2_f32: prologues and epilogues do not know the difference.
 struct Split3 { bf16x8 h, m, l; };
+// One pair of fp32 values -> the packed bf16 pairs of its three terms (element 0 in the low 16 bits).  The terms are ROUND-TO-NEAREST
+// cuts (v_cvt_pk_bf16_f32: one instruction per pair and term): h = bf16(x), m = bf16(x - h), l = bf16(x - h - m); the subtractions
+// are exact and l is exact (x - h - m has at most 6 significant bits), so h + m + l = x exactly, with |m| <= 2^-9 |x| and
+// |l| <= 2^-18 |x| -- the three dropped cross products are <= 2^-26 of the product (top-16-bit truncation, the first version:
+// |m| < 2^-7, |l| < 2^-14, dropped terms up to 2^-20 and all of one sign).  Same instruction count as the truncating cut (11 per pair).
+__device__ __forceinline__ void cut_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const bf16x2 hh = {(__bf16)x0, (__bf16)x1};
+  h = __builtin_bit_cast(uint32_t, hh);
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xFFFF0000u);
+  const bf16x2 mm = {(__bf16)r0, (__bf16)r1};
+  m = __builtin_bit_cast(uint32_t, mm);
+  const float t0 = r0 - __uint_as_float(m << 16), t1 = r1 - __uint_as_float(m & 0xFFFF0000u);
+  const bf16x2 ll = {(__bf16)t0, (__bf16)t1};
+  l = __builtin_bit_cast(uint32_t, ll);
+}
 __device__ __forceinline__ Split3 split8(const float4& q0, const float4& q1) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   const float x[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
   uint32_t hw[4], mw[4], lw[4];
 #pragma unroll
-  for (int pr = 0; pr < 4; ++pr) {
-    float r[2], t[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const float v = x[2 * pr + e];
-      r[e] = v - __uint_as_float(__float_as_uint(v) & 0xFFFF0000u);
-      t[e] = r[e] - __uint_as_float(__float_as_uint(r[e]) & 0xFFFF0000u);
-    }
-    // pack the high halves of two values into one register: element 2pr in the low 16 bits (v_perm_b32)
-    hw[pr] = __builtin_amdgcn_perm(__float_as_uint(x[2 * pr + 1]), __float_as_uint(x[2 * pr]), 0x07060302u);
-    mw[pr] = __builtin_amdgcn_perm(__float_as_uint(r[1]), __float_as_uint(r[0]), 0x07060302u);
-    lw[pr] = __builtin_amdgcn_perm(__float_as_uint(t[1]), __float_as_uint(t[0]), 0x07060302u);
-  }
+  for (int pr = 0; pr < 4; ++pr) cut_pair(x[2 * pr], x[2 * pr + 1], hw[pr], mw[pr], lw[pr]);
   Split3 s;
   s.h = __builtin_bit_cast(bf16x8, (u32x4){hw[0], hw[1], hw[2], hw[3]});
   s.m = __builtin_bit_cast(bf16x8, (u32x4){mw[0], mw[1], mw[2], mw[3]});
@@ -423,13 +427,18 @@ __device__ __forceinline__ SplitBView split_bview(const float* ws, int plane, co
   v.voff = lane * 16;
   return v;
 }
+#ifndef SPLIT_LAB_U0
+#define SPLIT_LAB_U0 0     // lab (wrong results, timing only): every weight load reads k-unit 0 -- takes the L2 stream out of the k-loop
+#endif
 __device__ __forceinline__ bf16x8 split_bload(const SplitBView& B, int ni, int u, int pl) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  if (SPLIT_LAB_U0) u = 0;
   const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(B.rsrc, B.voff, pl * B.plane + ((B.tbase[ni] + u) << 10), 0);
   return __builtin_bit_cast(bf16x8, r);
 }
 __device__ __forceinline__ float4 split_bload32(const SplitBView& B, int ni, int u, int half) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  if (SPLIT_LAB_U0) u = 0;
   const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(B.rsrc32, B.voff + 1024 * half, (B.tbase[ni] + u) * 2048, 0);
   return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
 }
@@ -537,6 +546,157 @@ __device__ __forceinline__ void fused_kloop_split(f32x16 (&acc)[2][4], const flo
   }
 }
 
+// ---- the same loop with the interleave written out (NACT = 4, the 512-wide layers) ---------------------------------------------------
+// The compiler does not interleave the cut with the MFMAs, with or without sched_group_barrier (emitted order of the loop above: ~140
+// VALU instructions, then a mixed stretch, then ~45 MFMAs back to back), and a lone in-order wave only overlaps VALU work that sits
+// BETWEEN its MFMAs: the step runs in VALU time + MFMA time (2281 cycles per k-unit against 1536 of MFMAs).  Here a half-step is 16
+// asm groups, each  MFMA, 4 VALU, MFMA, 4 VALU, MFMA, 3 VALU  = three MFMAs of unit u woven with the cut of ONE value pair of unit
+// u+1 (16 pairs per unit: 8 of the activation rows, 8 of the two weight tiles that are cut in registers).  volatile asm statements
+// keep their order, so the emitted stream IS this order; 3.7 VALU instructions per 32-cycle MFMA gap is inside what a bf16 MFMA
+// leaves free (MI355X_MICROARCH.md: issue costs summing to <= 24 cycles per gap hide).  Loads stay compiler-issued builtins (it
+// counts them and waits before the first group that reads their registers).  No hazard needs padding inside a group: the VALU
+// results are MFMA operands only one half-step later, the three MFMAs write three different accumulators.
+#ifndef SPLIT_ASM
+#define SPLIT_ASM 1        // 0: the compiler-scheduled loop above for every NACT (A/B switch)
+#endif
+#define SPLIT_GROUP(C0, A0, B0, C1, A1, B1, C2, A2, B2, X0, X1, H, M, L)                                                       \
+  {                                                                                                                           \
+    uint32_t t0_, t1_;                                                                                                        \
+    float r0_, r1_;                                                                                                           \
+    asm volatile(                                                                                                             \
+        "v_mfma_f32_32x32x16_bf16 %[c0], %[a0], %[b0], %[c0]\n"                                                               \
+        "v_cvt_pk_bf16_f32 %[h], %[x0], %[x1]\n"                                                                              \
+        "v_lshlrev_b32 %[t0], 16, %[h]\n"                                                                                     \
+        "v_and_b32 %[t1], %[msk], %[h]\n"                                                                                     \
+        "v_sub_f32 %[r0], %[x0], %[t0]\n"                                                                                     \
+        "v_mfma_f32_32x32x16_bf16 %[c1], %[a1], %[b1], %[c1]\n"                                                               \
+        "v_sub_f32 %[r1], %[x1], %[t1]\n"                                                                                     \
+        "v_cvt_pk_bf16_f32 %[m], %[r0], %[r1]\n"                                                                              \
+        "v_lshlrev_b32 %[t0], 16, %[m]\n"                                                                                     \
+        "v_and_b32 %[t1], %[msk], %[m]\n"                                                                                     \
+        "v_mfma_f32_32x32x16_bf16 %[c2], %[a2], %[b2], %[c2]\n"                                                               \
+        "v_sub_f32 %[r0], %[r0], %[t0]\n"                                                                                     \
+        "v_sub_f32 %[r1], %[r1], %[t1]\n"                                                                                     \
+        "v_cvt_pk_bf16_f32 %[l], %[r0], %[r1]\n"                                                                              \
+        : [c0] "+a"(C0), [c1] "+a"(C1), [c2] "+a"(C2), [h] "=&v"(H), [m] "=&v"(M), [l] "=&v"(L), [t0] "=&v"(t0_), [t1] "=&v"(t1_),  \
+          [r0] "=&v"(r0_), [r1] "=&v"(r1_)                                                                                     \
+        : [a0] "v"(A0), [b0] "v"(B0), [a1] "v"(A1), [b1] "v"(B1), [a2] "v"(A2), [b2] "v"(B2), [x0] "v"(X0), [x1] "v"(X1),         \
+          [msk] "s"(0xFFFF0000u));                                                                                            \
+  }
+
+__device__ __forceinline__ void fused_kloop_split_asm4(f32x16 (&acc)[2][4], const float* ap, const SplitBView& bv, int nu, SplitBSet& PB) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  // Register lifetimes are what the loop is built around (a value that lives three half-steps in a loop of period two makes the
+  // compiler copy it into place -- and WAIT for its load first, in the middle of the MFMA stream):
+  //   Raw    the fp32 operands of a unit (activation rows + the two weight tiles cut in registers): loaded in half-step k, cut in k+1
+  //   Cut    their bf16 terms: written in half-step k+1, MFMA operands in k+2
+  //   Planes the pre-cut terms of weight tiles 0, 1: loaded in half-step k+1 (one half-step after the unit's Raw), MFMA operands in k+2
+  // every set has two instances that alternate.
+  struct Raw { float4 a[4]; float4 f[2][2]; };
+  struct Cut { Split3 sa[2]; Split3 sb[2]; };
+  struct Planes { bf16x8 b[2][3]; };
+  static_assert(split_npl(4) == 2, "the woven loop cuts exactly two of the four weight tiles in registers");
+  Raw r0, r1;
+  Cut c0, c1;
+  Planes p0, p1;
+  const int ulast = nu - 1;
+  auto load_raw = [&](Raw& r, int u) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      r.f[ni][0] = split_bload32(bv, 2 + ni, u, 0);
+      r.f[ni][1] = split_bload32(bv, 2 + ni, u, 1);
+    }
+    r.a[0] = *reinterpret_cast<const float4*>(ap + 16 * u);
+    r.a[1] = *reinterpret_cast<const float4*>(ap + 32 * FLD + 16 * u);
+    r.a[2] = *reinterpret_cast<const float4*>(ap + 16 * u + 4);
+    r.a[3] = *reinterpret_cast<const float4*>(ap + 32 * FLD + 16 * u + 4);
+  };
+  // the 8 values of cut operand q (0, 1: activation rows fr / 32 + fr; 2, 3: weight tiles 2, 3) of a raw unit
+  auto xval = [&](const Raw& r, int q, int e) __attribute__((always_inline)) -> float {
+    const float4& lo = q < 2 ? r.a[q] : r.f[q - 2][0];
+    const float4& hi = q < 2 ? r.a[q + 2] : r.f[q - 2][1];
+    const float4& v = e < 4 ? lo : hi;
+    const int k = e & 3;
+    return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w));
+  };
+  // The loads of a half-step go out ONE PER GROUP, behind the group's MFMAs (slot i after group i): issued as a cluster at the top
+  // of the half-step (where the compiler puts them by itself) their ~35 load + address instructions run with the MFMA pipe idle.
+  // The scalar offset passes through an empty volatile asm, which pins the load behind the group in front of it.
+  //   slots 0-5: the six plane loads of unit up (operands of the NEXT half-step's first MFMAs: earliest), 6-9: the fp32 weight
+  //   tiles of unit ur (cut in the second half of the next half-step), 10-13: the activation rows of unit ur (LDS: short latency)
+  auto load_slot = [&](int i, Planes& pn, int up, Raw& rn, int ur) __attribute__((always_inline)) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    if (i < 6) {
+      const int ni = i / 3, pl = i % 3;
+      int so = pl * bv.plane + ((bv.tbase[ni] + (SPLIT_LAB_U0 ? 0 : up)) << 10);
+      asm volatile("" : "+s"(so));
+      pn.b[ni][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(bv.rsrc, bv.voff, so, 0));
+    } else if (i < 10) {
+      const int ni = (i - 6) / 2, half = (i - 6) % 2;
+      int so = (bv.tbase[2 + ni] + (SPLIT_LAB_U0 ? 0 : ur)) * 2048;
+      asm volatile("" : "+s"(so));
+      const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(bv.rsrc32, bv.voff + 1024 * half, so, 0);
+      rn.f[ni][half] = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
+    } else if (i < 14) {
+      const int k = i - 10;                                       // a[0], a[1], a[2], a[3]
+      int uo = 16 * ur;
+      asm volatile("" : "+s"(uo));
+      rn.a[k] = *reinterpret_cast<const float4*>(ap + (k & 1) * 32 * FLD + uo + (k >> 1) * 4);
+    }
+  };
+  // half-step: the 48 MFMAs of the unit whose terms are (c, p), woven with the cut of the raw unit r into n; meanwhile the planes of
+  // unit up go to pn and the fp32 operands of unit ur to rn
+  auto step = [&](const Cut& c, const Planes& p, const Raw& r, Cut& n, Planes& pn, int up, Raw& rn, int ur) __attribute__((always_inline)) {
+    uint32_t hw[4][4], mw[4][4], lw[4][4];      // [cut operand][pair]
+    // MFMA i of the half-step (i = 0 .. 47): pass i / 8 in the order l h, h l, m m, m h, h m, h h (small terms first), tile (i % 8) / 2,
+    // row tile i % 2 -- consecutive MFMAs never touch the same accumulator.  B term t (0 = h, 1 = m, 2 = l) of tile j: planes for j < 2
+#define SPLIT_A_OF(i) ((i) / 8 == 0 ? c.sa[(i) % 2].l : ((i) / 8 == 2 || (i) / 8 == 3) ? c.sa[(i) % 2].m : c.sa[(i) % 2].h)
+#define SPLIT_BT(j, t) ((j) < 2 ? p.b[(j) & 1][t] : ((t) == 0 ? c.sb[(j) & 1].h : (t) == 1 ? c.sb[(j) & 1].m : c.sb[(j) & 1].l))
+#define SPLIT_B_OF(i) SPLIT_BT(((i) % 8) / 2, ((i) / 8 == 1 ? 2 : ((i) / 8 == 2 || (i) / 8 == 4) ? 1 : 0))
+#define SPLIT_G(g)                                                                                                                       \
+    SPLIT_GROUP(acc[(3 * (g)) % 2][((3 * (g)) % 8) / 2], SPLIT_A_OF(3 * (g)), SPLIT_B_OF(3 * (g)),                                          \
+                acc[(3 * (g) + 1) % 2][((3 * (g) + 1) % 8) / 2], SPLIT_A_OF(3 * (g) + 1), SPLIT_B_OF(3 * (g) + 1),                          \
+                acc[(3 * (g) + 2) % 2][((3 * (g) + 2) % 8) / 2], SPLIT_A_OF(3 * (g) + 2), SPLIT_B_OF(3 * (g) + 2),                          \
+                xval(r, (g) / 4, 2 * ((g) % 4)), xval(r, (g) / 4, 2 * ((g) % 4) + 1), hw[(g) / 4][(g) % 4], mw[(g) / 4][(g) % 4], lw[(g) / 4][(g) % 4]) \
+    load_slot(g, pn, up, rn, ur);
+    SPLIT_G(0) SPLIT_G(1) SPLIT_G(2) SPLIT_G(3) SPLIT_G(4) SPLIT_G(5) SPLIT_G(6) SPLIT_G(7)
+    SPLIT_G(8) SPLIT_G(9) SPLIT_G(10) SPLIT_G(11) SPLIT_G(12) SPLIT_G(13) SPLIT_G(14) SPLIT_G(15)
+#undef SPLIT_G
+#undef SPLIT_B_OF
+#undef SPLIT_BT
+#undef SPLIT_A_OF
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      Split3& d = q < 2 ? n.sa[q] : n.sb[q - 2];
+      d.h = __builtin_bit_cast(bf16x8, (u32x4){hw[q][0], hw[q][1], hw[q][2], hw[q][3]});
+      d.m = __builtin_bit_cast(bf16x8, (u32x4){mw[q][0], mw[q][1], mw[q][2], mw[q][3]});
+      d.l = __builtin_bit_cast(bf16x8, (u32x4){lw[q][0], lw[q][1], lw[q][2], lw[q][3]});
+    }
+  };
+  // unit 0: its weights came with the cross-layer prefetch; it is cut by compiler-scheduled code (no MFMAs to hide it behind yet)
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) p0.b[ni][pl] = PB.b[ni][pl];
+    r0.f[ni][0] = PB.f[2 + ni][0]; r0.f[ni][1] = PB.f[2 + ni][1];
+  }
+  r0.a[0] = *reinterpret_cast<const float4*>(ap);
+  r0.a[1] = *reinterpret_cast<const float4*>(ap + 32 * FLD);
+  r0.a[2] = *reinterpret_cast<const float4*>(ap + 4);
+  r0.a[3] = *reinterpret_cast<const float4*>(ap + 32 * FLD + 4);
+  load_raw(r1, min(1, ulast));
+  c0.sa[0] = split8(r0.a[0], r0.a[2]);
+  c0.sa[1] = split8(r0.a[1], r0.a[3]);
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) c0.sb[ni] = split8(r0.f[ni][0], r0.f[ni][1]);
+  for (int u = 0; u < nu; u += 2) {
+    // MFMAs of unit u, cut of unit u+1; on the way: terms of unit u+1 (operands of the next half-step), fp32 of unit u+2 (cut there)
+    step(c0, p0, r1, c1, p1, min(u + 1, ulast), r0, min(u + 2, ulast));
+    if (u + 1 >= nu) break;
+    step(c1, p1, r0, c0, p0, min(u + 2, ulast), r1, min(u + 3, ulast));
+  }
+}
+
 // what a body needs from the k-loop, in either mode: the carried prefetch set, the prefetch, the loop
 template <bool SPLIT> struct KlSets { typedef FusedBSets type; };
 template <> struct KlSets<true> { typedef SplitBSet type; };
@@ -552,7 +712,11 @@ __device__ __forceinline__ void fused_kloop_dispatch(f32x16 (&acc)[2][4], const 
   if constexpr (SPLIT) {
     const SplitBView bv = split_bview(wf, wplane, wf32, U, w, lane);
     switch (nact) {
+#if SPLIT_ASM
+      case 4: fused_kloop_split_asm4(acc, ap, bv, nu, PB); break;
+#else
       case 4: fused_kloop_split<4>(acc, ap, bv, nu, PB); break;
+#endif
       case 3: fused_kloop_split<3>(acc, ap, bv, nu, PB); break;
       case 2: fused_kloop_split<2>(acc, ap, bv, nu, PB); break;
       case 1: fused_kloop_split<1>(acc, ap, bv, nu, PB); break;
