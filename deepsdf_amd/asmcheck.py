@@ -6,8 +6,8 @@ window.  The compiler cannot see loads inside asm, so BETWEEN the two statements
 an AGPR move or a spill of one of them placed there would read stale registers.  Whether it does that is a register-allocation
 outcome -- so every build of the library (lab flags included) is checked on the gfx950 code object itself:
 
-  for each ``s_waitcnt lgkmcnt(8)`` preceded by 16 ds_read_b128: no instruction up to the next ``s_waitcnt lgkmcnt(0)`` may
-  name a destination VGPR of the last eight reads, and none may touch scratch (a spill in the window).
+  for each run of 16 ds_read_b128 whose statement leaves reads in flight: no instruction up to the next ``s_waitcnt lgkmcnt(0)``
+  may name a destination VGPR of those reads, and none may touch scratch (a spill in the window).
 
 Tooling only (no GPU, no torch): ``python -m deepsdf_amd.asmcheck [lib]``; deepsdf_amd.build runs it after every compile.
 """
@@ -63,20 +63,28 @@ def vgprs(operands):
 
 
 def check_split_wait_windows(ins):
-    """Returns the number of windows checked; raises AsmHazard on a violation."""
+    """Returns the number of windows checked; raises AsmHazard on a violation.  A window opens behind a run of 16 ds_read_b128
+    (the fragment reads of dwstream.hpp) that is not closed by an ``s_waitcnt lgkmcnt(0)`` at once, and extends to the next
+    ``s_waitcnt lgkmcnt(0)``: directly behind the reads either ``lgkmcnt(8)`` (dw_block_split_v1: the first eight have landed, the
+    last eight are in flight) or nothing (dw_block_split: all sixteen are in flight)."""
     windows = 0
     for i, (op, args) in enumerate(ins):
-        if op != "s_waitcnt" or "lgkmcnt(8)" not in args:
+        if i < 16 or ins[i - 1][0] != "ds_read_b128" or op == "ds_read_b128":
             continue
         reads = ins[i - 16:i]
-        if len(reads) != 16 or any(o != "ds_read_b128" for o, _ in reads):
-            continue                       # some other lgkmcnt(8) of the compiler's own: not the asm window
+        if any(o != "ds_read_b128" for o, _ in reads):
+            continue
+        if op == "s_waitcnt" and "lgkmcnt(0)" in args:
+            continue                       # reads and their wait in one statement: no window
+        first_open = 8 if (op == "s_waitcnt" and "lgkmcnt(8)" in args) else 0
         in_flight = set()
-        for _, a in reads[8:]:
+        for _, a in reads[first_open:]:
             in_flight |= vgprs(a.split(",")[0])
-        if len(in_flight) != 32:
-            raise AsmHazard(f"window at instruction {i}: the eight B reads name {len(in_flight)} destination VGPRs, expected 32")
-        for j in range(i + 1, len(ins)):
+        if len(in_flight) != 4 * (16 - first_open):
+            raise AsmHazard(f"window at instruction {i}: the reads in flight name {len(in_flight)} destination VGPRs, "
+                            f"expected {4 * (16 - first_open)}")
+        start = i + 1 if first_open else i
+        for j in range(start, len(ins)):
             o, a = ins[j]
             if o == "s_waitcnt" and "lgkmcnt(0)" in a:
                 break
@@ -84,7 +92,7 @@ def check_split_wait_windows(ins):
                 raise AsmHazard(f"scratch traffic inside the split-wait window: {o} {a}")
             hit = vgprs(a) & in_flight
             if hit:
-                raise AsmHazard(f"instruction {j} inside the split-wait window names B registers still in flight "
+                raise AsmHazard(f"instruction {j} inside the split-wait window names registers whose reads are still in flight "
                                 f"(v{sorted(hit)}): {o} {a}")
             if o in ("s_endpgm", "s_branch", "s_cbranch_scc0", "s_cbranch_scc1", "s_cbranch_vccz", "s_cbranch_vccnz",
                      "s_cbranch_execz", "s_cbranch_execnz", "s_setpc_b64"):
@@ -102,7 +110,7 @@ def check_library(lib, expect_windows=True):
         ins = disassemble(extract_code_object(lib, d), KERNEL)
     n = check_split_wait_windows(ins)
     if expect_windows and n == 0:
-        raise AsmHazard(f"{KERNEL}: no split-wait window found (16 ds_read_b128 + s_waitcnt lgkmcnt(8)); the check would be vacuous")
+        raise AsmHazard(f"{KERNEL}: no split-wait window found (16 ds_read_b128 left in flight); the check would be vacuous")
     return n
 
 

@@ -180,18 +180,7 @@ __device__ __forceinline__ Split3 split8v(const float (&x)[8]) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   uint32_t hw[4], mw[4], lw[4];
 #pragma unroll
-  for (int pr = 0; pr < 4; ++pr) {
-    float r[2], t[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const float v = x[2 * pr + e];
-      r[e] = v - __uint_as_float(__float_as_uint(v) & 0xFFFF0000u);
-      t[e] = r[e] - __uint_as_float(__float_as_uint(r[e]) & 0xFFFF0000u);
-    }
-    hw[pr] = __builtin_amdgcn_perm(__float_as_uint(x[2 * pr + 1]), __float_as_uint(x[2 * pr]), 0x07060302u);
-    mw[pr] = __builtin_amdgcn_perm(__float_as_uint(r[1]), __float_as_uint(r[0]), 0x07060302u);
-    lw[pr] = __builtin_amdgcn_perm(__float_as_uint(t[1]), __float_as_uint(t[0]), 0x07060302u);
-  }
+  for (int pr = 0; pr < 4; ++pr) cut_pair(x[2 * pr], x[2 * pr + 1], hw[pr], mw[pr], lw[pr]);      // (fused.hpp: round-to-nearest terms)
   Split3 s;
   s.h = __builtin_bit_cast(bf16x8, (u32x4){hw[0], hw[1], hw[2], hw[3]});
   s.m = __builtin_bit_cast(bf16x8, (u32x4){mw[0], mw[1], mw[2], mw[3]});
@@ -200,7 +189,7 @@ __device__ __forceinline__ Split3 split8v(const float (&x)[8]) {
 }
 
 // the workgroup's block: row tiles tmb, tmb + 1 and column tiles tnb, tnb + 1 of `split`; wave w takes (tmb + (w >> 1), tnb + (w & 1))
-__device__ __forceinline__ void dw_block_split(const DwLayer& L, int split, int tmb, int tnb, int kbeg, int kend, int w, int lane, float* ring) {
+__device__ __forceinline__ void dw_block_split_v1(const DwLayer& L, int split, int tmb, int tnb, int kbeg, int kend, int w, int lane, float* ring) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   typedef __attribute__((address_space(3))) void* lds_ptr;
   const int fr = lane & 31, fh = lane >> 5;
@@ -307,6 +296,173 @@ __device__ __forceinline__ void dw_block_split(const DwLayer& L, int split, int 
     }
 }
 
+// ---- the same block with the cut woven between the MFMAs (DW_SPLIT_WEAVE, default) ----------------------------------------------------
+// dw_block_split_v1 above runs a step as  [16 LDS reads] [cut A: 176 VALU] [per column: cut B, 24 MFMAs]: a lone in-order wave overlaps
+// none of the cut with its MFMAs (tools/lab/split_weave.hip: 11 VALU in front of 3 MFMAs = 140 cycles, woven between them 101-112), the
+// kernel sat at 60 % MFMA-busy.  Here the step is software-pipelined by one step and written as 32 asm groups (fused.hpp SPLIT_GROUP:
+// MFMA, 4 VALU, MFMA, 4 VALU, MFMA, 3 VALU), the MFMAs of step st woven with the cut of what comes next:
+//   column block j (24 MFMAs = 8 groups):  groups 0-3 cut column (j + 1) of the B operand (column 0 of step st + 1 in block 3),
+//                                          groups 4-7 cut row tile j of the A operand of step st + 1
+// so every term is cut one block / one step before its first MFMA.  Registers: two sets of A terms (this step's / the next's, 2 x 48),
+// two of one B column (2 x 12), the raw A rows of the next step (32) and the raw B rows of this and the next step (2 x 32).
+// The raw rows of step st + 1 are read from the LDS ring at the top of step st (16 ds_read_b128 in one asm statement); their first use
+// is group 4, which opens with the s_waitcnt lgkmcnt(0) -- groups 0-3 run in that window and name none of the 64 destination
+// registers (deepsdf_amd/asmcheck.py checks exactly that on every build's code object).
+#ifndef DW_SPLIT_WEAVE
+#define DW_SPLIT_WEAVE 1
+#endif
+typedef float dw_f32x4 __attribute__((ext_vector_type(4)));
+template <int J> __device__ __forceinline__ float dw_comp(const dw_f32x4& v) { return J == 0 ? v.x : (J == 1 ? v.y : (J == 2 ? v.z : v.w)); }
+struct DwRaw { dw_f32x4 v[8]; };                 // 8 points x 4 consecutive columns of one operand panel
+
+__device__ __forceinline__ void dw_block_split(const DwLayer& L, int split, int tmb, int tnb, int kbeg, int kend, int w, int lane, float* ring) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef __attribute__((address_space(3))) const float* lds_cf;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int npts = kend - kbeg, nsteps = (npts + 15) >> 4;      // steps of 16 points (uniform over the workgroup)
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(L.dp + (size_t)kbeg * L.ld_dp), 0, npts * L.ld_dp * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(L.act + (size_t)kbeg * L.ld_act), 0, npts * L.ld_act * 4, 0x00020000);
+  const int pva = (tmb * 128 + 4 * lane) * 4, pvb = (tnb * 128 + 4 * lane) * 4;
+  auto issue = [&](int st) __attribute__((always_inline)) {     // this wave brings rows 4w .. 4w+3 of step st's two panels (see v1)
+    float* slot = ring + (st % DWS_RING) * DWS_SLOT;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row = 4 * w + rr, pt = 16 * st + row;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(slot + row * 256), 16, pt * L.ld_dp * 4 + pva, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(slot + 4096 + row * 256), 16, pt * L.ld_act * 4 + pvb, 0, 0, 0);
+    }
+  };
+  const int ca = (w >> 1) * 128 + 4 * fr, cb = 4096 + (w & 1) * 128 + 4 * fr;
+  // 16 fragment reads of one step's slot -> raw A, raw B.  WAIT = 1: the statement ends in lgkmcnt(0); WAIT = 0: the reads stay in
+  // flight, the caller's next DW_WAIT_LGKM closes the window (nothing in between may name a.v[] / b.v[])
+#define DW_READ_RAW(ST, A, B, WAITSTR)                                                                                              \
+  {                                                                                                                                 \
+    const float* slot_ = ring + ((ST) % DWS_RING) * DWS_SLOT;                                                                       \
+    const uint32_t aa_ = (uint32_t)(uintptr_t)(lds_cf)(slot_ + 8 * fh * 256 + ca), ab_ = (uint32_t)(uintptr_t)(lds_cf)(slot_ + 8 * fh * 256 + cb); \
+    asm volatile(                                                                                                                   \
+        "ds_read_b128 %0, %16\n ds_read_b128 %1, %16 offset:1024\n ds_read_b128 %2, %16 offset:2048\n ds_read_b128 %3, %16 offset:3072\n" \
+        "ds_read_b128 %4, %16 offset:4096\n ds_read_b128 %5, %16 offset:5120\n ds_read_b128 %6, %16 offset:6144\n ds_read_b128 %7, %16 offset:7168\n" \
+        "ds_read_b128 %8, %17\n ds_read_b128 %9, %17 offset:1024\n ds_read_b128 %10, %17 offset:2048\n ds_read_b128 %11, %17 offset:3072\n" \
+        "ds_read_b128 %12, %17 offset:4096\n ds_read_b128 %13, %17 offset:5120\n ds_read_b128 %14, %17 offset:6144\n ds_read_b128 %15, %17 offset:7168\n" \
+        WAITSTR                                                                                                                     \
+        : "=&v"((A).v[0]), "=&v"((A).v[1]), "=&v"((A).v[2]), "=&v"((A).v[3]), "=&v"((A).v[4]), "=&v"((A).v[5]), "=&v"((A).v[6]), "=&v"((A).v[7]), \
+          "=&v"((B).v[0]), "=&v"((B).v[1]), "=&v"((B).v[2]), "=&v"((B).v[3]), "=&v"((B).v[4]), "=&v"((B).v[5]), "=&v"((B).v[6]), "=&v"((B).v[7])  \
+        : "v"(aa_), "v"(ab_)                                                                                                        \
+        : "memory");                                                                                                                \
+  }
+#define DW_WAIT_LGKM(A, B)                                                                                                          \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                                               \
+               : "+v"((A).v[0]), "+v"((A).v[1]), "+v"((A).v[2]), "+v"((A).v[3]), "+v"((A).v[4]), "+v"((A).v[5]), "+v"((A).v[6]), "+v"((A).v[7]), \
+                 "+v"((B).v[0]), "+v"((B).v[1]), "+v"((B).v[2]), "+v"((B).v[3]), "+v"((B).v[4]), "+v"((B).v[5]), "+v"((B).v[6]), "+v"((B).v[7]));
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+  for (int st = 0; st < DWS_RING - 1; ++st) issue(st);      // (steps past the end: every row out of range, zeros land in LDS)
+
+  DwRaw an, b0, b1;                    // raw A of the next step; raw B of the even / odd steps
+  Split3 sa0[4], sa1[4], sb0, sb1;     // A terms of the even / odd steps; one B column's terms, alternating
+  // prologue = "step -1": the raw rows of step 0, their A terms and the terms of B column 0, cut by compiler-scheduled code
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (((8 * (DWS_RING - 2)) & 15)) | ((((8 * (DWS_RING - 2)) >> 4) & 3) << 14));   // vmcnt(16): step 0 has landed
+  __builtin_amdgcn_s_barrier();
+  issue(DWS_RING - 1);
+  DW_READ_RAW(0, an, b0, "s_waitcnt lgkmcnt(0)")
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = i == 0 ? an.v[k].x : (i == 1 ? an.v[k].y : (i == 2 ? an.v[k].z : an.v[k].w));
+    sa0[i] = split8v(x);
+  }
+  {
+    float x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = b0.v[k].x;
+    sb0 = split8v(x);
+  }
+  // one group: MFMAs 3g .. 3g+2 of the step (MFMA m: column m / 24, pass (m % 24) / 4 in the order l h, h l, m m, m h, h m, h h, row
+  // tile m % 4) + the cut of pair g: block j = g / 8; g % 8 < 4: pair g % 8 of B column (j + 1) % 4 (of BN in block 3, else of BC)
+  // -> sb[(j + 1) & 1]; else pair g % 8 - 4 of row tile j of AN -> SAN[j]
+#define DW_SA_OF(SAC, q_) (((q_) % 24) / 4 == 0 ? SAC[(q_) % 4].l : (((q_) % 24) / 4 == 2 || ((q_) % 24) / 4 == 3) ? SAC[(q_) % 4].m : SAC[(q_) % 4].h)
+#define DW_SBSEL(q_) ((((q_) / 24) & 1) ? sb1 : sb0)
+#define DW_SB_OF(q_) (((q_) % 24) / 4 == 1 ? DW_SBSEL(q_).l : (((q_) % 24) / 4 == 2 || ((q_) % 24) / 4 == 4) ? DW_SBSEL(q_).m : DW_SBSEL(q_).h)
+#define DW_X(g, e, AN, BC, BN)                                                                                                       \
+  (((g) % 8) < 4 ? dw_comp<(((g) / 8) + 1) % 4>(((g) / 8) == 3 ? (BN).v[2 * ((g) % 8) + (e)] : (BC).v[2 * ((g) % 8) + (e)])            \
+                 : dw_comp<(g) / 8>((AN).v[2 * (((g) % 8) - 4) + (e)]))
+#define DW_G(g, SAC, AN, BC, BN)                                                                                                     \
+  SPLIT_GROUP(acc[(3 * (g)) % 4][(3 * (g)) / 24], DW_SA_OF(SAC, 3 * (g)), DW_SB_OF(3 * (g)),                                             \
+              acc[(3 * (g) + 1) % 4][(3 * (g) + 1) / 24], DW_SA_OF(SAC, 3 * (g) + 1), DW_SB_OF(3 * (g) + 1),                             \
+              acc[(3 * (g) + 2) % 4][(3 * (g) + 2) / 24], DW_SA_OF(SAC, 3 * (g) + 2), DW_SB_OF(3 * (g) + 2),                             \
+              DW_X(g, 0, AN, BC, BN), DW_X(g, 1, AN, BC, BN), hw_[(g) / 4][(g) % 4], mw_[(g) / 4][(g) % 4], lw_[(g) / 4][(g) % 4])
+  // after the 4 groups that cut one B column / one A row tile: assemble the terms (register renaming, no instructions)
+#define DW_PACK(DST, q)                                                                                                              \
+  DST.h = __builtin_bit_cast(bf16x8, (u32x4){hw_[q][0], hw_[q][1], hw_[q][2], hw_[q][3]});                                           \
+  DST.m = __builtin_bit_cast(bf16x8, (u32x4){mw_[q][0], mw_[q][1], mw_[q][2], mw_[q][3]});                                           \
+  DST.l = __builtin_bit_cast(bf16x8, (u32x4){lw_[q][0], lw_[q][1], lw_[q][2], lw_[q][3]});
+  // one step: SAC = this step's A terms, SAN = the next step's (written here), BC = this step's raw B, BN = the next step's (read here)
+#define DW_STEP(ST, SAC, SAN, BC, BN)                                                                                                \
+  {                                                                                                                                 \
+    uint32_t hw_[8][4], mw_[8][4], lw_[8][4];                                                                                       \
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (((8 * (DWS_RING - 2)) & 15)) | ((((8 * (DWS_RING - 2)) >> 4) & 3) << 14)); /* vmcnt(16): step ST + 1 has landed */ \
+    __builtin_amdgcn_s_barrier();          /* ... for every wave; everybody has finished reading the slot of step ST */               \
+    issue((ST) + DWS_RING);                /* ... which takes step ST + 4 */                                                          \
+    DW_READ_RAW((ST) + 1, an, BN, "")      /* window: open until DW_WAIT_LGKM below */                                                \
+    DW_G(0, SAC, an, BC, BN) DW_G(1, SAC, an, BC, BN) DW_G(2, SAC, an, BC, BN) DW_G(3, SAC, an, BC, BN)                               \
+    DW_PACK(sb1, 0)                                                                                                                  \
+    DW_WAIT_LGKM(an, BN)                                                                                                             \
+    DW_G(4, SAC, an, BC, BN) DW_G(5, SAC, an, BC, BN) DW_G(6, SAC, an, BC, BN) DW_G(7, SAC, an, BC, BN)                               \
+    DW_PACK(SAN[0], 1)                                                                                                               \
+    DW_G(8, SAC, an, BC, BN) DW_G(9, SAC, an, BC, BN) DW_G(10, SAC, an, BC, BN) DW_G(11, SAC, an, BC, BN)                             \
+    DW_PACK(sb0, 2)                                                                                                                  \
+    DW_G(12, SAC, an, BC, BN) DW_G(13, SAC, an, BC, BN) DW_G(14, SAC, an, BC, BN) DW_G(15, SAC, an, BC, BN)                           \
+    DW_PACK(SAN[1], 3)                                                                                                               \
+    DW_G(16, SAC, an, BC, BN) DW_G(17, SAC, an, BC, BN) DW_G(18, SAC, an, BC, BN) DW_G(19, SAC, an, BC, BN)                           \
+    DW_PACK(sb1, 4)                                                                                                                  \
+    DW_G(20, SAC, an, BC, BN) DW_G(21, SAC, an, BC, BN) DW_G(22, SAC, an, BC, BN) DW_G(23, SAC, an, BC, BN)                           \
+    DW_PACK(SAN[2], 5)                                                                                                               \
+    DW_G(24, SAC, an, BC, BN) DW_G(25, SAC, an, BC, BN) DW_G(26, SAC, an, BC, BN) DW_G(27, SAC, an, BC, BN)                           \
+    DW_PACK(sb0, 6)                                                                                                                  \
+    DW_G(28, SAC, an, BC, BN) DW_G(29, SAC, an, BC, BN) DW_G(30, SAC, an, BC, BN) DW_G(31, SAC, an, BC, BN)                           \
+    DW_PACK(SAN[3], 7)                                                                                                               \
+  }
+  for (int st = 0; st < nsteps; st += 2) {
+    DW_STEP(st, sa0, sa1, b0, b1)
+    if (st + 1 >= nsteps) break;
+    DW_STEP(st + 1, sa1, sa0, b1, b0)
+  }
+#undef DW_STEP
+#undef DW_PACK
+#undef DW_G
+#undef DW_X
+#undef DW_SB_OF
+#undef DW_SBSEL
+#undef DW_SA_OF
+#undef DW_WAIT_LGKM
+#undef DW_READ_RAW
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the loads issued past the last step have landed ...
+  __syncthreads();                         // ... before anybody reuses the ring
+  // epilogue: acc[i][j][reg] = dW[m0 + 4 (crow(reg) + 4 fh) + i][n0 + 4 fr + j]  ->  one 16-byte store per (i, reg)
+  const int m0 = (tmb + (w >> 1)) * 128, n0 = (tnb + (w & 1)) * 128;
+  float* slab = L.slabs + (size_t)split * L.slab;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)slab, 0, L.M * L.ldc * 4, 0x00020000);
+  const int n = n0 + 4 * fr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) {
+      const int m = m0 + 4 * (crow(rg) + 4 * fh) + i;       // rows >= M fall outside the descriptor and are dropped
+      const uint32_t voff = n < L.ldc ? (uint32_t)((m * L.ldc + n) * 4) : 0x7FFFFFFFu;   // ldc % 4 == 0
+      u32x4 v = {__float_as_uint(acc[i][0][rg]), __float_as_uint(acc[i][1][rg]), __float_as_uint(acc[i][2][rg]),
+                 __float_as_uint(acc[i][3][rg])};
+      __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, 0, 0);
+    }
+}
+
 // `busy_wg` workgroups (= ceil(items / 4)) stream the dW tiles; the launch covers the whole chip, and the workgroups beyond
 // them -- the items never fill it exactly (96 tiles x 10 splits = 960 of 1024 waves for the 8x512 net) -- work through
 // the post-backward roles of kernels.hpp (head partials, x0 columns of dW, per-segment latent gradient) meanwhile, so
@@ -339,7 +495,11 @@ __device__ __forceinline__ void dw_stream_body(const DwArgs& p, const PostBwdArg
       if (block) {
         const int split = local0 / tf0, b = (local0 - split * tf0) >> 2, nbn = L0.nfull_n >> 1;
         const int kbeg = split * L0.kchunk;
+#if DW_SPLIT_WEAVE
         dw_block_split(L0, split, 2 * (b / nbn), 2 * (b % nbn), kbeg, min(p.N, kbeg + L0.kchunk), w, lane, ring);
+#else
+        dw_block_split_v1(L0, split, 2 * (b / nbn), 2 * (b % nbn), kbeg, min(p.N, kbeg + L0.kchunk), w, lane, ring);
+#endif
         continue;
       }
     }

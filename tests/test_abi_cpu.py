@@ -217,6 +217,12 @@ def test_split_wait_window_of_the_dw_split_kernel_is_clean():
             asmcheck.check_split_wait_windows(reads + [("s_waitcnt", "lgkmcnt(8)")] + body + [bad] + close)
     with pytest.raises(asmcheck.AsmHazard):                                # a window that is never closed
         asmcheck.check_split_wait_windows(reads + [("s_waitcnt", "lgkmcnt(8)")] + body)
+    # the woven block leaves all sixteen reads in flight: A registers (v16..v47) are protected too; MFMAs on other registers may run
+    mf = ("v_mfma_f32_32x32x16_bf16", "a[0:15], v[100:103], v[104:107], a[0:15]")
+    assert asmcheck.check_split_wait_windows(reads + [mf, ("v_sub_f32_e32", "v2, v3, v4")] + close) == 1
+    with pytest.raises(asmcheck.AsmHazard):
+        asmcheck.check_split_wait_windows(reads + [mf, ("v_and_b32_e32", "v0, 0xffff0000, v16")] + close)
+    assert asmcheck.check_split_wait_windows(reads + close) == 0             # reads + wait in one statement: no window at all
     assert asmcheck.vgprs("a[0:15], v[4:7], v9, s[0:3], 0xff, v12 offset:16") == {4, 5, 6, 7, 9, 12}
     if not asmcheck.tools_available() or not os.path.exists(LIB):
         pytest.skip("ROCm LLVM tools or the built library are not available")

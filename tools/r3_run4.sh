@@ -1,6 +1,6 @@
 # round 3, GPU call 4: the asm-woven split k-loop: parity (gemm_split tests) + speed against the compiler-scheduled loop
 R=$GRAFT_REPO_ROOT; cd $R
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -q -s -k "gemm_split or shipped_experiment" > gpurun_out/r3_t4.log 2>&1
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -q -s -k "gemm_split or shipped_experiment or two_phase" > gpurun_out/r3_t4.log 2>&1
 rc=$?; grep -E "gemm_split|passed|failed|Error|error" gpurun_out/r3_t4.log | tail -30
 [ $rc -le 1 ] || exit 1
 for round in 1 2; do bash tools/lab_split.sh; done 2>&1 | tee gpurun_out/r3_asm_ab.log
