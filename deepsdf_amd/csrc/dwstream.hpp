@@ -333,6 +333,21 @@ __device__ __forceinline__ void dw_block_split(const DwLayer& L, int split, int 
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(slot + 4096 + row * 256), 16, pt * L.ld_act * 4 + pvb, 0, 0, 0);
     }
   };
+  // the same, one row pair at a time and pinned behind the asm group in front of it (the row number passes through an empty
+  // volatile asm): inside the loop the 8 DMA instructions of a step go out between the MFMA groups instead of as a cluster at the
+  // top of the step, where each of them costs the idle MFMA pipe ~100 cycles (MI355X_MICROARCH.md: LDS-DMA issue cost)
+  // (the two row strides are made opaque once: left as kernel-argument loads the compiler re-fetches them -- s_load + s_waitcnt
+  // lgkmcnt(0), a full stall of the lone wave -- at every one of the four issue points of a step)
+  int lda4 = L.ld_dp * 4, ldb4 = L.ld_act * 4;
+  asm volatile("" : "+s"(lda4), "+s"(ldb4));
+  auto issue_row = [&](int st, int rr) __attribute__((always_inline)) {
+    float* slot = ring + (st % DWS_RING) * DWS_SLOT;
+    int row = 4 * w + rr;
+    asm volatile("" : "+s"(row));
+    const int pt = 16 * st + row;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(slot + row * 256), 16, pt * lda4 + pva, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(slot + 4096 + row * 256), 16, pt * ldb4 + pvb, 0, 0, 0);
+  };
   const int ca = (w >> 1) * 128 + 4 * fr, cb = 4096 + (w & 1) * 128 + 4 * fr;
   // 16 fragment reads of one step's slot -> raw A, raw B.  WAIT = 1: the statement ends in lgkmcnt(0); WAIT = 0: the reads stay in
   // flight, the caller's next DW_WAIT_LGKM closes the window (nothing in between may name a.v[] / b.v[])
@@ -409,23 +424,23 @@ __device__ __forceinline__ void dw_block_split(const DwLayer& L, int split, int 
   {                                                                                                                                 \
     uint32_t hw_[8][4], mw_[8][4], lw_[8][4];                                                                                       \
     __builtin_amdgcn_s_waitcnt(0x0F70 | (((8 * (DWS_RING - 2)) & 15)) | ((((8 * (DWS_RING - 2)) >> 4) & 3) << 14)); /* vmcnt(16): step ST + 1 has landed */ \
-    __builtin_amdgcn_s_barrier();          /* ... for every wave; everybody has finished reading the slot of step ST */               \
-    issue((ST) + DWS_RING);                /* ... which takes step ST + 4 */                                                          \
+    __builtin_amdgcn_s_barrier();          /* ... for every wave; everybody has finished reading the slot of step ST, which takes */    \
+                                           /* step ST + 4: its 8 DMA rows go out behind groups 9, 15, 21, 27 (all before the next top) */ \
     DW_READ_RAW((ST) + 1, an, BN, "")      /* window: open until DW_WAIT_LGKM below */                                                \
     DW_G(0, SAC, an, BC, BN) DW_G(1, SAC, an, BC, BN) DW_G(2, SAC, an, BC, BN) DW_G(3, SAC, an, BC, BN)                               \
     DW_PACK(sb1, 0)                                                                                                                  \
     DW_WAIT_LGKM(an, BN)                                                                                                             \
     DW_G(4, SAC, an, BC, BN) DW_G(5, SAC, an, BC, BN) DW_G(6, SAC, an, BC, BN) DW_G(7, SAC, an, BC, BN)                               \
     DW_PACK(SAN[0], 1)                                                                                                               \
-    DW_G(8, SAC, an, BC, BN) DW_G(9, SAC, an, BC, BN) DW_G(10, SAC, an, BC, BN) DW_G(11, SAC, an, BC, BN)                             \
+    DW_G(8, SAC, an, BC, BN) DW_G(9, SAC, an, BC, BN) issue_row((ST) + DWS_RING, 0); DW_G(10, SAC, an, BC, BN) DW_G(11, SAC, an, BC, BN)                             \
     DW_PACK(sb0, 2)                                                                                                                  \
-    DW_G(12, SAC, an, BC, BN) DW_G(13, SAC, an, BC, BN) DW_G(14, SAC, an, BC, BN) DW_G(15, SAC, an, BC, BN)                           \
+    DW_G(12, SAC, an, BC, BN) DW_G(13, SAC, an, BC, BN) DW_G(14, SAC, an, BC, BN) DW_G(15, SAC, an, BC, BN) issue_row((ST) + DWS_RING, 1);                           \
     DW_PACK(SAN[1], 3)                                                                                                               \
     DW_G(16, SAC, an, BC, BN) DW_G(17, SAC, an, BC, BN) DW_G(18, SAC, an, BC, BN) DW_G(19, SAC, an, BC, BN)                           \
     DW_PACK(sb1, 4)                                                                                                                  \
-    DW_G(20, SAC, an, BC, BN) DW_G(21, SAC, an, BC, BN) DW_G(22, SAC, an, BC, BN) DW_G(23, SAC, an, BC, BN)                           \
+    DW_G(20, SAC, an, BC, BN) DW_G(21, SAC, an, BC, BN) issue_row((ST) + DWS_RING, 2); DW_G(22, SAC, an, BC, BN) DW_G(23, SAC, an, BC, BN)                           \
     DW_PACK(SAN[2], 5)                                                                                                               \
-    DW_G(24, SAC, an, BC, BN) DW_G(25, SAC, an, BC, BN) DW_G(26, SAC, an, BC, BN) DW_G(27, SAC, an, BC, BN)                           \
+    DW_G(24, SAC, an, BC, BN) DW_G(25, SAC, an, BC, BN) DW_G(26, SAC, an, BC, BN) DW_G(27, SAC, an, BC, BN) issue_row((ST) + DWS_RING, 3);                           \
     DW_PACK(sb0, 6)                                                                                                                  \
     DW_G(28, SAC, an, BC, BN) DW_G(29, SAC, an, BC, BN) DW_G(30, SAC, an, BC, BN) DW_G(31, SAC, an, BC, BN)                           \
     DW_PACK(SAN[3], 7)                                                                                                               \
