@@ -400,50 +400,76 @@ __device__ __forceinline__ void dw_block_split(const DwLayer& L, int split, int 
     for (int k = 0; k < 8; ++k) x[k] = b0.v[k].x;
     sb0 = split8v(x);
   }
-  // one group: MFMAs 3g .. 3g+2 of the step (MFMA m: column m / 24, pass (m % 24) / 4 in the order l h, h l, m m, m h, h m, h h, row
-  // tile m % 4) + the cut of pair g: block j = g / 8; g % 8 < 4: pair g % 8 of B column (j + 1) % 4 (of BN in block 3, else of BC)
-  // -> sb[(j + 1) & 1]; else pair g % 8 - 4 of row tile j of AN -> SAN[j]
-#define DW_SA_OF(SAC, q_) (((q_) % 24) / 4 == 0 ? SAC[(q_) % 4].l : (((q_) % 24) / 4 == 2 || ((q_) % 24) / 4 == 3) ? SAC[(q_) % 4].m : SAC[(q_) % 4].h)
+  // one group: MFMAs 3g .. 3g+2 of the step (MFMA q: column q / 24, pass (q % 24) / 4 in the order h h, h m, m h, m m, h l, l h
+  // (A term, B term: big terms first), row tile q % 4) + one link of the cut chain, software-pipelined over three groups (fused.hpp
+  // SPLIT_GROUP_P): stage 1 of pair g, stage 2 of pair g - 1, stage 3 of pair g - 2.  Pair g: block j = g / 8; g % 8 < 4: pair g % 8 of
+  // B column (j + 1) % 4 (of BN in block 3, else of BC); else pair g % 8 - 4 of row tile j of AN.  The last three words of a step's chain
+  // (m of pair 31, l of pairs 30, 31 = words of the NEXT step's A terms of row tile 3) come out of the next step's groups 0 and 1,
+  // early enough because a column's m terms are operands from its 9th MFMA on and its l terms from its 17th.
+#define DW_SA_OF(SAC, q_) (((q_) % 24) / 4 == 5 ? SAC[(q_) % 4].l : (((q_) % 24) / 4 == 2 || ((q_) % 24) / 4 == 3) ? SAC[(q_) % 4].m : SAC[(q_) % 4].h)
 #define DW_SBSEL(q_) ((((q_) / 24) & 1) ? sb1 : sb0)
-#define DW_SB_OF(q_) (((q_) % 24) / 4 == 1 ? DW_SBSEL(q_).l : (((q_) % 24) / 4 == 2 || ((q_) % 24) / 4 == 4) ? DW_SBSEL(q_).m : DW_SBSEL(q_).h)
+#define DW_SB_OF(q_) (((q_) % 24) / 4 == 4 ? DW_SBSEL(q_).l : (((q_) % 24) / 4 == 1 || ((q_) % 24) / 4 == 3) ? DW_SBSEL(q_).m : DW_SBSEL(q_).h)
 #define DW_X(g, e, AN, BC, BN)                                                                                                       \
   (((g) % 8) < 4 ? dw_comp<(((g) / 8) + 1) % 4>(((g) / 8) == 3 ? (BN).v[2 * ((g) % 8) + (e)] : (BC).v[2 * ((g) % 8) + (e)])            \
                  : dw_comp<(g) / 8>((AN).v[2 * (((g) % 8) - 4) + (e)]))
-#define DW_G(g, SAC, AN, BC, BN)                                                                                                     \
-  SPLIT_GROUP(acc[(3 * (g)) % 4][(3 * (g)) / 24], DW_SA_OF(SAC, 3 * (g)), DW_SB_OF(3 * (g)),                                             \
-              acc[(3 * (g) + 1) % 4][(3 * (g) + 1) / 24], DW_SA_OF(SAC, 3 * (g) + 1), DW_SB_OF(3 * (g) + 1),                             \
-              acc[(3 * (g) + 2) % 4][(3 * (g) + 2) / 24], DW_SA_OF(SAC, 3 * (g) + 2), DW_SB_OF(3 * (g) + 2),                             \
-              DW_X(g, 0, AN, BC, BN), DW_X(g, 1, AN, BC, BN), hw_[(g) / 4][(g) % 4], mw_[(g) / 4][(g) % 4], lw_[(g) / 4][(g) % 4])
-  // after the 4 groups that cut one B column / one A row tile: assemble the terms (register renaming, no instructions)
+#define DW_MFMAS(g, SAC)                                                                                                             \
+  acc[(3 * (g)) % 4][(3 * (g)) / 24], DW_SA_OF(SAC, 3 * (g)), DW_SB_OF(3 * (g)),                                                        \
+  acc[(3 * (g) + 1) % 4][(3 * (g) + 1) / 24], DW_SA_OF(SAC, 3 * (g) + 1), DW_SB_OF(3 * (g) + 1),                                        \
+  acc[(3 * (g) + 2) % 4][(3 * (g) + 2) / 24], DW_SA_OF(SAC, 3 * (g) + 2), DW_SB_OF(3 * (g) + 2)
+  // even g: stage 1 -> (ra0, ra1), stage 2 on (rb0, rb1), stage 3 on (ta0, ta1); odd g the other way round (see fused.hpp)
+#define DW_GE(g, SAC, AN, BC, BN, M_, L_)                                                                                            \
+  SPLIT_GROUP_P(DW_MFMAS(g, SAC), DW_X(g, 0, AN, BC, BN), DW_X(g, 1, AN, BC, BN), hw_[(g) / 4][(g) % 4], ra0, ra1, rb0, rb1, M_, ta0, ta1, L_) \
+  tb0 = rb0; tb1 = rb1;
+#define DW_GO(g, SAC, AN, BC, BN, M_, L_)                                                                                            \
+  SPLIT_GROUP_P(DW_MFMAS(g, SAC), DW_X(g, 0, AN, BC, BN), DW_X(g, 1, AN, BC, BN), hw_[(g) / 4][(g) % 4], rb0, rb1, ra0, ra1, M_, tb0, tb1, L_) \
+  ta0 = ra0; ta1 = ra1;
+#define DW_MW(g) mw_[((g) - 1) / 4][((g) - 1) % 4]
+#define DW_LW(g) lw_[((g) - 2) / 4][((g) - 2) % 4]
+#define DW_G2(g, SAC, AN, BC, BN) DW_GE(g, SAC, AN, BC, BN, DW_MW(g), DW_LW(g)) DW_GO((g) + 1, SAC, AN, BC, BN, DW_MW((g) + 1), DW_LW((g) + 1))
+  // assemble the terms of one cut operand from its words (register renaming, no instructions)
 #define DW_PACK(DST, q)                                                                                                              \
   DST.h = __builtin_bit_cast(bf16x8, (u32x4){hw_[q][0], hw_[q][1], hw_[q][2], hw_[q][3]});                                           \
   DST.m = __builtin_bit_cast(bf16x8, (u32x4){mw_[q][0], mw_[q][1], mw_[q][2], mw_[q][3]});                                           \
   DST.l = __builtin_bit_cast(bf16x8, (u32x4){lw_[q][0], lw_[q][1], lw_[q][2], lw_[q][3]});
-  // one step: SAC = this step's A terms, SAN = the next step's (written here), BC = this step's raw B, BN = the next step's (read here)
+  // one step: SAC = this step's A terms (its row tile 3 still owed three words), SAN = the next step's (written here), BC = this
+  // step's raw B, BN = the next step's (read here).  The 8 DMA rows of step ST + 4 go out behind groups 9, 15, 21, 27.
 #define DW_STEP(ST, SAC, SAN, BC, BN)                                                                                                \
   {                                                                                                                                 \
-    uint32_t hw_[8][4], mw_[8][4], lw_[8][4];                                                                                       \
+    uint32_t hw_[8][4], mw_[8][4], lw_[8][4], mlate_, llate0_, llate1_;                                                             \
+    float ra0, ra1, rb0 = carry.r0, rb1 = carry.r1, ta0 = carry.t0, ta1 = carry.t1, tb0, tb1;                                       \
     __builtin_amdgcn_s_waitcnt(0x0F70 | (((8 * (DWS_RING - 2)) & 15)) | ((((8 * (DWS_RING - 2)) >> 4) & 3) << 14)); /* vmcnt(16): step ST + 1 has landed */ \
-    __builtin_amdgcn_s_barrier();          /* ... for every wave; everybody has finished reading the slot of step ST, which takes */    \
-                                           /* step ST + 4: its 8 DMA rows go out behind groups 9, 15, 21, 27 (all before the next top) */ \
+    __builtin_amdgcn_s_barrier();          /* ... for every wave; everybody has finished reading the slot of step ST, which takes step ST + 4 */ \
     DW_READ_RAW((ST) + 1, an, BN, "")      /* window: open until DW_WAIT_LGKM below */                                                \
-    DW_G(0, SAC, an, BC, BN) DW_G(1, SAC, an, BC, BN) DW_G(2, SAC, an, BC, BN) DW_G(3, SAC, an, BC, BN)                               \
-    DW_PACK(sb1, 0)                                                                                                                  \
-    DW_WAIT_LGKM(an, BN)                                                                                                             \
-    DW_G(4, SAC, an, BC, BN) DW_G(5, SAC, an, BC, BN) DW_G(6, SAC, an, BC, BN) DW_G(7, SAC, an, BC, BN)                               \
-    DW_PACK(SAN[0], 1)                                                                                                               \
-    DW_G(8, SAC, an, BC, BN) DW_G(9, SAC, an, BC, BN) issue_row((ST) + DWS_RING, 0); DW_G(10, SAC, an, BC, BN) DW_G(11, SAC, an, BC, BN)                             \
+    DW_GE(0, SAC, an, BC, BN, mlate_, llate0_)                                                                                       \
+    DW_GO(1, SAC, an, BC, BN, DW_MW(1), llate1_)                                                                                     \
+    SAC[3].m = bf16x8_set_word<3>(SAC[3].m, mlate_);                                                                                 \
+    SAC[3].l = bf16x8_set_word<3>(bf16x8_set_word<2>(SAC[3].l, llate0_), llate1_);                                                   \
+    DW_G2(2, SAC, an, BC, BN)                                                                                                        \
+    DW_WAIT_LGKM(an, BN)                   /* groups 0-3 cut pairs of BC only */                                                      \
+    DW_G2(4, SAC, an, BC, BN) DW_G2(6, SAC, an, BC, BN)                                                                              \
+    DW_PACK(sb1, 0)                        /* column 1: its last word came out of group 5 */                                          \
+    DW_GE(8, SAC, an, BC, BN, DW_MW(8), DW_LW(8)) DW_GO(9, SAC, an, BC, BN, DW_MW(9), DW_LW(9)) issue_row((ST) + DWS_RING, 0);        \
+    DW_G2(10, SAC, an, BC, BN) DW_G2(12, SAC, an, BC, BN)                                                                            \
+    DW_GE(14, SAC, an, BC, BN, DW_MW(14), DW_LW(14)) DW_GO(15, SAC, an, BC, BN, DW_MW(15), DW_LW(15)) issue_row((ST) + DWS_RING, 1); \
     DW_PACK(sb0, 2)                                                                                                                  \
-    DW_G(12, SAC, an, BC, BN) DW_G(13, SAC, an, BC, BN) DW_G(14, SAC, an, BC, BN) DW_G(15, SAC, an, BC, BN) issue_row((ST) + DWS_RING, 1);                           \
-    DW_PACK(SAN[1], 3)                                                                                                               \
-    DW_G(16, SAC, an, BC, BN) DW_G(17, SAC, an, BC, BN) DW_G(18, SAC, an, BC, BN) DW_G(19, SAC, an, BC, BN)                           \
+    DW_G2(16, SAC, an, BC, BN) DW_G2(18, SAC, an, BC, BN)                                                                            \
+    DW_GE(20, SAC, an, BC, BN, DW_MW(20), DW_LW(20)) DW_GO(21, SAC, an, BC, BN, DW_MW(21), DW_LW(21)) issue_row((ST) + DWS_RING, 2); \
+    DW_G2(22, SAC, an, BC, BN)                                                                                                       \
     DW_PACK(sb1, 4)                                                                                                                  \
-    DW_G(20, SAC, an, BC, BN) DW_G(21, SAC, an, BC, BN) issue_row((ST) + DWS_RING, 2); DW_G(22, SAC, an, BC, BN) DW_G(23, SAC, an, BC, BN)                           \
-    DW_PACK(SAN[2], 5)                                                                                                               \
-    DW_G(24, SAC, an, BC, BN) DW_G(25, SAC, an, BC, BN) DW_G(26, SAC, an, BC, BN) DW_G(27, SAC, an, BC, BN) issue_row((ST) + DWS_RING, 3);                           \
-    DW_PACK(sb0, 6)                                                                                                                  \
-    DW_G(28, SAC, an, BC, BN) DW_G(29, SAC, an, BC, BN) DW_G(30, SAC, an, BC, BN) DW_G(31, SAC, an, BC, BN)                           \
-    DW_PACK(SAN[3], 7)                                                                                                               \
+    DW_G2(24, SAC, an, BC, BN)                                                                                                       \
+    DW_GE(26, SAC, an, BC, BN, DW_MW(26), DW_LW(26)) DW_GO(27, SAC, an, BC, BN, DW_MW(27), DW_LW(27)) issue_row((ST) + DWS_RING, 3); \
+    DW_G2(28, SAC, an, BC, BN) DW_G2(30, SAC, an, BC, BN)                                                                            \
+    carry.r0 = rb0; carry.r1 = rb1; carry.t0 = ta0; carry.t1 = ta1;    /* owed: r of pair 31 (odd: rb), t of pair 30 */               \
+    mw_[7][3] = 0; lw_[7][2] = 0; lw_[7][3] = 0;                        /* (the next step's groups 0, 1 deliver these words) */        \
+    DW_PACK(sb0, 6) DW_PACK(SAN[0], 1) DW_PACK(SAN[1], 3) DW_PACK(SAN[2], 5) DW_PACK(SAN[3], 7)                                      \
+  }
+  // the chain's carry as if step 0's A terms had come out of the groups: r of its last pair, t of the one before (row tile 3, points 4-7)
+  SplitCarry carry;
+  {
+    uint32_t h_, m_, l_;
+    float d0, d1;
+    cut_pair_rt(an.v[4].w, an.v[5].w, h_, m_, l_, d0, d1, carry.t0, carry.t1);
+    cut_pair_rt(an.v[6].w, an.v[7].w, h_, m_, l_, carry.r0, carry.r1, d0, d1);
   }
   for (int st = 0; st < nsteps; st += 2) {
     DW_STEP(st, sa0, sa1, b0, b1)
@@ -452,7 +478,12 @@ __device__ __forceinline__ void dw_block_split(const DwLayer& L, int split, int 
   }
 #undef DW_STEP
 #undef DW_PACK
-#undef DW_G
+#undef DW_G2
+#undef DW_LW
+#undef DW_MW
+#undef DW_GO
+#undef DW_GE
+#undef DW_MFMAS
 #undef DW_X
 #undef DW_SB_OF
 #undef DW_SBSEL

@@ -584,6 +584,57 @@ __device__ __forceinline__ void fused_kloop_split(f32x16 (&acc)[2][4], const flo
           [msk] "s"(0xFFFF0000u));                                                                                            \
   }
 
+// The same group with the cut chain SOFTWARE-PIPELINED over three groups: stage 1 (h and the residual r = x - h) of pair g, stage 2
+// (m, and r -> t = r - m in place) of pair g - 1, stage 3 (l) of pair g - 2.  In SPLIT_GROUP every instruction depends on the one or two
+// in front of it; here no instruction reads a result of the same group's previous three, and the group runs ~5 % shorter
+// (tools/lab/split_weave.hip variants 1 / 7: 112 -> 107 cycles per 3 MFMAs).  R0, R1: this pair's r (out); PR0, PR1: the previous
+// pair's r (in, becomes its t); PT0, PT1: the t of the pair before that (in).
+#define SPLIT_GROUP_P(...) SPLIT_GROUP_P_(__VA_ARGS__)      /* (one more expansion: callers pass the nine MFMA operands as one macro) */
+#define SPLIT_GROUP_P_(C0, A0, B0, C1, A1, B1, C2, A2, B2, X0, X1, H, R0, R1, PR0, PR1, M, PT0, PT1, L)                           \
+  {                                                                                                                           \
+    uint32_t t0_, t1_, u0_, u1_;                                                                                              \
+    asm volatile(                                                                                                             \
+        "v_mfma_f32_32x32x16_bf16 %[c0], %[a0], %[b0], %[c0]\n"                                                               \
+        "v_cvt_pk_bf16_f32 %[h], %[x0], %[x1]\n"                                                                              \
+        "v_cvt_pk_bf16_f32 %[m], %[pr0], %[pr1]\n"                                                                            \
+        "v_cvt_pk_bf16_f32 %[l], %[pt0], %[pt1]\n"                                                                            \
+        "v_lshlrev_b32 %[t0], 16, %[h]\n"                                                                                     \
+        "v_mfma_f32_32x32x16_bf16 %[c1], %[a1], %[b1], %[c1]\n"                                                               \
+        "v_and_b32 %[t1], %[msk], %[h]\n"                                                                                     \
+        "v_lshlrev_b32 %[u0], 16, %[m]\n"                                                                                     \
+        "v_and_b32 %[u1], %[msk], %[m]\n"                                                                                     \
+        "v_sub_f32 %[r0], %[x0], %[t0]\n"                                                                                     \
+        "v_mfma_f32_32x32x16_bf16 %[c2], %[a2], %[b2], %[c2]\n"                                                               \
+        "v_sub_f32 %[r1], %[x1], %[t1]\n"                                                                                     \
+        "v_sub_f32 %[pr0], %[pr0], %[u0]\n"                                                                                   \
+        "v_sub_f32 %[pr1], %[pr1], %[u1]\n"                                                                                   \
+        : [c0] "+a"(C0), [c1] "+a"(C1), [c2] "+a"(C2), [h] "=&v"(H), [m] "=&v"(M), [l] "=&v"(L), [t0] "=&v"(t0_), [t1] "=&v"(t1_),  \
+          [u0] "=&v"(u0_), [u1] "=&v"(u1_), [r0] "=&v"(R0), [r1] "=&v"(R1), [pr0] "+v"(PR0), [pr1] "+v"(PR1)                       \
+        : [a0] "v"(A0), [b0] "v"(B0), [a1] "v"(A1), [b1] "v"(B1), [a2] "v"(A2), [b2] "v"(B2), [x0] "v"(X0), [x1] "v"(X1),         \
+          [pt0] "v"(PT0), [pt1] "v"(PT1), [msk] "s"(0xFFFF0000u));                                                            \
+  }
+// what the chain still owes at the end of a sequence of pairs: the r of the last pair and the t of the one before it
+struct SplitCarry { float r0, r1, t0, t1; };
+// a pair cut completely by compiler-scheduled code, with its residuals (prologues: they also seed the carry)
+__device__ __forceinline__ void cut_pair_rt(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l, float& r0, float& r1, float& t0, float& t1) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const bf16x2 hh = {(__bf16)x0, (__bf16)x1};
+  h = __builtin_bit_cast(uint32_t, hh);
+  r0 = x0 - __uint_as_float(h << 16); r1 = x1 - __uint_as_float(h & 0xFFFF0000u);
+  const bf16x2 mm = {(__bf16)r0, (__bf16)r1};
+  m = __builtin_bit_cast(uint32_t, mm);
+  t0 = r0 - __uint_as_float(m << 16); t1 = r1 - __uint_as_float(m & 0xFFFF0000u);
+  const bf16x2 ll = {(__bf16)t0, (__bf16)t1};
+  l = __builtin_bit_cast(uint32_t, ll);
+}
+template <int W>
+__device__ __forceinline__ bf16x8 bf16x8_set_word(const bf16x8& v, uint32_t w) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 q = __builtin_bit_cast(u32x4, v);
+  q[W] = w;
+  return __builtin_bit_cast(bf16x8, q);
+}
+
 __device__ __forceinline__ void fused_kloop_split_asm4(f32x16 (&acc)[2][4], const float* ap, const SplitBView& bv, int nu, SplitBSet& PB) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   // Register lifetimes are what the loop is built around (a value that lives three half-steps in a loop of period two makes the
@@ -645,26 +696,60 @@ __device__ __forceinline__ void fused_kloop_split_asm4(f32x16 (&acc)[2][4], cons
     }
   };
   // half-step: the 48 MFMAs of the unit whose terms are (c, p), woven with the cut of the raw unit r into n; meanwhile the planes of
-  // unit up go to pn and the fp32 operands of unit ur to rn
-  auto step = [&](const Cut& c, const Planes& p, const Raw& r, Cut& n, Planes& pn, int up, Raw& rn, int ur) __attribute__((always_inline)) {
+  // unit up go to pn and the fp32 operands of unit ur to rn.  The cut chain is pipelined over three groups (SPLIT_GROUP_P), also
+  // ACROSS half-steps: the m of pair 15 and the l of pairs 14, 15 of the unit cut in the previous half-step -- words of c.sb[1], the
+  // terms of weight tile 3 -- come out of this half-step's groups 0 and 1 (`carry` holds their residuals), which is early enough
+  // because the passes run big terms first: the l terms are MFMA operands only from group 10 on, tile 3's m term from group 4.
+  auto step = [&](Cut& c, const Planes& p, const Raw& r, Cut& n, Planes& pn, int up, Raw& rn, int ur, SplitCarry& carry) __attribute__((always_inline)) {
     uint32_t hw[4][4], mw[4][4], lw[4][4];      // [cut operand][pair]
-    // MFMA i of the half-step (i = 0 .. 47): pass i / 8 in the order l h, h l, m m, m h, h m, h h (small terms first), tile (i % 8) / 2,
+    uint32_t mlate, llate0, llate1;             // m of the previous unit's pair 15, l of its pairs 14, 15
+    float ra0, ra1, rb0, rb1;                   // residuals in flight: stage 1 writes (ra | rb), stage 2 turns the other into t
+    // MFMA i of the half-step (i = 0 .. 47): pass i / 8 in the order h h, h m, m h, m m, h l, l h (A term, B term), tile (i % 8) / 2,
     // row tile i % 2 -- consecutive MFMAs never touch the same accumulator.  B term t (0 = h, 1 = m, 2 = l) of tile j: planes for j < 2
-#define SPLIT_A_OF(i) ((i) / 8 == 0 ? c.sa[(i) % 2].l : ((i) / 8 == 2 || (i) / 8 == 3) ? c.sa[(i) % 2].m : c.sa[(i) % 2].h)
+#define SPLIT_A_OF(i) ((i) / 8 == 5 ? c.sa[(i) % 2].l : ((i) / 8 == 2 || (i) / 8 == 3) ? c.sa[(i) % 2].m : c.sa[(i) % 2].h)
 #define SPLIT_BT(j, t) ((j) < 2 ? p.b[(j) & 1][t] : ((t) == 0 ? c.sb[(j) & 1].h : (t) == 1 ? c.sb[(j) & 1].m : c.sb[(j) & 1].l))
-#define SPLIT_B_OF(i) SPLIT_BT(((i) % 8) / 2, ((i) / 8 == 1 ? 2 : ((i) / 8 == 2 || (i) / 8 == 4) ? 1 : 0))
-#define SPLIT_G(g)                                                                                                                       \
-    SPLIT_GROUP(acc[(3 * (g)) % 2][((3 * (g)) % 8) / 2], SPLIT_A_OF(3 * (g)), SPLIT_B_OF(3 * (g)),                                          \
-                acc[(3 * (g) + 1) % 2][((3 * (g) + 1) % 8) / 2], SPLIT_A_OF(3 * (g) + 1), SPLIT_B_OF(3 * (g) + 1),                          \
-                acc[(3 * (g) + 2) % 2][((3 * (g) + 2) % 8) / 2], SPLIT_A_OF(3 * (g) + 2), SPLIT_B_OF(3 * (g) + 2),                          \
-                xval(r, (g) / 4, 2 * ((g) % 4)), xval(r, (g) / 4, 2 * ((g) % 4) + 1), hw[(g) / 4][(g) % 4], mw[(g) / 4][(g) % 4], lw[(g) / 4][(g) % 4]) \
+#define SPLIT_B_OF(i) SPLIT_BT(((i) % 8) / 2, ((i) / 8 == 4 ? 2 : ((i) / 8 == 1 || (i) / 8 == 3) ? 1 : 0))
+#define SPLIT_MFMAS(g)                                                                                                                   \
+    acc[(3 * (g)) % 2][((3 * (g)) % 8) / 2], SPLIT_A_OF(3 * (g)), SPLIT_B_OF(3 * (g)),                                                      \
+    acc[(3 * (g) + 1) % 2][((3 * (g) + 1) % 8) / 2], SPLIT_A_OF(3 * (g) + 1), SPLIT_B_OF(3 * (g) + 1),                                      \
+    acc[(3 * (g) + 2) % 2][((3 * (g) + 2) % 8) / 2], SPLIT_A_OF(3 * (g) + 2), SPLIT_B_OF(3 * (g) + 2)
+    // Residual registers: stage 1 of an even pair writes (ra0, ra1), of an odd pair (rb0, rb1); stage 2 of the next group turns them
+    // into the pair's t in place; the group after that reads them in stage 3 -- under the names (ta | tb), taken over between the
+    // groups (pure renaming: the early-clobber stage-1 outputs of that group are new values and get registers of their own).
+    float ta0 = carry.t0, ta1 = carry.t1, tb0, tb1;     // t of pair g - 2 for even / odd g
+    rb0 = carry.r0; rb1 = carry.r1;                     // pair "-1" (= pair 15 of the previous unit) counts as odd
+#define SPLIT_GE(g, M_, L_)  /* even g: stage 1 -> ra, stage 2 on rb (pair g - 1), stage 3 on ta (pair g - 2) */                          \
+    SPLIT_GROUP_P(SPLIT_MFMAS(g), xval(r, (g) / 4, 2 * ((g) % 4)), xval(r, (g) / 4, 2 * ((g) % 4) + 1), hw[(g) / 4][(g) % 4], ra0, ra1,    \
+                  rb0, rb1, M_, ta0, ta1, L_)                                                                                           \
+    tb0 = rb0; tb1 = rb1;                        /* pair g - 1's t: read by stage 3 of group g + 1 */                                    \
     load_slot(g, pn, up, rn, ur);
-    SPLIT_G(0) SPLIT_G(1) SPLIT_G(2) SPLIT_G(3) SPLIT_G(4) SPLIT_G(5) SPLIT_G(6) SPLIT_G(7)
-    SPLIT_G(8) SPLIT_G(9) SPLIT_G(10) SPLIT_G(11) SPLIT_G(12) SPLIT_G(13) SPLIT_G(14) SPLIT_G(15)
-#undef SPLIT_G
+#define SPLIT_GO(g, M_, L_)  /* odd g: stage 1 -> rb, stage 2 on ra, stage 3 on tb */                                                     \
+    SPLIT_GROUP_P(SPLIT_MFMAS(g), xval(r, (g) / 4, 2 * ((g) % 4)), xval(r, (g) / 4, 2 * ((g) % 4) + 1), hw[(g) / 4][(g) % 4], rb0, rb1,    \
+                  ra0, ra1, M_, tb0, tb1, L_)                                                                                           \
+    ta0 = ra0; ta1 = ra1;                                                                                                              \
+    load_slot(g, pn, up, rn, ur);
+#define SPLIT_MW(g) mw[((g) - 1) / 4][((g) - 1) % 4]
+#define SPLIT_LW(g) lw[((g) - 2) / 4][((g) - 2) % 4]
+    SPLIT_GE(0, mlate, llate0)
+    SPLIT_GO(1, SPLIT_MW(1), llate1)
+    c.sb[1].m = bf16x8_set_word<3>(c.sb[1].m, mlate);
+    c.sb[1].l = bf16x8_set_word<3>(bf16x8_set_word<2>(c.sb[1].l, llate0), llate1);
+    SPLIT_GE(2, SPLIT_MW(2), SPLIT_LW(2)) SPLIT_GO(3, SPLIT_MW(3), SPLIT_LW(3)) SPLIT_GE(4, SPLIT_MW(4), SPLIT_LW(4))
+    SPLIT_GO(5, SPLIT_MW(5), SPLIT_LW(5)) SPLIT_GE(6, SPLIT_MW(6), SPLIT_LW(6)) SPLIT_GO(7, SPLIT_MW(7), SPLIT_LW(7))
+    SPLIT_GE(8, SPLIT_MW(8), SPLIT_LW(8)) SPLIT_GO(9, SPLIT_MW(9), SPLIT_LW(9)) SPLIT_GE(10, SPLIT_MW(10), SPLIT_LW(10))
+    SPLIT_GO(11, SPLIT_MW(11), SPLIT_LW(11)) SPLIT_GE(12, SPLIT_MW(12), SPLIT_LW(12)) SPLIT_GO(13, SPLIT_MW(13), SPLIT_LW(13))
+    SPLIT_GE(14, SPLIT_MW(14), SPLIT_LW(14)) SPLIT_GO(15, SPLIT_MW(15), SPLIT_LW(15))
+#undef SPLIT_LW
+#undef SPLIT_MW
+#undef SPLIT_GO
+#undef SPLIT_GE
+#undef SPLIT_MFMAS
 #undef SPLIT_B_OF
 #undef SPLIT_BT
 #undef SPLIT_A_OF
+    // owed to the next half-step: r of pair 15 (odd: rb), t of pair 14 (stage 2 of group 15 left it in ra -> ta)
+    carry.r0 = rb0; carry.r1 = rb1; carry.t0 = ta0; carry.t1 = ta1;
+    mw[3][3] = 0; lw[3][2] = 0; lw[3][3] = 0;       // placeholders: the next half-step's groups 0, 1 deliver these words
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       Split3& d = q < 2 ? n.sa[q] : n.sb[q - 2];
@@ -689,11 +774,20 @@ __device__ __forceinline__ void fused_kloop_split_asm4(f32x16 (&acc)[2][4], cons
   c0.sa[1] = split8(r0.a[1], r0.a[3]);
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) c0.sb[ni] = split8(r0.f[ni][0], r0.f[ni][1]);
+  // the chain's carry as if unit 0 had come out of the pipelined groups: the residual r of its pair 15 and the t of its pair 14 --
+  // the first half-step's groups 0 and 1 then re-derive the three late words of c0.sb[1] to the same bits
+  SplitCarry carry;
+  {
+    uint32_t h_, m_, l_;
+    float d0, d1;
+    cut_pair_rt(r0.f[1][1].x, r0.f[1][1].y, h_, m_, l_, d0, d1, carry.t0, carry.t1);       // pair 14 = values 4, 5 of weight tile 3
+    cut_pair_rt(r0.f[1][1].z, r0.f[1][1].w, h_, m_, l_, carry.r0, carry.r1, d0, d1);       // pair 15 = values 6, 7
+  }
   for (int u = 0; u < nu; u += 2) {
     // MFMAs of unit u, cut of unit u+1; on the way: terms of unit u+1 (operands of the next half-step), fp32 of unit u+2 (cut there)
-    step(c0, p0, r1, c1, p1, min(u + 1, ulast), r0, min(u + 2, ulast));
+    step(c0, p0, r1, c1, p1, min(u + 1, ulast), r0, min(u + 2, ulast), carry);
     if (u + 1 >= nu) break;
-    step(c1, p1, r0, c0, p0, min(u + 2, ulast), r1, min(u + 3, ulast));
+    step(c1, p1, r0, c0, p0, min(u + 2, ulast), r1, min(u + 3, ulast), carry);
   }
 }
 

@@ -5,6 +5,8 @@
 //   2 the same instructions, no dependences     3 two pairs' chains interleaved (6 MFMAs + 22 VALU, counted per 3 MFMAs)
 //   4 the group without the three v_cvt_pk (8 VALU: perm-free truncation skeleton)      5 4 VALU (v_and only) per MFMA
 //   6 11 VALU first, then the 3 MFMAs (what the compiler's order amounts to)
+//   7 the product's chain software-pipelined over three groups: stage 1 of pair g, stage 2 of pair g - 1, stage 3 of pair g - 2
+// (variants 1, 3, 6, 7 carry 3 extra compiler-emitted v_xor per group for the sink: compare them with each other)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -21,7 +23,7 @@ __global__ __launch_bounds__(256, 1) void weave(float* out, unsigned long long* 
   for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(threadIdx.x * 1e-3f + j); b[j] = (__bf16)(1.0f + threadIdx.x * 1e-4f * j); }
   float x0 = threadIdx.x * 1.37e-3f + 0.11f, x1 = threadIdx.x * 2.11e-3f + 0.23f, y0 = x0 * 1.5f, y1 = x1 * 0.7f;
   unsigned h = 0, m = 0, l = 0, h2 = 0, m2 = 0, l2 = 0, t0, t1, u0, u1;
-  float r0, r1, s0, s1;
+  float r0, r1, s0 = x0 * 0.3f, s1 = x1 * 0.3f;
   unsigned sink = 0;
   unsigned long long T0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < iters; ++it) {
@@ -63,6 +65,15 @@ __global__ __launch_bounds__(256, 1) void weave(float* out, unsigned long long* 
                        [t0] "=&v"(t0), [t1] "=&v"(t1), [r0] "=&v"(r0), [r1] "=&v"(r1), [u0] "=&v"(u0), [u1] "=&v"(u1), [s0] "=&v"(s0), [s1] "=&v"(s1)
                      : [a] "v"(a), [b] "v"(b), [x0] "v"(x0), [x1] "v"(x1), [y0] "v"(y0), [y1] "v"(y1), [msk] "s"(0xFFFF0000u));
         sink ^= h ^ m ^ l ^ h2 ^ m2 ^ l2;
+      } else if (V == 7) {   // the chain software-pipelined across groups: no instruction depends on one of the same group's last three
+        asm volatile(MF(c0) "v_cvt_pk_bf16_f32 %[h], %[x0], %[x1]\n v_cvt_pk_bf16_f32 %[m], %[pr0], %[pr1]\n v_cvt_pk_bf16_f32 %[l], %[pt0], %[pt1]\n v_lshlrev_b32 %[t0], 16, %[h]\n"
+                     MF(c1) "v_and_b32 %[t1], %[msk], %[h]\n v_lshlrev_b32 %[u0], 16, %[m]\n v_and_b32 %[u1], %[msk], %[m]\n v_sub_f32 %[r0], %[x0], %[t0]\n"
+                     MF(c2) "v_sub_f32 %[r1], %[x1], %[t1]\n v_sub_f32 %[pr0], %[pr0], %[u0]\n v_sub_f32 %[pr1], %[pr1], %[u1]\n"
+                     : [c0] "+a"(acc[i0]), [c1] "+a"(acc[i1]), [c2] "+a"(acc[i2]), [h] "=&v"(h), [m] "=&v"(m), [l] "=&v"(l), [t0] "=&v"(t0), [t1] "=&v"(t1), [u0] "=&v"(u0), [u1] "=&v"(u1),
+                       [r0] "=&v"(r0), [r1] "=&v"(r1), [pr0] "+v"(s0), [pr1] "+v"(s1)
+                     : [a] "v"(a), [b] "v"(b), [x0] "v"(x0), [x1] "v"(x1), [pt0] "v"(y0), [pt1] "v"(y1), [msk] "s"(0xFFFF0000u));
+        sink ^= h ^ m ^ l;
+        y0 = s0; y1 = s1; s0 = r0; s1 = r1;      // pair g's r becomes "previous r", the finished t becomes "previous t" (renaming)
       } else if (V == 4) {   // no v_cvt_pk: 8 simple VALU in the same positions
         asm volatile(MF(c0) "v_lshlrev_b32 %[t0], 16, %[k]\n v_and_b32 %[t1], %[msk], %[k]\n v_sub_f32 %[r0], %[x0], %[t0]\n"
                      MF(c1) "v_sub_f32 %[r1], %[x1], %[t1]\n v_lshlrev_b32 %[t0], 16, %[r0]\n v_and_b32 %[t1], %[msk], %[r1]\n"
@@ -113,4 +124,6 @@ int main() {
   run<4>("4: without the three v_cvt_pk_bf16_f32 (8 VALU)", out, cyc, nblk);
   run<5>("5: 4 independent v_and_b32 per MFMA (12 VALU)", out, cyc, nblk);
   run<6>("6: the 11 VALU first, then the 3 MFMAs", out, cyc, nblk);
+  run<7>("7: the chain pipelined over three groups (same 11 VALU, none dependent)", out, cyc, nblk);
   return 0;
+}
