@@ -299,7 +299,7 @@ __device__ __forceinline__ void dw_block_split_v1(const DwLayer& L, int split, i
 // ---- the same block with the cut woven between the MFMAs (DW_SPLIT_WEAVE, default) ----------------------------------------------------
 // dw_block_split_v1 above runs a step as  [16 LDS reads] [cut A: 176 VALU] [per column: cut B, 24 MFMAs]: a lone in-order wave overlaps
 // none of the cut with its MFMAs (tools/lab/split_weave.hip: 11 VALU in front of 3 MFMAs = 140 cycles, woven between them 101-112), the
-// kernel sat at 60 % MFMA-busy.  Here the step is software-pipelined by one step and written as 32 asm groups (fused.hpp SPLIT_GROUP:
+// kernel sat at 60 % MFMA-busy.  Here the step is software-pipelined by one step and written as 32 asm groups (fused.hpp SPLIT_GROUP_P:
 // MFMA, 4 VALU, MFMA, 4 VALU, MFMA, 3 VALU), the MFMAs of step st woven with the cut of what comes next:
 //   column block j (24 MFMAs = 8 groups):  groups 0-3 cut column (j + 1) of the B operand (column 0 of step st + 1 in block 3),
 //                                          groups 4-7 cut row tile j of the A operand of step st + 1
@@ -471,6 +471,10 @@ __device__ __forceinline__ void dw_block_split(const DwLayer& L, int split, int 
     cut_pair_rt(an.v[4].w, an.v[5].w, h_, m_, l_, d0, d1, carry.t0, carry.t1);
     cut_pair_rt(an.v[6].w, an.v[7].w, h_, m_, l_, carry.r0, carry.r1, d0, d1);
   }
+  // (compiler-written terms -> the first groups' MFMAs: held and padded as in fused_kloop_split_asm4)
+  asm volatile("s_nop 1"
+               : "+v"(sa0[0].h), "+v"(sa0[0].m), "+v"(sa0[0].l), "+v"(sa0[1].h), "+v"(sa0[1].m), "+v"(sa0[1].l), "+v"(sa0[2].h), "+v"(sa0[2].m),
+                 "+v"(sa0[2].l), "+v"(sa0[3].h), "+v"(sa0[3].m), "+v"(sa0[3].l), "+v"(sb0.h), "+v"(sb0.m), "+v"(sb0.l));
   for (int st = 0; st < nsteps; st += 2) {
     DW_STEP(st, sa0, sa1, b0, b1)
     if (st + 1 >= nsteps) break;

@@ -550,7 +550,7 @@ __device__ __forceinline__ void fused_kloop_split(f32x16 (&acc)[2][4], const flo
 // The compiler does not interleave the cut with the MFMAs, with or without sched_group_barrier (emitted order of the loop above: ~140
 // VALU instructions, then a mixed stretch, then ~45 MFMAs back to back), and a lone in-order wave only overlaps VALU work that sits
 // BETWEEN its MFMAs: the step runs in VALU time + MFMA time (2281 cycles per k-unit against 1536 of MFMAs).  Here a half-step is 16
-// asm groups, each  MFMA, 4 VALU, MFMA, 4 VALU, MFMA, 3 VALU  = three MFMAs of unit u woven with the cut of ONE value pair of unit
+// asm groups (SPLIT_GROUP_P below), each  MFMA, 4 VALU, MFMA, 4 VALU, MFMA, 3 VALU  = three MFMAs of unit u woven with the cut of ONE value pair of unit
 // u+1 (16 pairs per unit: 8 of the activation rows, 8 of the two weight tiles that are cut in registers).  volatile asm statements
 // keep their order, so the emitted stream IS this order; 3.7 VALU instructions per 32-cycle MFMA gap is inside what a bf16 MFMA
 // leaves free (MI355X_MICROARCH.md: issue costs summing to <= 24 cycles per gap hide).  Loads stay compiler-issued builtins (it
@@ -559,35 +559,10 @@ __device__ __forceinline__ void fused_kloop_split(f32x16 (&acc)[2][4], const flo
 #ifndef SPLIT_ASM
 #define SPLIT_ASM 1        // 0: the compiler-scheduled loop above for every NACT (A/B switch)
 #endif
-#define SPLIT_GROUP(C0, A0, B0, C1, A1, B1, C2, A2, B2, X0, X1, H, M, L)                                                       \
-  {                                                                                                                           \
-    uint32_t t0_, t1_;                                                                                                        \
-    float r0_, r1_;                                                                                                           \
-    asm volatile(                                                                                                             \
-        "v_mfma_f32_32x32x16_bf16 %[c0], %[a0], %[b0], %[c0]\n"                                                               \
-        "v_cvt_pk_bf16_f32 %[h], %[x0], %[x1]\n"                                                                              \
-        "v_lshlrev_b32 %[t0], 16, %[h]\n"                                                                                     \
-        "v_and_b32 %[t1], %[msk], %[h]\n"                                                                                     \
-        "v_sub_f32 %[r0], %[x0], %[t0]\n"                                                                                     \
-        "v_mfma_f32_32x32x16_bf16 %[c1], %[a1], %[b1], %[c1]\n"                                                               \
-        "v_sub_f32 %[r1], %[x1], %[t1]\n"                                                                                     \
-        "v_cvt_pk_bf16_f32 %[m], %[r0], %[r1]\n"                                                                              \
-        "v_lshlrev_b32 %[t0], 16, %[m]\n"                                                                                     \
-        "v_and_b32 %[t1], %[msk], %[m]\n"                                                                                     \
-        "v_mfma_f32_32x32x16_bf16 %[c2], %[a2], %[b2], %[c2]\n"                                                               \
-        "v_sub_f32 %[r0], %[r0], %[t0]\n"                                                                                     \
-        "v_sub_f32 %[r1], %[r1], %[t1]\n"                                                                                     \
-        "v_cvt_pk_bf16_f32 %[l], %[r0], %[r1]\n"                                                                              \
-        : [c0] "+a"(C0), [c1] "+a"(C1), [c2] "+a"(C2), [h] "=&v"(H), [m] "=&v"(M), [l] "=&v"(L), [t0] "=&v"(t0_), [t1] "=&v"(t1_),  \
-          [r0] "=&v"(r0_), [r1] "=&v"(r1_)                                                                                     \
-        : [a0] "v"(A0), [b0] "v"(B0), [a1] "v"(A1), [b1] "v"(B1), [a2] "v"(A2), [b2] "v"(B2), [x0] "v"(X0), [x1] "v"(X1),         \
-          [msk] "s"(0xFFFF0000u));                                                                                            \
-  }
-
-// The same group with the cut chain SOFTWARE-PIPELINED over three groups: stage 1 (h and the residual r = x - h) of pair g, stage 2
-// (m, and r -> t = r - m in place) of pair g - 1, stage 3 (l) of pair g - 2.  In SPLIT_GROUP every instruction depends on the one or two
-// in front of it; here no instruction reads a result of the same group's previous three, and the group runs ~5 % shorter
-// (tools/lab/split_weave.hip variants 1 / 7: 112 -> 107 cycles per 3 MFMAs).  R0, R1: this pair's r (out); PR0, PR1: the previous
+// One group: three MFMAs and 11 VALU instructions of the cut chain, SOFTWARE-PIPELINED over three groups: stage 1 (h and the residual
+// r = x - h) of pair g, stage 2 (m, and r -> t = r - m in place) of pair g - 1, stage 3 (l) of pair g - 2.  Written as one dependent chain
+// per group (the first version) every instruction depends on the one or two in front of it; here no instruction reads a result of the
+// same group's previous three, and the group runs ~5 % shorter (tools/lab/split_weave.hip variants 1 / 7: 112 -> 107 cycles per 3 MFMAs).  R0, R1: this pair's r (out); PR0, PR1: the previous
 // pair's r (in, becomes its t); PT0, PT1: the t of the pair before that (in).
 #define SPLIT_GROUP_P(...) SPLIT_GROUP_P_(__VA_ARGS__)      /* (one more expansion: callers pass the nine MFMA operands as one macro) */
 #define SPLIT_GROUP_P_(C0, A0, B0, C1, A1, B1, C2, A2, B2, X0, X1, H, R0, R1, PR0, PR1, M, PT0, PT1, L)                           \
@@ -783,6 +758,13 @@ __device__ __forceinline__ void fused_kloop_split_asm4(f32x16 (&acc)[2][4], cons
     cut_pair_rt(r0.f[1][1].x, r0.f[1][1].y, h_, m_, l_, d0, d1, carry.t0, carry.t1);       // pair 14 = values 4, 5 of weight tile 3
     cut_pair_rt(r0.f[1][1].z, r0.f[1][1].w, h_, m_, l_, carry.r0, carry.r1, d0, d1);       // pair 15 = values 6, 7
   }
+  // The first groups' MFMAs read terms that compiler-scheduled VALU code has just written, and the compiler does not know that the asm
+  // statement it hands them to opens with an MFMA (a VALU write needs two wait states before an MFMA reads it as srcA / srcB): the
+  // terms pass through one statement that holds them and pads (inside the loop every term comes out of a group at least one group
+  // -- and the compiler's own boundary pad -- before its first MFMA).
+  asm volatile("s_nop 1"
+               : "+v"(c0.sa[0].h), "+v"(c0.sa[0].m), "+v"(c0.sa[0].l), "+v"(c0.sa[1].h), "+v"(c0.sa[1].m), "+v"(c0.sa[1].l),
+                 "+v"(c0.sb[0].h), "+v"(c0.sb[0].m), "+v"(c0.sb[0].l), "+v"(c0.sb[1].h), "+v"(c0.sb[1].m), "+v"(c0.sb[1].l));
   for (int u = 0; u < nu; u += 2) {
     // MFMAs of unit u, cut of unit u+1; on the way: terms of unit u+1 (operands of the next half-step), fp32 of unit u+2 (cut there)
     step(c0, p0, r1, c1, p1, min(u + 1, ulast), r0, min(u + 2, ulast), carry);

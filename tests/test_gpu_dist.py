@@ -132,10 +132,10 @@ def test_two_rank_hip_step_equals_single_process_and_oracle(tmp_path, buckets):
         assert rel_err(lat_dp, o["lat"]) <= PARAM_TOL, step
 
 
-def _torchrun_two_ranks(script_args, timeout=900):
+def _torchrun_two_ranks(script_args, timeout=900, **extra_env):
     """`python -m torch.distributed.run --nproc-per-node 2 <script_args>` as a FRESH child of the test process, both ranks on
     the box's one card over gloo (the rehearsal knobs of deepsdf_amd.dist.init).  Returns the merged stdout + stderr."""
-    env = dict(os.environ, DSDF_DIST_BACKEND="gloo", DSDF_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, DSDF_DIST_BACKEND="gloo", DSDF_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -167,7 +167,8 @@ def test_trainer_at_world_size_two_checkpoints_and_resumes(tmp_path):
     train_deep_sdf.py:353): the ScenesPerBatch batch is split over the ranks, every rank owns half of the scenes.  Checked:
     checkpoints hold the FULL latent table and the reference's 2-group optimizer state (train_deep_sdf.py:106-143); the
     trainer's own replica check passed before every checkpoint (decoder parameters and both Adam moments bit-identical on
-    the two ranks); `-c latest` resumes at world size 2, and the SAME experiment directory then resumes in ONE process."""
+    the two ranks); `-c latest` resumes at world size 2 -- that run with the two-bucket gradient exchange (DSDF_AR_BUCKETS=2) --, and
+    the SAME experiment directory then resumes in ONE process."""
     import json
     from deepsdf_amd import train
     from tests.test_gpu_module_trainer import _make_experiment
@@ -198,7 +199,7 @@ def test_trainer_at_world_size_two_checkpoints_and_resumes(tmp_path):
     specs = json.load(open(os.path.join(exp, "specs.json")))
     specs["NumEpochs"], specs["SnapshotFrequency"] = 4, 4
     json.dump(specs, open(os.path.join(exp, "specs.json"), "w"))
-    out = _torchrun_two_ranks([script, "-e", exp, "-c", "latest"])                # resume at world size 2
+    out = _torchrun_two_ranks([script, "-e", exp, "-c", "latest"], DSDF_AR_BUCKETS="2")   # resume at world size 2, two gradient buckets
     assert "starting from epoch 3" in out and "decoder replicas bit-identical on 2 ranks" in out, out[-3000:]
     sd4, logs4 = check(4, ["2.pth", "4.pth", "latest.pth"])
     assert logs4["loss"][:4] == logs2["loss"]                                     # the first run's log is kept
