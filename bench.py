@@ -273,14 +273,23 @@ def main():
                                   ms_per_step=prof.ms[c] / args.steps,
                                   tflops=prof.flops[c] / (prof.ms[c] * 1e-3) / 1e12 if prof.ms[c] > 0 else None)
         dom = max(kern, key=lambda k: kern[k]["ms_per_step"])
-        # f32split: the dominant kernel's GEMMs run on the bf16 pipe, 6 MFMAs per fp32 product: its roof is the bf16 dense peak / 6
-        peak = 2500.0 / 6.0 if split else PEAK_TFLOPS
+        # The roof of the dominant kernel by the pipe its GEMMs run on: fp32 MFMA 157.3; f32split: bf16 dense peak / 6 (6 MFMAs per fp32
+        # product); the merged forward+backward launch of config 5 runs HALF of its algorithmic FLOPs (the forward) on the bf16 pipe at
+        # 2500 and the other half (the backward) on fp32 MFMAs (bf16: 157.3) or in split mode (bf16split: 2500 / 6): the roof of such a
+        # launch is total FLOPs / (time of each half at its own peak) = the harmonic mean of the two peaks
+        p_split = 2500.0 / 6.0
+        if dom == "fused_fwd_bwd_kernel" and bf16:
+            peak = 2.0 / (1.0 / 2500.0 + 1.0 / (p_split if split else PEAK_TFLOPS))
+        else:
+            peak = p_split if split else PEAK_TFLOPS
         roofline = dict(bound="mfma", kernel=dom, achieved=kern[dom]["tflops"], peak=peak, unit="TFLOP/s",
                         frac=kern[dom]["tflops"] / peak, traffic=None, executed_frac=None,
                         avg_launch_us=kern[dom]["avg_us"], launches_per_step=kern[dom]["launches_per_step"],
                         step_achieved=step_tflops, step_frac=step_tflops / PEAK_TFLOPS, kernels=kern,
-                        peak_note=("bf16 dense peak 2500 TFLOP/s / 6 MFMAs per product (the dW kernel of this step is still fp32 MFMA: "
-                                   "step_frac stays against 157.3)" if split else "fp32 MFMA dense peak"),
+                        peak_note=("harmonic mean of the bf16 dense peak (forward half of the launch) and " + ("bf16 dense peak / 6" if split else "the fp32 MFMA peak")
+                                   + " (backward half)" if (bf16 and dom == "fused_fwd_bwd_kernel") else
+                                   "bf16 dense peak 2500 TFLOP/s / 6 MFMAs per product (step_frac stays against the fp32 MFMA peak 157.3)"
+                                   if split else "fp32 MFMA dense peak"),
                         note="achieved = ALGORITHMIC 2*pts*sum(in*out) of the hidden layers the kernel covers (the reference's "
                              "dense formulation, SURVEY 8d) / HIP-event time around its launches; segment mode executes fewer MFMA "
                              "FLOPs than that (per-scene latent products are hoisted, DESIGN.md 4): executed_frac = MFMA FLOPs "
