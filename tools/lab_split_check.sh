@@ -1,4 +1,4 @@
-# round 3, GPU call 4: the asm-woven split k-loop: parity (gemm_split tests) + speed against the compiler-scheduled loop
+# lab: gemm_split parity (the gemm_split, shipped-shape and two-phase tests) + step / kernel times per library variant under tools/lab/variants/
 R=$GRAFT_REPO_ROOT; cd $R
 timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -q -s -k "gemm_split or shipped_experiment or two_phase" > gpurun_out/r3_t4.log 2>&1
 rc=$?; grep -E "gemm_split|passed|failed|Error|error" gpurun_out/r3_t4.log | tail -30
