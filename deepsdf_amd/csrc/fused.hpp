@@ -648,12 +648,12 @@ __device__ __forceinline__ void fused_kloop_split_asm4(f32x16 (&acc)[2][4], cons
   // The loads of a half-step go out ONE PER GROUP, behind the group's MFMAs (slot i after group i): issued as a cluster at the top
   // of the half-step (where the compiler puts them by itself) their ~35 load + address instructions run with the MFMA pipe idle.
   // The scalar offset passes through an empty volatile asm, which pins the load behind the group in front of it.
-  //   slots 0-5: the six plane loads of unit up (operands of the NEXT half-step's first MFMAs: earliest), 6-9: the fp32 weight
+  //   slots 0-5: the six plane loads of unit up (operands of the NEXT half-step's MFMAs: earliest, in the order they are needed), 6-9: the fp32 weight
   //   tiles of unit ur (cut in the second half of the next half-step), 10-13: the activation rows of unit ur (LDS: short latency)
   auto load_slot = [&](int i, Planes& pn, int up, Raw& rn, int ur) __attribute__((always_inline)) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     if (i < 6) {
-      const int ni = i / 3, pl = i % 3;
+      const int ni = i % 2, pl = i / 2;      // both tiles' h terms first (operands of the next half-step's very first MFMAs), then m, then l
       int so = pl * bv.plane + ((bv.tbase[ni] + (SPLIT_LAB_U0 ? 0 : up)) << 10);
       asm volatile("" : "+s"(so));
       pn.b[ni][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(bv.rsrc, bv.voff, so, 0));
