@@ -8,13 +8,16 @@ regulariser -> backward -> [N>1: RCCL all-reduce of decoder grads, latent Adam u
 runs).  Workload at N=1 = BASELINE.json configs[1]; N>1 = configs[2] (512 scenes sharded, weak scaling).
 
   python bench.py --gpus 1 --steps 50 --warmup 10
+  python bench.py --code-length 2 --scenes-per-batch 10 --samples 16000      # the reference's shipped 8x512 experiment shape (not the headline)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Beside the contract's line (value / ms_per_step over the barrier-bracketed timed region) rank 0 reports, at N=1:
   step_time_ms    median / p10 / p90 of single steps (device time between per-step events on the compute stream)
   roofline        dominant kernel: algorithmic FLOP / HIP-event time; `traffic` (HBM bytes per launch) and `executed_frac`
                   (MFMA FLOPs actually issued, from SQ counters) measured by rocprofv3 --pmc child passes of THIS command
-  cpu_baseline    the step in stock torch ops (oracle/torch_native.py) on this host: all cores and one core
+  cpu_baseline    the step in stock torch ops (oracle/torch_native.py) on this host, timed AFTER the PMC child passes have been joined
+                  (nothing else of the bench alive): a thread-count scan incl. k = 1, k = 64 (one socket) and k = all; value = the best
+  init_steps      untimed steps in front of the contract's --warmup steps (code-object loading, runtime pools)
   config.one_scene_ms_per_step   the locality extreme B=1 x S=16384
   config.inference_forward       --config bf16 only: the bf16 forward alone (one code x the step's points)
   config.gemm_split              headline config only: ms/step of the same workload with the opt-in gemm_split
