@@ -37,7 +37,7 @@ from deepsdf_amd import dist  # noqa: E402  (first: HSA_*/NCCL_* defaults must b
 
 import torch  # noqa: E402
 
-INIT_STEPS = 40
+INIT_STEPS = 40             # default of --init-steps
 PEAK_TFLOPS = 157.3          # fp32 MFMA dense peak, MI355X_MICROARCH.md "Peak FP32 (matrix)"
 NET = dict(dims=[512] * 8, dropout=list(range(8)), dropout_prob=0.2, norm_layers=list(range(8)), latent_in=[4],
            xyz_in_all=False, use_tanh=False, latent_dropout=False, weight_norm=True, geom_dimension=3)
@@ -171,6 +171,10 @@ def main():
                          "matrix pipe with every fp32 operand cut into three bf16 terms (6 MFMAs per product, fp32 accumulate: fp32 accuracy, "
                          "the fp32 parity tolerances; dW, Adam and everything else unchanged) -- opt-in, NOT the headline; bf16split = configs[4] with "
                          "gemm_split: the bf16 forward as it is, the backward dX chain in split mode")
+    ap.add_argument("--init-steps", type=int, default=INIT_STEPS,
+                    help="untimed steps in FRONT of the contract's --warmup steps (reported in the line as init_steps; 0 = only --warmup): "
+                         "the first ~100 kernel launches of a process load the code objects and grow the runtime's kernarg / signal pools "
+                         "(one-off stalls of 80-90 ms were observed as late as the 4th step), a cost a trainer pays once per process")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event instrumented pass")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (HBM traffic, MFMA counters)")
@@ -217,7 +221,7 @@ def main():
     # initialisation, not part of the contract's W warm-up steps: the first ~100 launches of a process load the code objects
     # and grow the runtime's kernarg / signal pools (one-off stalls of 80-90 ms were observed as late as the 4th step).
     # Reported in the line as `init_steps` (untimed, like `warmup`).
-    for i in range(INIT_STEPS):
+    for i in range(args.init_steps):
         step(i)
     torch.cuda.synchronize()
     for i in range(args.warmup):
@@ -325,7 +329,7 @@ def main():
         sfused = FusedTrainStep(seng, slat, clamp_dist=0.1, code_reg=True, code_reg_lambda=1e-4, code_bound=1.0, grad_clip=None, seed=3)
         sstep = lambda i: sfused(batches[i % len(batches)]["scenes"], S, batches[i % len(batches)]["xyz"], batches[i % len(batches)]["gt"],  # noqa: E731
                                  1, 5e-4, 1e-3, batch_split=1, n_norm=n_global)
-        for i in range(INIT_STEPS + args.warmup):     # its kernels are new to the process: the same initialisation as the headline's
+        for i in range(args.init_steps + args.warmup):     # its kernels are new to the process: the same initialisation as the headline's
             sstep(i)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -418,7 +422,7 @@ def main():
             cfg["one_scene_value"] = 16384 / (one_scene * 1e-3)
         print(json.dumps({
             "metric": "SDF point-samples/sec per training step (8x512 decoder, 16384 pts)", "value": value,
-            "unit": "point-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "init_steps": INIT_STEPS,
+            "unit": "point-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "init_steps": args.init_steps,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("bf16-fwd/f32 (backward dX GEMMs: 3 bf16 terms per operand, 6 bf16 MFMAs per product, fp32 accumulate)" if bf16 and split
                       else "bf16-fwd/f32") if bf16 else ("f32 (hidden GEMMs of the fused kernels: 3 bf16 terms per operand, 6 bf16 MFMAs per product, "

@@ -6,7 +6,8 @@ import os
 from .build import LIB
 
 MAX_LAYERS = 16
-ABI_VERSION = 13
+ABI_VERSION = 14
+MAX_BUCKETS = 8
 
 
 class DsdfNet(C.Structure):
@@ -32,7 +33,7 @@ class DsdfBatch(C.Structure):
 class DsdfLossCfg(C.Structure):
     _fields_ = [("clamp_dist", C.c_float), ("reg_coef", C.c_float), ("code_bound", C.c_float),
                 ("training", C.c_int32), ("frozen_decoder", C.c_int32), ("dropout_key", C.c_uint32 * MAX_LAYERS),
-                ("dw_phase", C.c_int32)]
+                ("dw_phase", C.c_int32), ("dw_buckets", C.c_int32)]
 
 
 class DsdfAdamCfg(C.Structure):
@@ -64,7 +65,9 @@ PROTOTYPES = {
     "dsdf_packed_floats": [_NET, C.POINTER(_I64)],
     "dsdf_workspace_bytes": [_NET, _I64, _I64, C.POINTER(_SZ)],
     "dsdf_decode_workspace_bytes": [_NET, _I64, C.POINTER(_SZ)],
-    "dsdf_grad_bucket_split": [_NET, C.POINTER(_I32), C.POINTER(_I64)],
+    "dsdf_workspace_bytes_buckets": [_NET, _I64, _I64, _I32, C.POINTER(_SZ)],
+    "dsdf_dw_phase_supported": [_NET],
+    "dsdf_grad_buckets": [_NET, _I32, C.POINTER(_I32), C.POINTER(_I64)],
     "dsdf_materialize_weights": [_NET, _P, _P, _P],
     "dsdf_decode": [_NET, _P, _P, _P, _I64, _I64, _P, _P, _SZ, _P],
     "dsdf_module_forward": [_NET, _P, _P, _P, _I64, _I64, _I32, C.POINTER(C.c_uint32), _P, _P, _SZ, _P],

@@ -146,20 +146,29 @@ def disassemble_with_addresses(co, name_part):
     return ins
 
 
-def mfma_src_reuse_distances(ins, limit=12, fall_through_only=False):
+def mfma_src_reuse_distances(ins, limit=12, fall_through_only=False, edges=None):
     """{load index: MFMAs issued strictly between the last MFMA reading one of the load's destination VGPRs as srcA/srcB and
     the load} for every ds_read* / buffer_load* / global_load* with a VGPR destination that has such a reader within `limit`
-    MFMAs on some path.  Paths follow fall-through and branch edges backwards (loop back-edges included);
-    fall_through_only: fall-through edges alone (every conditional branch not taken) -- paths that exist whatever the branch
-    conditions are, where the full set also contains paths the program's own guards exclude."""
+    MFMAs on some path.  Which control-flow edges a path may follow (`edges`):
+      "all"           fall-through and every branch edge: also contains paths the program's own guards exclude (a forward branch
+                      over a block of MFMAs taken together with the branch that only a step WITH MFMAs takes);
+      "loops"         fall-through and BACKWARD branch edges (target <= branch: loop back-edges) -- every conditional forward
+                      branch not taken, every loop iterated: the steady state of a k-loop, where the loads at the top of the body
+                      follow the last MFMAs of the previous trip;
+      "fall_through"  fall-through edges alone (every conditional branch not taken; `fall_through_only=True` is the old name)."""
+    if edges is None:
+        edges = "fall_through" if fall_through_only else "all"
+    if edges not in ("all", "loops", "fall_through"):
+        raise ValueError(edges)
     by_addr = {x["addr"]: i for i, x in enumerate(ins)}
     preds = [[] for _ in ins]
     for i, x in enumerate(ins):
         uncond = x["op"] in ("s_branch", "s_endpgm", "s_setpc_b64")
         if i + 1 < len(ins) and not uncond:
             preds[i + 1].append(i)
-        if not fall_through_only and x["op"].startswith(("s_branch", "s_cbranch")) and x["target"] in by_addr:
-            preds[by_addr[x["target"]]].append(i)
+        if edges != "fall_through" and x["op"].startswith(("s_branch", "s_cbranch")) and x["target"] in by_addr:
+            if edges == "all" or x["target"] <= x["addr"]:
+                preds[by_addr[x["target"]]].append(i)
     src_ab, acc_regs = {}, set()
     for i, x in enumerate(ins):
         if x["op"].startswith("v_mfma"):
@@ -196,12 +205,13 @@ def mfma_src_reuse_distances(ins, limit=12, fall_through_only=False):
 
 
 def check_mfma_src_reuse(lib, kernel="fused_forward_bf16x8_kernel", min_distance=1):
-    """Raises AsmHazard if, on a fall-through path, some load in `kernel` overwrites srcA/srcB registers of an MFMA with fewer than
-    `min_distance` other MFMAs issued in between (the signature of the first 8-wave k-loop: 46 such loads; the rewritten loop: none);
+    """Raises AsmHazard if, on a path of fall-through and loop back-edges (every loop iterated, no forward branch taken: the
+    k-loop's steady state included), some load in `kernel` overwrites srcA/srcB registers of an MFMA with fewer than `min_distance`
+    other MFMAs issued in between (the signature of the first 8-wave k-loop: 46 such loads; the rewritten loop: none);
     returns (smallest distance found, number of load/MFMA pairs looked at)."""
     with tempfile.TemporaryDirectory(prefix="dsdf_asmcheck_") as d:
         ins = disassemble_with_addresses(extract_code_object(lib, d), kernel)
-    dist = mfma_src_reuse_distances(ins, fall_through_only=True)
+    dist = mfma_src_reuse_distances(ins, edges="loops")
     if not dist:
         return None, 0
     worst = min(dist.values())

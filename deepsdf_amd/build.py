@@ -9,7 +9,8 @@ SRC = os.path.join(HERE, "csrc", "dsdf_api.hip")
 # every kernel source is a dependency: a stale .so would travel to the GPU box and be the thing measured
 DEPS = sorted(glob.glob(os.path.join(HERE, "csrc", "*.hip")) + glob.glob(os.path.join(HERE, "csrc", "*.hpp"))) + [
     os.path.join(os.path.dirname(HERE), "include", "dsdf.h")]
-LIB = os.environ.get("DSDF_LIB_PATH") or os.path.join(HERE, "libdsdf_hip.so")   # override: lab builds only
+LIB = os.environ.get("DSDF_LIB_PATH") or os.path.join(HERE, "libdsdf_hip.so")   # override: lab builds only (tools/lab_*.sh build those
+# with hipcc directly: they are NOT audited by asmcheck unless built through build_library -- measurement libraries, never shipped)
 
 
 def hipcc_path():
@@ -38,15 +39,21 @@ def build_library(force=False, verbose=False):
     if r.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
     # the one inline-asm window that keeps loads in flight across compiler-scheduled code is verified on the code object of
-    # EVERY build, lab flags included (asmcheck.py); a library that violates it is removed, not shipped
+    # EVERY build, lab flags included (asmcheck.py); a library that violates it -- or that could not be checked -- is removed,
+    # not shipped: left on disk it would pass is_stale() next time and be loaded unverified
     from . import asmcheck
     if asmcheck.tools_available():
         try:
             asmcheck.check_library(LIB, expect_windows="-DDW_SPLIT_ONE_WAIT=1" not in cmd)
             asmcheck.check_mfma_src_reuse(LIB, min_distance=2)      # fused_bf16x8.hpp: a step is >= 2 MFMAs (one n-tile per wave)
-        except asmcheck.AsmHazard:
-            os.remove(LIB)
+        except BaseException:      # AsmHazard, a failing llvm tool (CalledProcessError), an interrupt: no unverified library stays
+            if os.path.exists(LIB):
+                os.remove(LIB)
             raise
+    else:
+        import warnings
+        warnings.warn("deepsdf_amd.build: ROCm LLVM tools not found under " + asmcheck.LLVM + " -- the inline-asm audits of the code "
+                      "object (asmcheck.py) were SKIPPED for " + LIB)
     return LIB
 
 

@@ -264,9 +264,13 @@ DwSched dw_schedule(const DsdfNet* n, int64_t N, const int* ld_in, bool segmode,
   return S;
 }
 
-// Two-bucket gradient exchange (data parallel): the decoder's layers [k, last] finish first (bucket 0), [0, k) second (bucket 1);
-// k splits the hidden layers in the middle -- for the 8 x 512 net 1.05 M / 0.79 M parameters.
-int dw_bucket_layer(const DsdfNet* n) { return n->n_layers / 2; }
+// K-bucket gradient exchange (data parallel): the decoder's layers are cut into K contiguous groups, handed out LAST layer
+// first (the order the backward finishes them in): bucket b = layers [cut[b + 1], cut[b]), cut[0] = n_layers, cut[K] = 0.
+// K = 2 on the 8 x 512 net: layers [4, 8] (1.05 M parameters) then [0, 4) (0.79 M).  A net with fewer layers than buckets
+// leaves the trailing buckets empty (cut repeats 0).
+void dw_bucket_cuts(const DsdfNet* n, int K, int* cut) {
+  for (int b = 0; b <= K; ++b) cut[b] = (int)((int64_t)n->n_layers * (K - b) / K);
+}
 
 // ---- workspace plan -----------------------------------------------------------------------------
 struct Plan {
@@ -282,15 +286,17 @@ struct Plan {
   size_t dpl_off[DSDF_MAX_LAYERS], mask_off[DSDF_MAX_LAYERS], cs_off[DSDF_MAX_LAYERS], dwslab_off[DSDF_MAX_LAYERS];
   int nwg;
   DwSched dw;
-  DwSched dwph[2];   // two-phase backward: the schedule of the late layers [dw_k, last) and of the early layers [0, dw_k)
-  int dw_k;          // first layer of the late half (dw_bucket_layer)
+  DwSched dwph[DSDF_MAX_BUCKETS];   // phased backward: the schedule of bucket b's layers [dw_cut[b + 1], dw_cut[b])
+  int dw_nb, dw_cut[DSDF_MAX_BUCKETS + 1];   // dw_bucket_cuts
   // segment mode: U[R][2][ldu] of the hoisted layers, per-workgroup xyz sums [nwg][4][ldcs] for each of them
   int segmode, ldu, ldh;
   long long hstride;
   size_t hoistU_off, xsum_off[2], hs_off;   // hs: [2][maxout][ldh] x0 columns of the hoisted layers' weight gradients
 };
 
-Plan make_plan(const DsdfNet* n, int64_t N, int64_t R, bool inference, bool segmode = false) {
+// nb: the bucket count the workspace is laid out for (DsdfLossCfg.dw_buckets; every call of one step passes the same one).
+// 2 also serves the un-phased step, so dsdf_workspace_bytes' answer covers K <= 2.
+Plan make_plan(const DsdfNet* n, int64_t N, int64_t R, bool inference, bool segmode = false, int nb = 2) {
   Plan P;
   memset(&P, 0, sizeof(P));
   P.nl = n->n_layers; P.W0 = n->latent_size + n->geom_dim; P.N = (int)N; P.R = (int)R;
@@ -366,12 +372,12 @@ Plan make_plan(const DsdfNet* n, int64_t N, int64_t R, bool inference, bool segm
     P.cs_off[l] = take((size_t)P.nwg * P.ldcs * 4);
   }
   P.dw = dw_schedule(n, N, P.ld_in, segmode);
-  P.dw_k = dw_bucket_layer(n);
-  P.dwph[0] = dw_schedule(n, N, P.ld_in, segmode, P.dw_k, P.nl - 1);
-  P.dwph[1] = dw_schedule(n, N, P.ld_in, segmode, 0, P.dw_k);
+  P.dw_nb = nb < 2 ? 2 : (nb > DSDF_MAX_BUCKETS ? DSDF_MAX_BUCKETS : nb);
+  dw_bucket_cuts(n, P.dw_nb, P.dw_cut);
+  for (int t = 0; t < P.dw_nb; ++t) P.dwph[t] = dw_schedule(n, N, P.ld_in, segmode, P.dw_cut[t + 1], P.dw_cut[t]);
   for (int l = 0; l < P.nl - 1; ++l) {   // slabs sized for whichever schedule splits K finest: the layout does not depend on the phase
     int ns = P.dw.nsplit[l];
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < P.dw_nb; ++t)
       if (P.dwph[t].nsplit[l] > ns) ns = P.dwph[t].nsplit[l];
     P.dwslab_off[l] = take((size_t)ns * P.dw.slab[l] * 4);
   }
@@ -826,9 +832,10 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
                        int training, float* grads, int accumulate, int ncols_dz, bool* used_dzB, hipStream_t st,
                        bool want_dw, const FusedBwdHead& head, const FuseAdam* fz = nullptr, const SegBwd* sb = nullptr,
                        const FusedFwdArgs* fwd = nullptr,     // fwd: the deferred forward of the same points -> one launch for both
-                       int phase = 0) {                       // DsdfLossCfg.dw_phase: 1 = all but the early layers' dW + finalize, 2 = only those
+                       int phase = 0) {                       // DsdfLossCfg.dw_phase: 0 = everything; p >= 1: dW + finalize of bucket p - 1
+                                                              // only (p = 1: after the forward + backward launch and its roles)
   const DwSched& DS = phase == 0 ? P.dw : P.dwph[phase - 1];
-  auto in_phase = [&](int l) { return phase == 0 || (phase == 1 ? l >= P.dw_k : l < P.dw_k); };
+  auto in_phase = [&](int l) { return phase == 0 || (l >= P.dw_cut[phase] && l < P.dw_cut[phase - 1]); };
   DsdfParamLayout L;
   param_layout(net, &L);
   const Packed pk = packed_layout(net);
@@ -867,7 +874,7 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     wmac += (double)y.K * y.ncols;
   }
   a.n_layers = cnt;
-  if (phase != 2) {
+  if (phase <= 1) {
     // algorithmic FLOPs of the dX chain (the reference back-propagates through every hidden layer down to x0); the
     // executed count `wmac` is smaller: layer 0's dX and the skip layer's x0 columns come from column sums instead
     double amac = 0;
@@ -889,7 +896,7 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
   }
   const ReduceRowsArgs rr{at<float>(ws, P.part_off), P.nwg, P.ld_part, P.ld_part, at<float>(ws, P.part2_off), LAST_GROUPS};
   const int rr_bx = (P.ld_part + 63) / 64;
-  if (!segmode && phase != 2) {
+  if (!segmode && phase <= 1) {
     if (want_dw) {   // second stage of the head's per-workgroup partials
       hipLaunchKernelGGL(reduce_rows_kernel, dim3(rr_bx, LAST_GROUPS), dim3(256), 0, st, rr);
       LAUNCH_OK("reduce_rows_kernel");
@@ -934,9 +941,9 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
   static const bool no_ride = [] { const char* e = getenv("DSDF_NO_RIDE"); return e && e[0] == '1'; }();   // A/B switch
   // (gemm_split: the dW items finish in ~60 % of the time the riding roles need on the 16 spare workgroups -- they would be the
   // launch's tail, 462 us against 227; there the roles go out as a launch of their own, 18 us)
-  const bool post_rides = segmode && want_dw && cus - dw_busy >= 8 && P.nwg <= cus && !no_ride && !net->gemm_split && phase != 2 &&
+  const bool post_rides = segmode && want_dw && cus - dw_busy >= 8 && P.nwg <= cus && !no_ride && !net->gemm_split && phase <= 1 &&
                           dw_items > 0;
-  if (segmode && !post_rides && phase != 2) {
+  if (segmode && !post_rides && phase <= 1) {
     hipLaunchKernelGGL(post_bwd_kernel, dim3((unsigned)(q.rr_n + q.dw_n + lat_n)), dim3(256), 0, st, q);
     LAUNCH_OK("post_bwd_kernel");
   }
@@ -958,6 +965,12 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     PostBwdArgs none;
     memset(&none, 0, sizeof(none));
     int grid = dw_busy < 1 ? 1 : dw_busy;
+#ifdef DSDF_LAB
+    static unsigned long long* dwdbg = nullptr;      // lab: per-wave stamps of the LAST dW launch, dumped at every launch
+    if (!dwdbg && getenv("DSDF_LAB_DWDBG")) { (void)hipMalloc(&dwdbg, 1024 * 4 * 8 * 8); }
+    if (dwdbg) (void)hipMemsetAsync(dwdbg, 0, 1024 * 4 * 8 * 8, st);
+    d.dbg = dwdbg;
+#endif
     ProfScope ps(DSDF_PROF_DW_STREAM, fl, st);
     if (net->gemm_split) {
       if (post_rides) hipLaunchKernelGGL(dw_stream_split_kernel, dim3(cus), dim3(256), 0, st, d, q, lat_n, dw_busy);
@@ -965,6 +978,15 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     } else if (post_rides) hipLaunchKernelGGL(dw_stream_kernel, dim3(cus), dim3(256), 0, st, d, q, lat_n, dw_busy);
     else hipLaunchKernelGGL(dw_stream_kernel, dim3(grid), dim3(256), 0, st, d, none, 0, grid);
     LAUNCH_OK("dw_stream_kernel");
+#ifdef DSDF_LAB
+    if (dwdbg && getenv("DSDF_LAB_DWDBG")) {
+      (void)hipDeviceSynchronize();
+      static unsigned long long h[1024 * 4 * 8];
+      (void)hipMemcpy(h, dwdbg, sizeof(h), hipMemcpyDeviceToHost);
+      FILE* f = fopen(getenv("DSDF_LAB_DWDBG"), "wb");
+      if (f) { fwrite(h, 1, sizeof(h), f); fclose(f); }
+    }
+#endif
   }
   if (want_dw) {   // split-K sums, weight-norm backward and bias gradients of ALL layers (last layer included) in one launch
     FinAll fa;
@@ -1009,7 +1031,8 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
       ++fa.n;
     }
     fa.row0[fa.n] = rows;
-    if (segmode && sb->scatter != nullptr && phase != 2) {
+    if (rows == 0) return 0;   // an empty bucket (fewer layers than buckets)
+    if (segmode && sb->scatter != nullptr && phase <= 1) {
       hipLaunchKernelGGL(finalize_scatter_kernel, dim3(rows + sb->R), dim3(256), 0, st, fa, *sb->scatter, rows);
       LAUNCH_OK("finalize_scatter_kernel");
       *sb->scatter_done = true;
@@ -1081,17 +1104,40 @@ int dsdf_workspace_bytes(const DsdfNet* net, int64_t n_points, int64_t n_segment
   return 0;
 }
 
-int dsdf_grad_bucket_split(const DsdfNet* net, int32_t* first_late_layer, int64_t* arena_split) {
+int dsdf_workspace_bytes_buckets(const DsdfNet* net, int64_t n_points, int64_t n_segments, int32_t n_buckets, size_t* bytes) {
   TRY(validate(net));
-  if (!first_late_layer || !arena_split) return fail(DSDF_E_INVALID, "NULL argument");
+  if (!bytes || n_points < 0 || n_segments < 0) return fail(DSDF_E_INVALID, "bad arguments");
+  if (n_points > (1ll << 30)) return fail(DSDF_E_INVALID, "n_points too large");
+  if (n_buckets < 0 || n_buckets > DSDF_MAX_BUCKETS) return fail(DSDF_E_INVALID, "n_buckets %d out of range [0, %d]", n_buckets, DSDF_MAX_BUCKETS);
+  const size_t a = make_plan(net, n_points, n_segments, false, false, n_buckets).total;
+  const size_t b = make_plan(net, n_points, n_segments, false, true, n_buckets).total;
+  *bytes = a > b ? a : b;
+  return 0;
+}
+
+int dsdf_dw_phase_supported(const DsdfNet* net) {
+  TRY(validate(net));
+  return fused_enabled() && fused_eligible(net) ? 1 : 0;
+}
+
+int dsdf_grad_buckets(const DsdfNet* net, int32_t n_buckets, int32_t* first_layer, int64_t* arena_off) {
+  TRY(validate(net));
+  if (!first_layer || !arena_off) return fail(DSDF_E_INVALID, "NULL argument");
+  if (n_buckets < 2 || n_buckets > DSDF_MAX_BUCKETS) return fail(DSDF_E_INVALID, "n_buckets %d out of range [2, %d]", n_buckets, DSDF_MAX_BUCKETS);
   DsdfParamLayout L;
   param_layout(net, &L);
-  const int k = dw_bucket_layer(net);
-  int64_t o = L.v_off[k];                      // a layer's parameters are one contiguous block: its first offset
-  if (L.bias_off[k] >= 0 && L.bias_off[k] < o) o = L.bias_off[k];
-  if (L.g_off[k] >= 0 && L.g_off[k] < o) o = L.g_off[k];
-  *first_late_layer = k;
-  *arena_split = o;
+  int cut[DSDF_MAX_BUCKETS + 1];
+  dw_bucket_cuts(net, n_buckets, cut);
+  auto layer_start = [&](int k) {              // a layer's parameters are one contiguous block: its first offset
+    if (k >= net->n_layers) return L.total;
+    int64_t o = L.v_off[k];
+    if (L.bias_off[k] >= 0 && L.bias_off[k] < o) o = L.bias_off[k];
+    if (L.g_off[k] >= 0 && L.g_off[k] < o) o = L.g_off[k];
+    if (L.ln_w_off[k] >= 0 && L.ln_w_off[k] < o) o = L.ln_w_off[k];
+    return o;
+  };
+  arena_off[0] = L.total;                      // bucket b = layers [first_layer[b], ...) = arena floats [arena_off[b + 1], arena_off[b])
+  for (int b = 0; b < n_buckets; ++b) { first_layer[b] = cut[b + 1]; arena_off[b + 1] = layer_start(cut[b + 1]); }
   return 0;
 }
 
@@ -1372,22 +1418,24 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
                       skip_l != net->n_layers - 2 &&   // the deepest hidden layer's dP column sums live in the head's partials
                       net->geom_dim <= FGEO && net->latent_size <= HOIST_MAXL;   // (config 5 too: bf16 rounding is element-wise
                                                                                   // on the operands, so the latent products still hoist)
-  const Plan P = make_plan(net, n, R, false, segsum);
+  const int phase = cfg->dw_phase, nbk = cfg->dw_buckets;
+  if (nbk < 0 || nbk > DSDF_MAX_BUCKETS) return fail(DSDF_E_INVALID, "dw_buckets %d out of range [0, %d]", nbk, DSDF_MAX_BUCKETS);
+  if (phase < 0 || (nbk <= 1 ? phase != 0 : phase < 1 || phase > nbk))
+    return fail(DSDF_E_INVALID, "dw_phase %d out of range for dw_buckets %d (0 without buckets, 1..K with K >= 2)", phase, nbk);
+  const Plan P = make_plan(net, n, R, false, segsum, nbk);
   if (ws_bytes < P.total) return fail(DSDF_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, P.total);
   hipStream_t st = (hipStream_t)stream;
   const int Lc = net->latent_size;
-  const int phase = cfg->dw_phase;
-  if (phase < 0 || phase > 2) return fail(DSDF_E_INVALID, "dw_phase %d out of range", phase);
   if (phase != 0 && (!fusedb || cfg->frozen_decoder || accumulate || fz != nullptr))
-    return fail(DSDF_E_INVALID, "dw_phase needs the fused kernels, a trainable decoder, accumulate = 0 and the two-call path");
-  if (phase == 2) {   // only the weight gradients of the early layers, from what the phase-1 call left in the workspace
+    return fail(DSDF_E_INVALID, "dw_phase needs the fused kernels (dsdf_dw_phase_supported), a trainable decoder, accumulate = 0 and the two-call path");
+  if (phase >= 2) {   // only the weight gradients of bucket phase - 1, from what the phase-1 call left in the workspace
     FusedSeg seg0;
     memset(&seg0, 0, sizeof(seg0));
     const FusedBwdHead h0 = make_head(net, P, ws, packed, params, HEAD_TRAIN, cfg->training);
     const SegBwd sb0{&seg0, b->seg_scene, latent_table, (int)R, nullptr, nullptr};
     bool used = false;
     return run_backward_fused(net, P, ws, packed, params, n, cfg->training, grads, 0, segsum ? 0 : Lc, &used, st, true, h0, nullptr,
-                              segsum ? &sb0 : nullptr, nullptr, 2);
+                              segsum ? &sb0 : nullptr, nullptr, phase);
   }
 
   if (cfg->code_bound > 0.f || !accumulate) {   // max-norm renorm of the looked-up rows + zero of the dense latent gradient

@@ -30,7 +30,8 @@ struct DwLayer {
 };
 // Items: all full-width (128x128) items of all layers first, then the narrow edge items.  Full items go one per wave
 // (round-robin beyond that); the narrow ones are dealt to the waves that got no full item in the last round.
-struct DwArgs { int n_layers, n_full, n_narrow, N; DwLayer ly[DSDF_MAX_LAYERS]; };
+struct DwArgs { int n_layers, n_full, n_narrow, N; DwLayer ly[DSDF_MAX_LAYERS];
+                unsigned long long* dbg; };   // lab builds (-DDSDF_LAB): per-wave s_memrealtime stamps (100 MHz, chip-wide), else unused
 
 #ifndef DW_RING_STEPS
 #define DW_RING_STEPS 16
@@ -522,12 +523,29 @@ __device__ __forceinline__ void dw_stream_body(const DwArgs& p, const PostBwdArg
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: item, K range and the
   const int fr = lane & 31, fh = lane >> 5;                                                  // ring's bounds checks stay scalar
   const int lwg = xcd_remap(blockIdx.x, gridDim.x);
+#ifdef DSDF_LAB
+  // lab: [0] start, [1] end, [2] 1 = role workgroup, [3..5] time inside the three role kinds (wave 0 of a role workgroup)
+  unsigned long long* const dbgw = p.dbg ? p.dbg + (size_t)(lwg * 4 + w) * 8 : nullptr;
+  if (dbgw && lane == 0) { dbgw[0] = __builtin_amdgcn_s_memrealtime(); dbgw[2] = lwg >= busy_wg; }
+#endif
   if (lwg >= busy_wg) {
     const int total = post.rr_n + post.dw_n + post_lat_n;
+#ifdef DSDF_LAB
+    unsigned long long tk[3] = {0, 0, 0};
+#endif
     for (int i = lwg - busy_wg; i < total; i += (int)gridDim.x - busy_wg) {
       __syncthreads();   // the roles reuse their static LDS arrays
+#ifdef DSDF_LAB
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+#endif
       post_bwd_role(post, i);
+#ifdef DSDF_LAB
+      tk[i < post.rr_n ? 0 : (i < post.rr_n + post.dw_n ? 1 : 2)] += __builtin_amdgcn_s_memrealtime() - t0;
+#endif
     }
+#ifdef DSDF_LAB
+    if (dbgw && lane == 0) { dbgw[1] = __builtin_amdgcn_s_memrealtime(); dbgw[3] = tk[0]; dbgw[4] = tk[1]; dbgw[5] = tk[2]; }
+#endif
     return;
   }
   const int nwaves = busy_wg * 4;
@@ -592,6 +610,9 @@ __device__ __forceinline__ void dw_stream_body(const DwArgs& p, const PostBwdArg
       }
     }
   }
+#ifdef DSDF_LAB
+  if (dbgw && lane == 0) dbgw[1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 __global__ __launch_bounds__(256, 1) void dw_stream_kernel(const DwArgs p, const PostBwdArgs post, const int post_lat_n,

@@ -1,25 +1,26 @@
 """SDF sample files -> training batches.
 
-Host side mirrors the reference's deep_sdf/data.py (get_instance_filenames :15-33, remove_nans :61-63,
-unpack_sdf_samples :74-110, SDFSamples :142-194): ``.npz`` files with arrays ``pos`` / ``neg`` of shape [*, G+1]
-(xyz..., sdf), NaN rows filtered, balanced positive/negative subsample without replacement.
+On-disk format (the reference's, deep_sdf/data.py:74-80 and sdf_sampler/sdf_sampler.py:146): one ``.npz`` per scene with arrays
+``pos`` / ``neg`` of shape [*, G+1] (xyz..., sdf), float32 or float64, NaN rows possible.
 
-``DeviceSampleCache`` is the MI355X-side replacement of the DataLoader: every scene's filtered
-samples are uploaded ONCE into HBM (288 GB holds thousands of 50k-point scenes) and each step's balanced
-subsample is drawn on the device, so no per-step np.load / H2D copy remains.
+``DeviceSampleCache`` is the MI355X-side replacement of the reference's ``SDFSamples`` dataset + DataLoader workers
+(deep_sdf/data.py:142-194): every scene's filtered samples are uploaded ONCE into HBM (288 GB holds thousands
+of 50k-point scenes) and each step's balanced subsample is drawn on the device, so no per-step np.load / H2D copy remains.
+There is deliberately no host-side ``Dataset`` here: the trainer never iterates samples on the CPU.  What stays on the host
+is the file list (``get_instance_filenames``), the reader of one scene file (``load_scene``) and -- for tools that want one
+draw without a GPU, and for pinning the count rule to the reference (golden G12) -- ``unpack_sdf_samples``.
 """
 import logging
 import os
-import random
 
 import numpy as np
 import torch
-import torch.utils.data
 
 from . import workspace as ws
 
 
 def get_instance_filenames(data_source, split):
+    """Scene files of a split, in split order; a missing file only warns (deep_sdf/data.py:15-33)."""
     npzfiles = []
     for dataset in split:
         for class_name in split[dataset]:
@@ -32,12 +33,19 @@ def get_instance_filenames(data_source, split):
 
 
 def remove_nans(tensor, geom_dimension):
-    keep = ~torch.isnan(tensor[:, geom_dimension])
-    return tensor[keep, :].float()
+    """Rows whose sdf column is NaN are dropped; the rest as fp32 (deep_sdf/data.py:61-63)."""
+    return tensor[~torch.isnan(tensor[:, geom_dimension])].float()
+
+
+def load_scene(path, geom_dimension):
+    """One scene file -> (positives, negatives): fp32 [n, G+1] tensors without NaN rows."""
+    with np.load(path) as npz:
+        return tuple(remove_nans(torch.from_numpy(npz[k]), geom_dimension) for k in ("pos", "neg"))
 
 
 def _balanced_counts(n_pos, n_neg, subsample):
-    """deep_sdf/data.py:83-91: half each, a shortfall on one sign is taken from the other."""
+    """Rows per sign of one draw: half each, a shortfall of one sign is made up by the other (deep_sdf/data.py:83-91; pinned to
+    the reference's loader by golden G12)."""
     half = int(subsample / 2)
     if n_pos < half:
         return n_pos, 2 * half - n_pos
@@ -46,67 +54,15 @@ def _balanced_counts(n_pos, n_neg, subsample):
     return half, half
 
 
-def read_sdf_samples_into_ram(filename):
-    npz = np.load(filename)
-    return [torch.from_numpy(npz["pos"]).float(), torch.from_numpy(npz["neg"]).float()]
-
-
-def unpack_sdf_samples(filename, geom_dimension, subsample=None):
-    npz = np.load(filename)
-    pos = remove_nans(torch.from_numpy(npz["pos"]), geom_dimension)
-    neg = remove_nans(torch.from_numpy(npz["neg"]), geom_dimension)
+def unpack_sdf_samples(filename, geom_dimension, subsample=None, generator=None):
+    """One draw from one scene file ON THE HOST: positives first, then negatives, each without replacement; everything when
+    subsample is None (deep_sdf/data.py:74-110).  The trainer does not use this (DeviceSampleCache.sample draws on the GPU)."""
+    pos, neg = load_scene(filename, geom_dimension)
     if subsample is None:
         return torch.cat([pos, neg], 0)
     n_pos, n_neg = _balanced_counts(len(pos), len(neg), subsample)
-    sel_pos = torch.randperm(len(pos))[:n_pos]
-    sel_neg = torch.randperm(len(neg))[:n_neg]
-    return torch.cat([torch.index_select(pos, 0, sel_pos), torch.index_select(neg, 0, sel_neg)], 0)
-
-
-def unpack_sdf_samples_from_ram(data, subsample=None):
-    if subsample is None:
-        return torch.cat(data, 0)
-    pos, neg = data
-    half = int(subsample / 2)
-    p0 = random.randint(0, pos.shape[0] - half)
-    sample_pos = pos[p0:p0 + half]
-    if neg.shape[0] <= half:
-        sample_neg = torch.index_select(neg, 0, (torch.rand(half) * neg.shape[0]).long())
-    else:
-        n0 = random.randint(0, neg.shape[0] - half)
-        sample_neg = neg[n0:n0 + half]
-    return torch.cat([sample_pos, sample_neg], 0)
-
-
-class SDFSamples(torch.utils.data.Dataset):
-    """Host-side dataset with the reference's constructor and item format ``(samples [S, G+1], idx)``."""
-
-    def __init__(self, data_source, split, subsample, geom_dimension, load_ram=False, print_filename=False,
-                 num_files=1000000):
-        self.subsample = subsample
-        self.geom_dimension = geom_dimension
-        self.data_source = data_source
-        self.npyfiles = get_instance_filenames(data_source, split)
-        logging.debug("using " + str(len(self.npyfiles)) + " shapes from data source " + data_source)
-        self.load_ram = load_ram
-        if load_ram:
-            self.loaded_data = []
-            for f in self.npyfiles:
-                npz = np.load(self._path(f))
-                pos = remove_nans(torch.from_numpy(npz["pos"]), geom_dimension)
-                neg = remove_nans(torch.from_numpy(npz["neg"]), geom_dimension)
-                self.loaded_data.append([pos[torch.randperm(pos.shape[0])], neg[torch.randperm(neg.shape[0])]])
-
-    def _path(self, f):
-        return os.path.join(self.data_source, ws.sdf_samples_subdir, f)
-
-    def __len__(self):
-        return len(self.npyfiles)
-
-    def __getitem__(self, idx):
-        if self.load_ram:
-            return unpack_sdf_samples_from_ram(self.loaded_data[idx], self.subsample), idx
-        return unpack_sdf_samples(self._path(self.npyfiles[idx]), self.geom_dimension, self.subsample), idx
+    pick = lambda t, n: t[torch.randperm(len(t), generator=generator)[:n]]   # noqa: E731  (fewer rows than n: all of them, as the reference)
+    return torch.cat([pick(pos, n_pos), pick(neg, n_neg)], 0)
 
 
 class DeviceSampleCache:
@@ -139,11 +95,7 @@ class DeviceSampleCache:
 
     @staticmethod
     def from_files(data_source, npzfiles, geom_dimension, device):
-        items = []
-        for f in npzfiles:
-            npz = np.load(os.path.join(data_source, ws.sdf_samples_subdir, f))
-            items.append((remove_nans(torch.from_numpy(npz["pos"]), geom_dimension),
-                          remove_nans(torch.from_numpy(npz["neg"]), geom_dimension)))
+        items = [load_scene(os.path.join(data_source, ws.sdf_samples_subdir, f), geom_dimension) for f in npzfiles]
         return DeviceSampleCache(items, geom_dimension, device)
 
     def __len__(self):

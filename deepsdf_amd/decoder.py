@@ -9,6 +9,8 @@ arena (the layout the HIP kernels and the fused Adam use); gradients land in a s
 There is no CPU fallback: ``forward`` on a non-CUDA tensor raises.  ``xyz_in_all``, ``latent_dropout`` and the LayerNorm
 variant (norm_layers without weight_norm: modules ``bn{i}``) -- used by no shipped spec -- run on the layer-by-layer kernels.
 """
+import warnings
+
 import torch
 import torch.nn as nn
 
@@ -50,6 +52,9 @@ class _LayerNormParams(nn.Module):
         super().__init__()
         self.register_parameter("weight", None)
         self.register_parameter("bias", None)
+
+
+_warned_second_order = False
 
 
 class _DecoderBwdFn(torch.autograd.Function):
@@ -106,6 +111,15 @@ class _DecoderFn(torch.autograd.Function):
     def backward(ctx, dy):
         if dy is None:
             return (None,) * (2 + ctx.n_params)
+        if torch.is_grad_enabled() and ctx.need_x and not dy.requires_grad and not _warned_second_order:
+            # create_graph=True with a constant incoming gradient: the caller is about to differentiate d sdf / d input a second
+            # time (gradient penalty, eikonal loss) -- the one thing _DecoderBwdFn does not produce.  (The reference's own
+            # second-order use, torch.autograd.functional.jvp in deep_sdf/mesh.py:420, differentiates w.r.t. dy and is served.)
+            globals()["_warned_second_order"] = True
+            warnings.warn("deepsdf_amd.Decoder: backward(create_graph=True) through the HIP decoder is differentiable with respect to "
+                          "the incoming gradient only (the jvp double-backward trick); second-order terms through the input / the "
+                          "weights are NOT produced and would silently be missing from a later backward.  Use "
+                          "Decoder.export_torchscript() (stock torch ops) for gradient-penalty / eikonal losses.", stacklevel=2)
         out = _DecoderBwdFn.apply(ctx.dec, dy, ctx.token, ctx.n, ctx.training, ctx.need_x)
         return (None, out[0] if ctx.need_x else None) + tuple(out[1:])
 

@@ -28,11 +28,14 @@ def init(backend=None):
 
     Rehearsal knobs for a ONE-GPU box (tests/test_gpu_dist.py; the driver's multi-GPU runs use neither):
     DSDF_DIST_BACKEND=gloo selects the transport when the caller names none, DSDF_SINGLE_DEVICE=1 puts every rank on
-    device 0 (returned as local_rank), so that bench.py, the trainer and the tests' worker share one definition."""
+    device 0 (returned as local_rank), so that bench.py, the trainer and the tests' worker share one definition.
+    DSDF_DIST_FORCE_GROUP=1 creates the process group even for ONE rank and makes is_multi() true for it: the whole
+    data-parallel call sequence (asynchronous all-reduce on RCCL's stream, stream-ordered wait, object collectives) then
+    executes through real RCCL on a one-GPU box -- what gloo cannot show, because its wait() blocks the host."""
     rank, local, world = env_world()
     if os.environ.get("DSDF_SINGLE_DEVICE") == "1":
         local = 0
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_group()) and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("DSDF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -41,6 +44,16 @@ def init(backend=None):
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
+
+
+def force_group():
+    return os.environ.get("DSDF_DIST_FORCE_GROUP") == "1"
+
+
+def _active():
+    """A process group exists and the data-parallel call sequence applies to it (more than one rank, or the one-rank
+    rehearsal group of DSDF_DIST_FORCE_GROUP=1)."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_group())
 
 
 def replicas_identical(flat):
@@ -65,7 +78,7 @@ def owned_scenes(num_scenes, rank, world):
 
 def allreduce_sum_(flat):
     """In-place SUM all-reduce of a flat fp32 arena (no-op for a single process)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 
@@ -75,30 +88,30 @@ def allreduce_sum_async(flat):
     With the nccl (= RCCL) backend the collective runs on RCCL's own stream, ordered after everything already enqueued on
     the current stream; kernels enqueued on the current stream before ``work.wait()`` overlap with it, and ``wait()`` makes
     the current stream (not the host) wait.  With gloo (CPU tests, single-card rehearsal) ``wait()`` blocks the host."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
     return None
 
 
 def is_multi():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return _active()
 
 
 def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.barrier()
 
 
 def shutdown():
     """Leave the process group in step (barrier) and tear it down; a no-op for a single process."""
     if dist.is_available() and dist.is_initialized():
-        if dist.get_world_size() > 1:
+        if _active():
             dist.barrier()
         dist.destroy_process_group()
 
 
 def max_over_ranks(value, device):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

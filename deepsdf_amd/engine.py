@@ -102,9 +102,12 @@ class Engine:
             self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
         return self._ws
 
-    def train_workspace(self, n_points, n_segments):
+    def train_workspace(self, n_points, n_segments, buckets=0):
         b = C.c_size_t()
-        _lib.check(self.lib.dsdf_workspace_bytes(C.byref(self.cnet), n_points, n_segments, C.byref(b)))
+        if buckets > 2:      # finer split-K slabs than dsdf_workspace_bytes plans for
+            _lib.check(self.lib.dsdf_workspace_bytes_buckets(C.byref(self.cnet), n_points, n_segments, buckets, C.byref(b)))
+        else:
+            _lib.check(self.lib.dsdf_workspace_bytes(C.byref(self.cnet), n_points, n_segments, C.byref(b)))
         return self._workspace(b.value)
 
     # ---- weights -----------------------------------------------------------------------------------------
@@ -204,12 +207,15 @@ class Engine:
     # ---- training --------------------------------------------------------------------------------------------
     def train_forward_backward(self, latents, dlat, seg_scene, seg_offset, xyz, sdf_gt, *, n_norm, clamp_dist,
                                reg_coef, code_bound, training=True, seed=0, row_offset=0, accumulate=False,
-                               sdf_out=None, step=None, seg_len=0, frozen_decoder=False, loss_out=None, dw_phase=0):
+                               sdf_out=None, step=None, seg_len=0, frozen_decoder=False, loss_out=None, dw_phase=0,
+                               dw_buckets=None):
         """One chunk of train_deep_sdf.py:509-533.  Gradients land in self.grads / dlat, loss in self.loss (or in the
         caller's 1-element fp32 device tensor `loss_out`, e.g. a slot of a per-epoch loss buffer: no copy kernel per step)."""
         self._fresh_weights()
         n, R = xyz.shape[0], seg_scene.shape[0]
-        ws = self.train_workspace(n, R)
+        if dw_buckets is None:
+            dw_buckets = 2 if dw_phase else 0
+        ws = self.train_workspace(n, R, dw_buckets)
         b = _lib.DsdfBatch(seg_scene.data_ptr(), seg_offset.data_ptr(), R, xyz.data_ptr(), sdf_gt.data_ptr(), n,
                            int(n_norm), int(row_offset), int(seg_len))
         cfg = _lib.DsdfLossCfg()
@@ -217,7 +223,7 @@ class Engine:
         cfg.code_bound = float(code_bound) if code_bound is not None else -1.0
         cfg.training = int(training)
         cfg.frozen_decoder = int(frozen_decoder)
-        cfg.dw_phase = int(dw_phase)      # 1 / 2: the two halves of a two-bucket data-parallel backward (include/dsdf.h DsdfLossCfg)
+        cfg.dw_phase, cfg.dw_buckets = int(dw_phase), int(dw_buckets)   # phase p of a K-bucket data-parallel backward (include/dsdf.h)
         st = self.step if step is None else step
         for l in range(_lib.MAX_LAYERS):
             cfg.dropout_key[l] = dropout_layer_key(seed, st, l)
@@ -226,11 +232,24 @@ class Engine:
             C.byref(cfg), _ptr(self.grads), _ptr(dlat), _ptr(self.loss if loss_out is None else loss_out), _ptr(sdf_out),
             int(accumulate), _ptr(ws), ws.numel(), _stream()))
 
+    def dw_phase_supported(self):
+        """Whether this net's backward can run in phases (dsdf_dw_phase_supported: the library's own condition)."""
+        rc = self.lib.dsdf_dw_phase_supported(C.byref(self.cnet))
+        if rc < 0:
+            _lib.check(rc)
+        return rc == 1
+
+    def grad_buckets(self, k):
+        """The k gradient buckets of a phased backward, last layers first (dsdf_grad_buckets): (first_layer [k],
+        arena_off [k + 1]); bucket b = arena floats [arena_off[b + 1], arena_off[b])."""
+        first, off = (C.c_int32 * k)(), (C.c_int64 * (k + 1))()
+        _lib.check(self.lib.dsdf_grad_buckets(C.byref(self.cnet), k, first, off))
+        return list(first), list(off)
+
     def grad_bucket_split(self):
-        """(first layer of the late bucket, arena offset separating the two gradient buckets): dsdf_grad_bucket_split."""
-        k, off = C.c_int32(), C.c_int64()
-        _lib.check(self.lib.dsdf_grad_bucket_split(C.byref(self.cnet), C.byref(k), C.byref(off)))
-        return int(k.value), int(off.value)
+        """(first layer of the late bucket, arena offset separating the two gradient buckets) of a TWO-bucket backward."""
+        first, off = self.grad_buckets(2)
+        return first[0], off[1]
 
     def train_step(self, latents, dlat, lat_m, lat_v, seg_scene, seg_offset, xyz, sdf_gt, *, n_norm, clamp_dist, reg_coef,
                    code_bound, lr_decoder, lr_latent, training=True, seed=0, seg_len=0, betas=(0.9, 0.999), eps=1e-8,

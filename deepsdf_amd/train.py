@@ -240,9 +240,16 @@ class FusedTrainStep:
         self.lat_m, self.lat_v = torch.zeros_like(latents), torch.zeros_like(latents)
         self.clamp_dist, self.code_reg, self.lam = clamp_dist, code_reg, code_reg_lambda
         self.code_bound, self.grad_clip, self.seed = code_bound, grad_clip, seed
-        # DSDF_AR_BUCKETS=2 (data-parallel steps only): the decoder gradient is exchanged in two buckets -- the late layers'
-        # all-reduce runs under the early layers' weight-gradient launch.  Default 1: ONE all-reduce.
-        self.ar_buckets = 2 if os.environ.get("DSDF_AR_BUCKETS") == "2" else 1
+        # DSDF_AR_BUCKETS=K (2..8, data-parallel steps only): the decoder gradient is exchanged in K buckets, last layers first --
+        # bucket b's all-reduce runs under the weight-gradient launches of the buckets below it.  Default 1:
+        # ONE all-reduce.  Decided once, here: a net the fused kernels do not cover exchanges its gradient in one piece on every
+        # rank alike (ranks deciding differently would issue mismatched collectives).
+        from ._lib import MAX_BUCKETS
+        want = os.environ.get("DSDF_AR_BUCKETS", "1")
+        if not want.isdigit() or not 1 <= int(want) <= MAX_BUCKETS:
+            raise ValueError("DSDF_AR_BUCKETS must be an integer in [1, {}], got {!r}".format(MAX_BUCKETS, want))
+        self.ar_buckets = int(want) if int(want) > 1 and engine.dw_phase_supported() else 1
+        self._bucket_off = engine.grad_buckets(self.ar_buckets)[1] if self.ar_buckets > 1 else None
 
     def __call__(self, scene_rows, samples_per_scene, xyz, sdf_gt, epoch, lr_decoder, lr_latent, batch_split=1,
                  n_norm=None, under_allreduce=None, loss_out=None):
@@ -286,7 +293,8 @@ class FusedTrainStep:
         def fb(ci, sc, so, xc, gc, row0, phase=0):
             self.eng.train_forward_backward(self.lat, self.dlat, sc, so, xc, gc, n_norm=n_norm, clamp_dist=self.clamp_dist,
                                             reg_coef=reg, code_bound=self.code_bound, training=True, seed=self.seed,
-                                            row_offset=row0, accumulate=ci > 0, seg_len=uniform, loss_out=loss_out, dw_phase=phase)
+                                            row_offset=row0, accumulate=ci > 0, seg_len=uniform, loss_out=loss_out, dw_phase=phase,
+                                            dw_buckets=self.ar_buckets if phase else 0)
 
         # Data parallel (train_deep_sdf.py:353 replaced): a sum all-reduce of the decoder-gradient
         # arena, issued asynchronously (RCCL runs it on its own stream, ordered after the finalize launch that wrote the
@@ -294,23 +302,14 @@ class FusedTrainStep:
         # update of this rank's latent rows (their gradient is complete and private to the owner rank) and `under_allreduce`
         # (the trainer passes the NEXT batch's sampling kernel).  The decoder's Adam + weight re-materialisation wait for it.
         works = None
-        if self.ar_buckets == 2 and len(chunks) == 1 and (dist.is_multi() or force_dp):
-            # two buckets: phase 1 leaves the late layers' gradients in the arena -> their all-reduce starts and runs under
-            # phase 2, the early layers' weight-gradient launch + finalize -> the second bucket follows
-            from ._lib import DsdfError
-            try:
-                fb(0, *chunks[0], 0, phase=1)
-            except DsdfError as e:             # a net the fused kernels do not cover: rejected on the host, nothing was launched
-                if "dw_phase" not in str(e):
-                    raise
-                self.ar_buckets = 1
-            else:
-                if getattr(self, "_bucket_split", None) is None:
-                    self._bucket_split = self.eng.grad_bucket_split()[1]
-                cut = self._bucket_split
-                w0 = dist.allreduce_sum_async(self.eng.grads[cut:])
-                fb(0, *chunks[0], 0, phase=2)
-                works = [w0, dist.allreduce_sum_async(self.eng.grads[:cut])]
+        if self.ar_buckets > 1 and len(chunks) == 1 and (dist.is_multi() or force_dp):
+            # K buckets, last layers first: phase 1 leaves bucket 0's gradients in the arena -> their all-reduce starts and runs
+            # under phase 2 (the next bucket's weight-gradient launch + finalize) -> ... -> the last bucket follows
+            works, off = [], self._bucket_off
+            for p in range(1, self.ar_buckets + 1):
+                fb(0, *chunks[0], 0, phase=p)
+                if off[p] < off[p - 1]:          # (a net with fewer layers than buckets leaves trailing buckets empty)
+                    works.append(dist.allreduce_sum_async(self.eng.grads[off[p]:off[p - 1]]))
         if works is None:
             row0 = 0
             for ci, (sc, so, xc, gc) in enumerate(chunks):
@@ -367,6 +366,7 @@ def main_function(experiment_directory, continue_from, batch_split):
     log_frequency = get_spec_with_default(specs, "LogFrequency", 10)
 
     rank, local, world = dist.init()
+    multi = dist.is_multi()       # a process group drives the step: world > 1, or the one-rank rehearsal group (DSDF_DIST_FORCE_GROUP=1)
     if not torch.cuda.is_available():
         raise RuntimeError("train_deep_sdf (deepsdf_amd) needs an AMD GPU: the HIP training step has no CPU fallback")
     device = torch.device("cuda", local)
@@ -376,7 +376,7 @@ def main_function(experiment_directory, continue_from, batch_split):
     if not hasattr(decoder, "engine"):
         raise RuntimeError("NetworkArch '{}' does not resolve to the HIP decoder".format(specs["NetworkArch"]))
     geom_dimension = decoder.geom_dimension
-    if world > 1:      # identical replicas: rank 0's initialisation wins
+    if multi:      # identical replicas: rank 0's initialisation wins
         torch.distributed.broadcast(decoder._arena, src=0)
     eng = decoder.engine()
     logging.info("training with {} GPU(s), one process each".format(world))
@@ -393,7 +393,7 @@ def main_function(experiment_directory, continue_from, batch_split):
     # from the same seed and keeps its own rows
     full = torch.empty(num_scenes, latent_size)
     torch.nn.init.normal_(full, 0.0, get_spec_with_default(specs, "CodeInitStdDev", 1.0) / math.sqrt(latent_size))
-    if world > 1:
+    if multi:
         objs = [full if rank == 0 else None]
         torch.distributed.broadcast_object_list(objs, src=0)
         full = objs[0]
@@ -408,7 +408,7 @@ def main_function(experiment_directory, continue_from, batch_split):
                                     lr_schedules[0].get_learning_rate(0), lr_schedules[1].get_learning_rate(0))
 
     def gather_latents(t):
-        if world == 1:
+        if not multi:
             return t
         parts = [None] * world
         torch.distributed.all_gather_object(parts, t.detach().cpu())
@@ -416,7 +416,7 @@ def main_function(experiment_directory, continue_from, batch_split):
 
     def save_all(name, epoch):
         full_lat, full_m, full_v = gather_latents(lat), gather_latents(fused.lat_m), gather_latents(fused.lat_v)
-        if world > 1:      # rank 0's decoder is what gets saved: it must BE every rank's decoder (bit for bit)
+        if multi:      # rank 0's decoder is what gets saved: it must BE every rank's decoder (bit for bit)
             for what, arena in (("parameters", eng.params), ("exp_avg", eng.exp_avg), ("exp_avg_sq", eng.exp_avg_sq)):
                 if not dist.replicas_identical(arena):
                     raise RuntimeError("data-parallel replicas diverged: decoder {} differ between ranks at epoch {}".format(
@@ -425,7 +425,7 @@ def main_function(experiment_directory, continue_from, batch_split):
         if rank != 0:
             return
         save_model(experiment_directory, name, decoder, epoch)
-        if world == 1:
+        if not multi:
             save_optimizer(experiment_directory, name, optimizer_all, epoch)
         else:   # write the optimizer state of the FULL latent table
             tmp = AdamStateBridge(decoder, eng, torch.nn.Parameter(full_lat.to(device)), full_m.to(device), full_v.to(device),
@@ -442,7 +442,7 @@ def main_function(experiment_directory, continue_from, batch_split):
         lat.copy_(full_lat[lo:hi])
         model_epoch = ws.load_model_parameters(experiment_directory, continue_from, torch.nn.DataParallel(decoder))
         eng.weights_dirty = True
-        if world == 1:
+        if not multi:
             optimizer_epoch = load_optimizer(experiment_directory, continue_from + ".pth", optimizer_all)
         else:
             fm, fv = torch.zeros(num_scenes, latent_size, device=device), torch.zeros(num_scenes, latent_size, device=device)
@@ -470,7 +470,7 @@ def main_function(experiment_directory, continue_from, batch_split):
     # grows with the world size and the learning rate is NOT rescaled -- a different optimisation problem, opt-in only).
     n_local = hi - lo
     per_rank = os.environ.get("DSDF_SCENES_PER_BATCH_PER_RANK") == "1"
-    if world > 1 and not per_rank:
+    if multi and not per_rank:
         if scene_per_batch % world != 0:
             raise RuntimeError("ScenesPerBatch {} is not divisible by the {} data-parallel ranks (nn.DataParallel would split "
                                "the batch unevenly; set DSDF_SCENES_PER_BATCH_PER_RANK=1 for a per-rank batch)".format(
@@ -479,7 +479,7 @@ def main_function(experiment_directory, continue_from, batch_split):
     else:
         local_batch = scene_per_batch
     steps_per_epoch = n_local // local_batch                 # drop_last=True (:374)
-    if world > 1:                                            # every rank must take the same number of steps
+    if multi:                                            # every rank must take the same number of steps
         t = torch.tensor([steps_per_epoch], device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
         steps_per_epoch = int(t.item())
@@ -524,7 +524,7 @@ def main_function(experiment_directory, continue_from, batch_split):
             fused(scenes_dev, 2 * int(num_samp_per_scene / 2), xyz, sdf_gt, epoch, lr0, lr1,
                   batch_split=batch_split, n_norm=n_norm, under_allreduce=prefetch, loss_out=loss_buf[it:it + 1])
         lat_mag = None
-        if world > 1:
+        if multi:
             torch.distributed.all_reduce(loss_buf)           # per-rank partial losses share the global normaliser
             mag = torch.stack([torch.norm(lat.detach(), dim=1).sum(), torch.full((), float(n_local), device=device)])
             torch.distributed.all_reduce(mag)                # mean code magnitude over the WHOLE table (:548-552), not this shard's
@@ -550,5 +550,5 @@ def main_function(experiment_directory, continue_from, batch_split):
             save_all("latest.pth", epoch)
             if rank == 0:
                 save_logs(experiment_directory, loss_log, lr_log, timing_log, lat_mag_log, param_mag_log, epoch)
-    if world > 1:
+    if multi:
         dist.shutdown()

@@ -27,7 +27,8 @@ extern "C" {
 #endif
 
 #define DSDF_MAX_LAYERS 16
-#define DSDF_ABI_VERSION 13
+#define DSDF_ABI_VERSION 14
+#define DSDF_MAX_BUCKETS 8
 
 enum {
   DSDF_OK = 0,
@@ -104,13 +105,15 @@ typedef struct DsdfLossCfg {
   int32_t training;           /* 1: dropout active (decoder.train(), :477) */
   int32_t frozen_decoder;     /* 1: skip the decoder's weight gradients (latent-only optimisation, config 4); grads untouched */
   uint32_t dropout_key[DSDF_MAX_LAYERS]; /* [host-computed] per-layer hash keys (oracle: dropout_layer_key) */
-  int32_t dw_phase;           /* data-parallel steps that exchange the decoder gradient in TWO buckets (replaces nn.DataParallel's
-                                 reduce, train_deep_sdf.py:353): 0 = the whole backward in this call (default); 1 = everything except
-                                 the weight gradients of the early layers [0, k) -- on return (stream order) the arena holds the
-                                 gradients of layers [k, last], whose all-reduce can start; 2 = only the weight gradients of layers
-                                 [0, k), from the activations / dP the phase-1 call left in `ws` (same net, batch and workspace; nothing
-                                 else may touch `ws` in between).  k and the arena offset that separates the two buckets:
-                                 dsdf_grad_bucket_split.  Phases need the fused kernels, a trainable decoder and accumulate = 0. */
+  int32_t dw_phase;           /* data-parallel steps that exchange the decoder gradient in K = dw_buckets >= 2 buckets (replaces
+                                 nn.DataParallel's reduce, train_deep_sdf.py:353), one call per bucket: 0 = the whole backward in this call
+                                 (dw_buckets <= 1); 1 = everything except the weight gradients of the layers below bucket 0 -- on
+                                 return (stream order) the arena holds the gradients of bucket 0 (the LAST layers), whose all-reduce
+                                 can start; p in 2..K = only the weight gradients of bucket p - 1, from the activations / dP the
+                                 phase-1 call left in `ws` (same net, batch, workspace and dw_buckets; nothing else may touch `ws` in
+                                 between).  Buckets and their arena ranges: dsdf_grad_buckets.  Phases need the fused kernels
+                                 (dsdf_dw_phase_supported), a trainable decoder and accumulate = 0. */
+  int32_t dw_buckets;         /* K of dw_phase (0 or 1: no buckets); workspace: dsdf_workspace_bytes_buckets when K > 2 */
 } DsdfLossCfg;
 
 typedef struct DsdfAdamCfg {
@@ -128,9 +131,19 @@ int dsdf_packed_floats(const DsdfNet* net, int64_t* n_floats);            /* [ho
 int dsdf_workspace_bytes(const DsdfNet* net, int64_t n_points, int64_t n_segments, size_t* bytes); /* [host] train/module */
 int dsdf_decode_workspace_bytes(const DsdfNet* net, int64_t n_points, size_t* bytes);                /* [host] dsdf_decode */
 
-/* [host] the two gradient buckets of DsdfLossCfg.dw_phase: layers [*first_late_layer, last] form bucket 0 = arena floats
- * [*arena_split, total), layers [0, *first_late_layer) bucket 1 = arena floats [0, *arena_split). */
-int dsdf_grad_bucket_split(const DsdfNet* net, int32_t* first_late_layer, int64_t* arena_split);
+/* [host] workspace of a step that runs its backward in n_buckets phases (DsdfLossCfg.dw_buckets): the split-K slabs of a
+ * bucket's weight-gradient launch are finer than the whole launch's.  dsdf_workspace_bytes covers n_buckets <= 2. */
+int dsdf_workspace_bytes_buckets(const DsdfNet* net, int64_t n_points, int64_t n_segments, int32_t n_buckets, size_t* bytes);
+
+/* [host] 1 if this net's training step can run its backward in phases (the fused kernels take it; in this process: the
+ * DSDF_NO_FUSED switch counts), 0 if not (a caller then exchanges the gradient in ONE piece), < 0 for an invalid net. */
+int dsdf_dw_phase_supported(const DsdfNet* net);
+
+/* [host] the K = n_buckets (2..DSDF_MAX_BUCKETS) gradient buckets of DsdfLossCfg.dw_phase, in the order the backward
+ * finishes them (last layers first): bucket b = layers [first_layer[b], first_layer[b - 1]) (b = 0: up to the last layer)
+ * = arena floats [arena_off[b + 1], arena_off[b]); arena_off has K + 1 entries, arena_off[0] = total, arena_off[K] = 0.
+ * A net with fewer layers than buckets leaves trailing buckets empty. */
+int dsdf_grad_buckets(const DsdfNet* net, int32_t n_buckets, int32_t* first_layer, int64_t* arena_off);
 
 /* ---- weights -------------------------------------------------------------------------------------
  * W = g * v / ||v||_row for weight-normed layers (torch._weight_norm via parametrizations.weight_norm,

@@ -48,20 +48,40 @@ def test_layout_and_sizes(lib):
     assert b.value < 200e6
 
 
-def test_gradient_bucket_split(lib):
-    """dsdf_grad_bucket_split: where the two-bucket data-parallel backward (DsdfLossCfg.dw_phase) cuts the layers and the arena."""
+def test_gradient_buckets(lib):
+    """dsdf_grad_buckets: where the K-bucket data-parallel backward (DsdfLossCfg.dw_phase / dw_buckets) cuts the layers and the
+    arena; dsdf_dw_phase_supported; dsdf_workspace_bytes_buckets."""
     from deepsdf_amd.net import NetSpec
     spec = NetSpec(256, [512] * 8, 3, dropout=list(range(8)), dropout_prob=0.2, norm_layers=list(range(8)), latent_in=[4], weight_norm=True)
-    k, off = C.c_int32(), C.c_int64()
-    assert lib.dsdf_grad_bucket_split(C.byref(spec.c_struct()), C.byref(k), C.byref(off)) == 0
-    assert k.value == 4
-    first = min(p.offset for p in spec.params if p.layer == 4)
-    assert off.value == first == sum(p.numel for p in spec.params if p.layer < 4)
-    assert 0.35 < off.value / spec.n_params < 0.65                                  # two buckets of comparable size
+    net = spec.c_struct()
+    first, off = (C.c_int32 * 2)(), (C.c_int64 * 3)()
+    assert lib.dsdf_grad_buckets(C.byref(net), 2, first, off) == 0
+    assert list(first) == [4, 0] and off[0] == spec.n_params and off[2] == 0
+    assert off[1] == min(p.offset for p in spec.params if p.layer == 4) == sum(p.numel for p in spec.params if p.layer < 4)
+    assert 0.35 < off[1] / spec.n_params < 0.65                                     # two buckets of comparable size
+    first, off = (C.c_int32 * 4)(), (C.c_int64 * 5)()
+    assert lib.dsdf_grad_buckets(C.byref(net), 4, first, off) == 0
+    assert list(first) == [6, 4, 2, 0]
+    assert list(off) == [spec.n_params] + [sum(p.numel for p in spec.params if p.layer < k) for k in (6, 4, 2, 0)]
     plain = NetSpec(5, [48] * 3, 3)                                                 # no weight norm: weight first, then bias
-    assert lib.dsdf_grad_bucket_split(C.byref(plain.c_struct()), C.byref(k), C.byref(off)) == 0
-    assert k.value == 2 and off.value == min(p.offset for p in plain.params if p.layer == 2)
-    assert lib.dsdf_grad_bucket_split(C.byref(plain.c_struct()), None, C.byref(off)) == -1
+    first, off = (C.c_int32 * 2)(), (C.c_int64 * 3)()
+    assert lib.dsdf_grad_buckets(C.byref(plain.c_struct()), 2, first, off) == 0
+    assert first[0] == 2 and off[1] == min(p.offset for p in plain.params if p.layer == 2)
+    first, off = (C.c_int32 * 8)(), (C.c_int64 * 9)()                               # 4 layers, 8 buckets: empty buckets repeat an offset
+    assert lib.dsdf_grad_buckets(C.byref(plain.c_struct()), 8, first, off) == 0
+    assert list(first) == [3, 3, 2, 2, 1, 1, 0, 0] and off[0] == plain.n_params and off[8] == 0
+    assert all(off[b + 1] <= off[b] for b in range(8)) and off[1] == off[2]
+    assert lib.dsdf_grad_buckets(C.byref(plain.c_struct()), 2, None, off) == -1
+    assert lib.dsdf_grad_buckets(C.byref(plain.c_struct()), 1, first, off) == -1
+    assert lib.dsdf_grad_buckets(C.byref(plain.c_struct()), 9, first, off) == -1
+    assert lib.dsdf_dw_phase_supported(C.byref(net)) == 1
+    wide = NetSpec(8, [640] * 3, 3)                                                 # wider than the fused kernels take
+    assert lib.dsdf_dw_phase_supported(C.byref(wide.c_struct())) == 0
+    b2, b8 = C.c_size_t(), C.c_size_t()
+    assert lib.dsdf_workspace_bytes(C.byref(net), 16384, 64, C.byref(b2)) == 0
+    assert lib.dsdf_workspace_bytes_buckets(C.byref(net), 16384, 64, 2, C.byref(b8)) == 0 and b8.value == b2.value
+    assert lib.dsdf_workspace_bytes_buckets(C.byref(net), 16384, 64, 8, C.byref(b8)) == 0 and b8.value > b2.value
+    assert lib.dsdf_workspace_bytes_buckets(C.byref(net), 16384, 64, 9, C.byref(b8)) == -1
 
 
 def test_invalid_nets_rejected(lib):
@@ -248,6 +268,11 @@ def test_bf16x8_kloop_never_reloads_the_sources_of_the_mfma_in_front():
     assert asmcheck.mfma_src_reuse_distances(drained) == {}
     loop = [mk("ds_read_b128", "v[104:107], v9", 0), mf(8, 0, 100, 104), mk("s_cbranch_scc1", "65533", 16, target=0)]  # across the back-edge
     assert asmcheck.mfma_src_reuse_distances(loop) == {0: 0} and asmcheck.mfma_src_reuse_distances(loop, fall_through_only=True) == {}
+    assert asmcheck.mfma_src_reuse_distances(loop, edges="loops") == {0: 0}       # the build gate follows loop back-edges: the steady state
+    # ... but not a FORWARD branch over a guarded step's MFMAs (the path only exists together with the guard that skips the load too)
+    guarded = [mf(0, 0, 100, 104), mk("s_cbranch_vccnz", "2", 8, target=32), mf(16, 16, 108, 112), mf(24, 32, 116, 120),
+               mk("ds_read_b128", "v[104:107], v9", 32)]
+    assert asmcheck.mfma_src_reuse_distances(guarded, edges="loops") == {4: 2} and asmcheck.mfma_src_reuse_distances(guarded) == {4: 0}
     if not asmcheck.tools_available() or not os.path.exists(LIB):
         pytest.skip("ROCm LLVM tools or the built library are not available")
     worst, pairs = asmcheck.check_mfma_src_reuse(LIB, min_distance=2)

@@ -33,7 +33,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("buckets", [1, 2], ids=["one_allreduce", "two_buckets"])
+@pytest.mark.parametrize("buckets", [1, 2, 4], ids=["one_allreduce", "two_buckets", "four_buckets"])
 def test_two_rank_hip_step_equals_single_process_and_oracle(tmp_path, buckets):
     """buckets = 2 (DSDF_AR_BUCKETS=2): the decoder gradient travels in two all-reduces, the late layers' under the early layers'
     weight-gradient launch (DsdfLossCfg.dw_phase 1 / 2).  The K-split of the two half-launches is finer than the single launch's,
@@ -134,6 +134,72 @@ def test_two_rank_hip_step_equals_single_process_and_oracle(tmp_path, buckets):
             assert worst_elem(G[k], o["grads"][k]) <= GRAD_ELEM_TOL, (step, k)
             assert float((P[k].double() - o["params"][k]).abs().max()) <= (step + 1) * 1e-2 * 5e-4, (step, k)
         assert rel_err(lat_dp, o["lat"]) <= PARAM_TOL, step
+
+
+def test_dp_step_through_a_one_rank_rccl_group_is_bit_identical(tmp_path):
+    """The RCCL branch EXECUTES (round-3 review: `backend="nccl"`, the stream-ordered `work.wait()` and the object collectives had
+    only ever run as gloo): tests/rccl_worker.py, a fresh child, runs three steps of the 8 x 512 net through FusedTrainStep's
+    data-parallel call sequence twice -- without a group (DSDF_FORCE_DP_PATH=1) and through a one-rank `nccl` process group
+    (DSDF_DIST_FORCE_GROUP=1) -- with 1, 2 and 4 gradient buckets; parameters, both Adam moments, packed weights, gradients, the
+    latent rows and their moments and every step's loss must be bit-identical, and the trainer's object collectives and replica
+    check pass through the same group.  (Replaces nn.DataParallel, train_deep_sdf.py:353.)"""
+    L, n_scenes, S = 256, 8, 256
+    net = orc.make_net(L, **BIG)
+    params = orc.init_params(net, 71)
+    lat0 = torch.randn(n_scenes, L, generator=torch.Generator().manual_seed(72)) / math.sqrt(L)
+    lat0[3] *= 1.4 / lat0[3].norm()                         # a code above CodeBound: the renorm runs
+    steps = []
+    for step in range(3):
+        g = torch.Generator().manual_seed(730 + step)
+        xyz = torch.rand(n_scenes * S, 3, generator=g) * 2 - 1
+        gt = (xyz - 0.1).norm(dim=1, keepdim=True) - 0.45 + 0.02 * torch.randn(n_scenes * S, 1, generator=g)
+        steps.append(dict(xyz=xyz, gt=gt))
+    torch.save(dict(L=L, net_specs=BIG, params=params, lat0=lat0, n_scenes=n_scenes, S=S, delta=0.1, lam=1e-4, code_bound=1.0,
+                    epoch=57, lr=[5e-4, 1e-3], seed=41, steps=steps, buckets=[1, 2, 4]), os.path.join(str(tmp_path), "case.pt"))
+    env = dict(os.environ, DSDF_DIST_FORCE_GROUP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "DSDF_DIST_BACKEND", "DSDF_SINGLE_DEVICE", "DSDF_FORCE_DP_PATH", "DSDF_AR_BUCKETS",
+              "HSA_ENABLE_IPC_MODE_LEGACY"):               # (the last one: deepsdf_amd.dist must put the default in place itself)
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_worker.py"), str(tmp_path)], env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-4000:]
+    out = torch.load(os.path.join(str(tmp_path), "rccl.pt"), weights_only=True)
+    assert out["ok"] and out["backend"] == "nccl" and sorted(out["last_loss"]) == [1, 2, 4]
+    assert all(math.isfinite(v) and v > 0 for v in out["last_loss"].values())
+
+
+def test_trainer_through_a_one_rank_rccl_group(tmp_path):
+    """`train_deep_sdf.py -e DIR` with DSDF_DIST_FORCE_GROUP=1: the drop-in trainer's whole world > 1 leg (arena broadcast,
+    broadcast_object_list of the latent table, the phased gradient exchange with DSDF_AR_BUCKETS=4, all_gather_object for the
+    checkpoints, the replica check) runs through a one-rank RCCL group, writes the reference's artefacts and resumes."""
+    import json
+    from tests.test_gpu_module_trainer import _make_experiment
+    exp = _make_experiment(str(tmp_path), 4, specs_over={"NumEpochs": 2, "SnapshotFrequency": 2, "AdditionalSnapshots": [],
+                                                         "LogFrequency": 1, "SamplesPerScene": 1024})
+    script = os.path.join(ROOT, "train_deep_sdf.py")
+
+    def run(extra):
+        env = dict(os.environ, DSDF_DIST_FORCE_GROUP="1", DSDF_AR_BUCKETS="4", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "DSDF_DIST_BACKEND", "DSDF_SINGLE_DEVICE"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, script, "-e", exp] + extra, env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-4000:]
+        return r.stdout
+
+    out = run([])
+    assert out.count("decoder replicas bit-identical on 1 ranks") >= 2, out[-3000:]
+    lc = torch.load(os.path.join(exp, "LatentCodes", "latest.pth"), weights_only=True)
+    assert lc["epoch"] == 2 and lc["latent_codes"]["weight"].shape == (4, 4)
+    logs = torch.load(os.path.join(exp, "Logs.pth"), weights_only=True)
+    assert logs["epoch"] == 2 and len(logs["loss"]) == 4 and all(math.isfinite(v) for v in logs["loss"])
+    specs = json.load(open(os.path.join(exp, "specs.json")))
+    specs["NumEpochs"], specs["SnapshotFrequency"] = 4, 4
+    json.dump(specs, open(os.path.join(exp, "specs.json"), "w"))
+    out = run(["-c", "latest"])
+    assert "starting from epoch 3" in out, out[-3000:]
+    logs4 = torch.load(os.path.join(exp, "Logs.pth"), weights_only=True)
+    assert logs4["epoch"] == 4 and logs4["loss"][:4] == logs["loss"] and len(logs4["loss"]) == 8
 
 
 def _torchrun_two_ranks(script_args, timeout=900, **extra_env):

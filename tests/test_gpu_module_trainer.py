@@ -318,6 +318,30 @@ def test_decoder_jvp_vs_oracle(name):
         assert rel_err(p.grad.cpu(), go[pname].reshape(p.shape)) <= GRAD_TOL, pname
 
 
+def test_second_order_through_the_decoder_warns_once_and_the_jvp_trick_does_not():
+    """The HIP decoder's backward is differentiable w.r.t. the incoming gradient only (what deep_sdf/mesh.py:420 needs); a
+    create_graph=True backward with a CONSTANT incoming gradient (gradient penalty / eikonal loss) would silently miss its
+    second-order terms, so it warns -- once per process -- and names the stock-torch export twin as the way to do it."""
+    import warnings
+    import deepsdf_amd.decoder as D
+    dec = D.Decoder(5, [64, 64, 64], 3, norm_layers=[0, 1, 2], latent_in=[2], weight_norm=True).cuda().eval()
+    x = torch.randn(200, 8, device="cuda")
+    D._warned_second_order = False
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                       # the reference's double-backward jvp must stay silent
+        torch.autograd.functional.jvp(lambda q: dec(q), x, torch.randn_like(x))
+        xg = x.clone().requires_grad_(True)
+        dec(xg).sum().backward()                             # so must an ordinary backward
+    assert D._warned_second_order is False
+    xg = x.clone().requires_grad_(True)
+    with pytest.warns(UserWarning, match="second-order"):
+        (g,) = torch.autograd.grad(dec(xg).sum(), xg, create_graph=True)
+    assert g.shape == x.shape and D._warned_second_order is True
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                       # once per process
+        torch.autograd.grad(dec(xg).sum(), xg, create_graph=True)
+
+
 @pytest.mark.parametrize("name", ["g11a_xyz_in_all", "g11b_latent_dropout", "g11c_layer_norm"])
 def test_decoder_variants_module_path_vs_oracle(name):
     """xyz_in_all / latent_dropout / LayerNorm through the nn.Module seam (Decoder.forward + autograd) against the oracle: eval and train

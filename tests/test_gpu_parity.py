@@ -255,30 +255,61 @@ def _safe_batch(net, st64, B, S, seed, delta, code_bound, drop_seed, margin=2e-5
     raise RuntimeError("could not build a margin-safe batch")
 
 
+class _Snapshot:
+    """The oracle's optimiser state after a step (copies; attribute names of oracle.TrainState)."""
+
+    def __init__(self, st):
+        cp = lambda d: {k: v.clone() for k, v in d.items()}   # noqa: E731
+        self.params, self.m, self.v = cp(st.params), cp(st.m), cp(st.v)
+        self.latents, self.m_lat, self.v_lat, self.step = st.latents.clone(), st.m_lat.clone(), st.v_lat.clone(), st.step
+
+
+_HEADLINE = dict(L=256, B=64, S=256, param_seed=5, lat_seed=6, batch_seed=100, drop_seed=4242, epoch=57, st64=None, steps=[])
+
+
+def _headline_trajectory(n_steps):
+    """ONE float64 oracle trajectory of BASELINE config 2 at full size (64 scenes x 256 points, L = 256, 8x512, dropout 0.2, one code
+    above CodeBound, margin-safe batches), shared by every full-size test of the headline shape: the float64 steps are most of the
+    GPU suite's wall time (a 16384-point step plus the margin search is ~15 s of CPU), so they are computed once per session and
+    extended on demand.  Returns (net, params, lat0, steps); steps[i] = dict(idx, xyz, gt, r64 = the oracle's step result,
+    after = the oracle's state after the step)."""
+    H = _HEADLINE
+    net = orc.make_net(H["L"], **BIG)
+    params = orc.init_params(net, H["param_seed"])
+    lat0 = torch.randn(H["B"], H["L"], generator=torch.Generator().manual_seed(H["lat_seed"])) / math.sqrt(H["L"])
+    lat0[3] *= 2.5 / lat0[3].norm()
+    if H["st64"] is None:
+        H["st64"] = orc.TrainState.create({k: v.double() for k, v in params.items()}, lat0.double())
+    st64 = H["st64"]
+    while len(H["steps"]) < n_steps:
+        step = len(H["steps"])
+        idx, xyz, gt = _safe_batch(net, st64, H["B"], H["S"], H["batch_seed"] + step, 0.1, 1.0, H["drop_seed"])
+        r64 = orc.train_step(net, st64, idx, xyz.double(), gt.double(), delta=0.1, code_bound=1.0, epoch=H["epoch"], seed=H["drop_seed"])
+        H["steps"].append(dict(idx=idx, xyz=xyz, gt=gt, r64=r64, after=_Snapshot(st64)))
+    return net, params, lat0, H["steps"][:n_steps]
+
+
 def test_full_size_step_vs_oracle():
     """BASELINE config 2 at full size: 64 scenes x 256 pts = 16384 pts, L=256, 8x512, dropout 0.2: two optimiser
     steps of the HIP path against the oracle run in float64 (the truth) on identical seeded inputs; the fp32
     oracle's own distance from that truth is printed for scale."""
-    L, B, S = 256, 64, 256
-    net = orc.make_net(L, **BIG)
+    L = 256
+    net, params, lat0, traj = _headline_trajectory(2)
     spec = spec_from_meta(dict(L=L, net_specs=BIG))
-    params = orc.init_params(net, 5)
-    gen = torch.Generator().manual_seed(6)
-    lat0 = torch.randn(B, L, generator=gen) / math.sqrt(L)
-    lat0[3] *= 2.5 / lat0[3].norm()
-    st64 = orc.TrainState.create({k: v.double() for k, v in params.items()}, lat0.double())
     st32 = orc.TrainState.create({k: v.clone() for k, v in params.items()}, lat0.clone())
     tr = HipTrainer(spec, params, lat0)
-    for step in range(2):
-        idx, xyz, gt = _safe_batch(net, st64, B, S, 100 + step, 0.1, 1.0, 4242)
-        r64 = orc.train_step(net, st64, idx, xyz.double(), gt.double(), delta=0.1, code_bound=1.0, epoch=57, seed=4242)
-        r32 = orc.train_step(net, st32, idx, xyz, gt, delta=0.1, code_bound=1.0, epoch=57, seed=4242)
+    for step, t in enumerate(traj):
+        idx, xyz, gt, r64, st64 = t["idx"], t["xyz"], t["gt"], t["r64"], t["after"]
         rh = tr.step(idx, xyz, gt, delta=0.1, code_bound=1.0, code_reg=True, lam=1e-4, epoch=57, lr=(5e-4, 1e-3), seed=4242,
                      want_y=True)
         assert abs(rh["loss"] - r64["loss"]) <= 1e-5 * abs(r64["loss"])
         worst_h = max(rel_err(rh["grads"][k], r64["grads"][k]) for k in r64["grads"])
-        worst_o = max(rel_err(r32["grads"][k], r64["grads"][k]) for k in r64["grads"])
-        print(f"step {step}: max grad rel err vs fp64 truth: HIP {worst_h:.2e}, fp32 CPU oracle {worst_o:.2e}")
+        if step == 0:      # the fp32 CPU oracle's own distance from the float64 truth, for scale (one step: it is a print, not a check)
+            r32 = orc.train_step(net, st32, idx, xyz, gt, delta=0.1, code_bound=1.0, epoch=57, seed=4242)
+            worst_o = max(rel_err(r32["grads"][k], r64["grads"][k]) for k in r64["grads"])
+            print(f"step {step}: max grad rel err vs fp64 truth: HIP {worst_h:.2e}, fp32 CPU oracle {worst_o:.2e}")
+        else:
+            print(f"step {step}: max grad rel err vs fp64 truth: HIP {worst_h:.2e}")
         for k in r64["grads"]:
             assert rel_err(rh["grads"][k], r64["grads"][k]) <= GRAD_TOL, (step, k)
         assert rel_err(rh["dlat"], r64["dlat"]) <= GRAD_TOL
@@ -305,19 +336,14 @@ def test_gemm_split_full_size_step_and_decode_vs_oracle():
     (loss 1e-5, gradients 1e-4, post-Adam state), the forward on 70001 points (1e-5, and no ROW further than 1e-5 of the range), and
     bit-identical reruns."""
     from deepsdf_amd.engine import Engine
-    L, B, S = 256, 64, 256
-    net = orc.make_net(L, **BIG)
+    L = 256
+    net, params, lat0, traj = _headline_trajectory(2)        # the float64 steps test_full_size_step_vs_oracle compares with
     spec = spec_from_meta(dict(L=L, net_specs=dict(BIG, gemm_split=True)))
     assert spec.gemm_split and spec.c_struct().gemm_split == 1
-    params = orc.init_params(net, 5)
     gen = torch.Generator().manual_seed(6)
-    lat0 = torch.randn(B, L, generator=gen) / math.sqrt(L)
-    lat0[3] *= 2.5 / lat0[3].norm()
-    st64 = orc.TrainState.create({k: v.double() for k, v in params.items()}, lat0.double())
     tr = HipTrainer(spec, params, lat0)
-    for step in range(2):
-        idx, xyz, gt = _safe_batch(net, st64, B, S, 100 + step, 0.1, 1.0, 4242)
-        r64 = orc.train_step(net, st64, idx, xyz.double(), gt.double(), delta=0.1, code_bound=1.0, epoch=57, seed=4242)
+    for step, t in enumerate(traj):
+        idx, xyz, gt, r64, st64 = t["idx"], t["xyz"], t["gt"], t["r64"], t["after"]
         rh = tr.step(idx, xyz, gt, delta=0.1, code_bound=1.0, code_reg=True, lam=1e-4, epoch=57, lr=(5e-4, 1e-3), seed=4242)
         assert abs(rh["loss"] - r64["loss"]) <= 1e-5 * abs(r64["loss"])
         worst = max(rel_err(rh["grads"][k], r64["grads"][k]) for k in r64["grads"])
@@ -505,6 +531,20 @@ def test_segment_mode_odd_shapes_vs_oracle(name):
             assert rel_err(tr.lat.cpu(), st64.latents) <= ptol, (step, kw)
 
 
+_CONFIG5 = {}
+
+
+def _config5_oracle(net, params, lat0, B, S):
+    """The oracle's bf16-forward step of config 5 (fp32, the rounding points of Net.forward_bf16) on one margin-safe batch: computed
+    once, shared by the two parametrisations below."""
+    if not _CONFIG5:
+        st = orc.TrainState.create({k: v.clone() for k, v in params.items()}, lat0.clone())
+        st64 = orc.TrainState.create({k: v.double() for k, v in params.items()}, lat0.double())
+        idx, xyz, gt = _safe_batch(net, st64, B, S, 100, 0.1, 1.0, 4242)   # clamp/sign margins; ReLU flips cannot be excluded here:
+        _CONFIG5.update(idx=idx, xyz=xyz, gt=gt, ro=orc.train_step(net, st, idx, xyz, gt, delta=0.1, code_bound=1.0, epoch=57, seed=4242))
+    return _CONFIG5["idx"], _CONFIG5["xyz"], _CONFIG5["gt"], _CONFIG5["ro"]
+
+
 @pytest.mark.parametrize("split", [False, True], ids=["fp32_backward", "split_backward"])
 def test_config5_bf16_forward_vs_oracle_and_fp32(split):
     """BASELINE config 5: hidden-layer forward GEMMs with bf16 inputs / fp32 accumulate (v_mfma_f32_32x32x16_bf16), backward and
@@ -530,10 +570,7 @@ def test_config5_bf16_forward_vs_oracle_and_fp32(split):
     assert e_or <= 1e-4
     assert 1e-4 <= e_32 <= 1e-2                      # bf16 really is in the loop, and inside the re-stated tolerance
     # (2) one optimiser step: gradients and post-Adam state against the oracle's bf16-forward step
-    st = orc.TrainState.create({k: v.clone() for k, v in params.items()}, lat0.clone())
-    st64 = orc.TrainState.create({k: v.double() for k, v in params.items()}, lat0.double())
-    idx, xyz, gt = _safe_batch(net, st64, B, S, 100, 0.1, 1.0, 4242)   # clamp/sign margins; ReLU flips cannot be excluded here:
-    ro = orc.train_step(net, st, idx, xyz, gt, delta=0.1, code_bound=1.0, epoch=57, seed=4242)
+    idx, xyz, gt, ro = _config5_oracle(net, params, lat0, B, S)
     tr = HipTrainer(spec, params, lat0)
     rh = tr.step(idx, xyz, gt, delta=0.1, code_bound=1.0, code_reg=True, lam=1e-4, epoch=57, lr=(5e-4, 1e-3), seed=4242)
     assert abs(rh["loss"] - ro["loss"]) <= 1e-4 * abs(ro["loss"])
@@ -622,23 +659,18 @@ def test_fast_path_train_step_vs_oracle_full_size():
     through them against the oracle's forward with the oracle's post-Adam parameters."""
     from deepsdf_amd.engine import make_segments
     L, B, S = 256, 64, 256
-    net = orc.make_net(L, **BIG)
+    net, params, lat0, traj = _headline_trajectory(3)        # (one code above CodeBound: the renorm fires on the fast path)
     spec = spec_from_meta(dict(L=L, net_specs=BIG))
-    params = orc.init_params(net, 15)
-    lat0 = torch.randn(B, L, generator=torch.Generator().manual_seed(16)) / math.sqrt(L)
-    lat0[7] *= 1.9 / lat0[7].norm()                         # one code above CodeBound: the renorm fires on the fast path
-    st64 = orc.TrainState.create({k: v.double() for k, v in params.items()}, lat0.double())
     tr = HipTrainer(spec, params, lat0)
     eng = tr.eng
     grads_before = eng.grads.clone()
     batches = []
-    for step in range(3):
-        idx, xyz, gt = _safe_batch(net, st64, B, S, 700 + step, 0.1, 1.0, 99)
-        r64 = orc.train_step(net, st64, idx, xyz.double(), gt.double(), delta=0.1, code_bound=1.0, epoch=57, seed=99)
+    for step, t in enumerate(traj):
+        idx, xyz, gt, r64, st64 = t["idx"], t["xyz"], t["gt"], t["r64"], t["after"]
         sc, so = make_segments(idx.cuda())
         eng.train_step(tr.lat, tr.dlat, tr.lat_m, tr.lat_v, sc, so, xyz.cuda().contiguous(), gt.reshape(-1).cuda().contiguous(),
                        n_norm=B * S, clamp_dist=0.1, reg_coef=1e-4 * min(1, 57 / 100), code_bound=1.0, lr_decoder=5e-4,
-                       lr_latent=1e-3, seed=99, seg_len=S)
+                       lr_latent=1e-3, seed=4242, seg_len=S)
         assert eng.step == st64.step == step + 1
         assert abs(float(eng.loss) - r64["loss"]) <= 1e-5 * abs(r64["loss"]), step
         P, M, V = tr.params(), tr.adam_m(), tr.adam_v()
@@ -677,19 +709,20 @@ def test_fast_path_train_step_vs_oracle_full_size():
     tr2 = HipTrainer(spec, params, lat0)
     for sc, so, xc, gc in batches:
         tr2.eng.train_step(tr2.lat, tr2.dlat, tr2.lat_m, tr2.lat_v, sc, so, xc, gc, n_norm=B * S, clamp_dist=0.1,
-                           reg_coef=1e-4 * min(1, 57 / 100), code_bound=1.0, lr_decoder=5e-4, lr_latent=1e-3, seed=99, seg_len=S)
+                           reg_coef=1e-4 * min(1, 57 / 100), code_bound=1.0, lr_decoder=5e-4, lr_latent=1e-3, seed=4242, seg_len=S)
     for name in ("params", "exp_avg", "exp_avg_sq", "packed", "loss"):
         assert torch.equal(getattr(tr2.eng, name), getattr(eng, name)), name
     for name in ("lat", "lat_m", "lat_v", "dlat"):
         assert torch.equal(getattr(tr2, name), getattr(tr, name)), name
 
 
-@pytest.mark.parametrize("S", [7936, 8000])
+@pytest.mark.parametrize("S", [8000, 8001], ids=["8000_segment_mode", "8001_ragged"])
 def test_config4_reconstruct_full_size_vs_oracle(S):
     """BASELINE config 4 at full size: reconstruct() (frozen 8x512 decoder in eval mode, Adam on the codes only) against
     oracle.latent_step in float64, 6 iterations, TWO shapes at once (each shape must follow its own single-code oracle
-    trajectory).  S = 7936 = 124 x 64 is what reconstruct.py uses (segment mode: the code's products hoisted, the latent
-    gradient from per-workgroup column sums); S = 8000 is the configured count and takes the general (ragged) path."""
+    trajectory).  S = 8000 = 125 x 64 is the configured count and what reconstruct.py uses: whole 64-point workgroups per shape,
+    i.e. SEGMENT MODE (the code's products hoisted, the latent gradient from per-workgroup column sums).  S = 8001 is not a
+    multiple of 64 and takes the general (ragged) frozen-decoder path: gather + full per-point dX chain + seg_reduce."""
     from deepsdf_amd.engine import Engine
     from deepsdf_amd.reconstruct import reconstruct
     L, Bz, iters = 256, 2, 6
@@ -712,6 +745,7 @@ def test_config4_reconstruct_full_size_vs_oracle(S):
         xyz[:, :half] = c[:, None, :] + r[:, None, None] * d / d.norm(dim=2, keepdim=True) + 0.05 * torch.randn(Bz, half, 3, generator=gen)
         sdf = (xyz - c[:, None, :]).norm(dim=2) - r[:, None]
         for b in range(Bz):
+            assert (S % 64 == 0) == (S == 8000)
             # margin-safe points (as _safe_batch: a clamp / sign flip of ONE point moves 1/S = 1.3e-4 of the code's gradient, and
             # Adam's early steps ~ lr * g / |g| pass that on undamped): re-draw what the float64 oracle calls close
             for _ in range(12):
@@ -869,13 +903,17 @@ PHASE_NETS = {
 
 
 @pytest.mark.parametrize("ragged", [False, True], ids=["segments", "ragged"])
+@pytest.mark.parametrize("K", [2, 4, 8], ids=["K2", "K4", "K8"])
 @pytest.mark.parametrize("name", sorted(PHASE_NETS))
-def test_two_phase_backward_equals_the_single_call(name, ragged):
-    """DsdfLossCfg.dw_phase (the two-bucket gradient exchange of a data-parallel step): phase 1 = forward, backward and the weight
-    gradients of the late layers, phase 2 = the weight gradients of the early layers from what phase 1 left in the workspace.
-    Against the single call on the same batch: loss, forward and latent gradient bit-identical (the same launches produce them),
-    weight gradients equal to summation order (the two half-launches split K finer); after phase 1 alone the late bucket is
-    already final and the early bucket untouched."""
+def test_phased_backward_equals_the_single_call(name, K, ragged):
+    """DsdfLossCfg.dw_phase / dw_buckets (the K-bucket gradient exchange of a data-parallel step): phase 1 = forward, backward and
+    the weight gradients of bucket 0 (the LAST layers), phase p = the weight gradients of bucket p - 1 from what phase 1 left in
+    the workspace.  Against the single call on the same batch: loss, forward and latent gradient bit-identical (the same launches
+    produce them), weight gradients equal to summation order (a bucket's launch splits K finer); after phase p the buckets
+    [0, p) are final and the others untouched.  K = 8 on the small nets leaves trailing buckets EMPTY (fewer layers than
+    buckets)."""
+    if K == 8 and ragged and name.startswith("8x512"):
+        pytest.skip("K = 8 on the big net is covered in segment mode; the ragged path differs only in launches phase 1 owns")
     c = PHASE_NETS[name]
     L, B, S = c["L"], c["B"], c["S"]
     spec = spec_from_meta(dict(L=L, net_specs=c["net"]))
@@ -884,34 +922,47 @@ def test_two_phase_backward_equals_the_single_call(name, ragged):
     idx, xyz, gt = _big_batch(B, S, 79)
     from deepsdf_amd.engine import make_segments
     one, two = HipTrainer(spec, params, lat0), HipTrainer(spec, params, lat0)
-    k, cut = one.eng.grad_bucket_split()
-    assert 0 < cut < spec.n_params and 0 < k < spec.n_layers
+    assert one.eng.dw_phase_supported()
+    first, off = one.eng.grad_buckets(K)
+    assert off[0] == spec.n_params and off[K] == 0 and all(off[b + 1] <= off[b] for b in range(K))
+    assert off[1] < spec.n_params and first[K - 1] == 0 and all(first[b + 1] <= first[b] for b in range(K - 1))
+    for b in range(K):                                          # a bucket's arena range is exactly its layers' parameters
+        lo_l, hi_l = first[b], (first[b - 1] if b else spec.n_layers)
+        assert off[b] - off[b + 1] == sum(p.numel for p in spec.params if lo_l <= p.layer < hi_l), b
+    if K == 2:
+        assert one.eng.grad_bucket_split() == (first[0], off[1])
     sc, so = make_segments(idx.cuda())
     xc, gc = xyz.cuda().contiguous(), gt.reshape(-1).cuda().contiguous()
     kw = dict(n_norm=B * S, clamp_dist=0.1, reg_coef=1e-4, code_bound=1.0, training=True, seed=5, seg_len=0 if ragged else S)
     y1, y2 = torch.empty(B * S, device="cuda"), torch.empty(B * S, device="cuda")
     one.eng.train_forward_backward(one.lat, one.dlat, sc, so, xc, gc, sdf_out=y1, **kw)
     two.eng.grads.fill_(float("nan"))                          # whatever a phase does not write stays NaN
-    two.eng.train_forward_backward(two.lat, two.dlat, sc, so, xc, gc, sdf_out=y2, dw_phase=1, **kw)
-    g_mid = two.eng.grads.clone()
-    assert bool(torch.isnan(g_mid[:cut]).all()) and not bool(torch.isnan(g_mid[cut:]).any())
-    two.eng.train_forward_backward(two.lat, two.dlat, sc, so, xc, gc, dw_phase=2, **kw)
-    assert torch.equal(two.eng.grads[cut:], g_mid[cut:])        # phase 2 leaves the late bucket alone
+    for p in range(1, K + 1):
+        before = two.eng.grads.clone()
+        two.eng.train_forward_backward(two.lat, two.dlat, sc, so, xc, gc, sdf_out=y2 if p == 1 else None, dw_phase=p, dw_buckets=K, **kw)
+        g = two.eng.grads
+        assert bool(torch.isnan(g[:off[p]]).all()) and not bool(torch.isnan(g[off[p]:]).any()), p
+        assert torch.equal(g[off[p - 1]:], before[off[p - 1]:]), p      # phase p leaves the finished buckets alone
     assert torch.equal(y1, y2) and torch.equal(one.eng.loss, two.eng.loss) and torch.equal(one.dlat, two.dlat)
     assert torch.equal(one.lat, two.lat)                        # (the renorm ran once, in phase 1)
     g1, g2 = one.eng.named_views(one.eng.grads), two.eng.named_views(two.eng.grads)
     worst = max(rel_err(g2[n].cpu(), g1[n].cpu()) for n in g1)
-    print(f"{name} {'ragged' if ragged else 'segments'}: two-phase vs single-call weight gradients, worst rel {worst:.2e}")
+    print(f"{name} K={K} {'ragged' if ragged else 'segments'}: phased vs single-call weight gradients, worst rel {worst:.2e}")
     for n in g1:
         assert rel_err(g2[n].cpu(), g1[n].cpu()) <= 2e-6 and worst_elem(g2[n].cpu(), g1[n].cpu()) <= 1e-5, n
-    # a second two-phase run reproduces the first bit for bit
+    # a second phased run reproduces the first bit for bit
     again = HipTrainer(spec, params, lat0)
-    again.eng.train_forward_backward(again.lat, again.dlat, sc, so, xc, gc, dw_phase=1, **kw)
-    again.eng.train_forward_backward(again.lat, again.dlat, sc, so, xc, gc, dw_phase=2, **kw)
+    for p in range(1, K + 1):
+        again.eng.train_forward_backward(again.lat, again.dlat, sc, so, xc, gc, dw_phase=p, dw_buckets=K, **kw)
     assert torch.equal(again.eng.grads, two.eng.grads)
-    # phases are refused where they cannot work: gradient accumulation (batch_split chunks), a frozen decoder
+    # phases are refused where they cannot work: gradient accumulation (batch_split chunks), a frozen decoder, a phase without or
+    # beyond its bucket count
     from deepsdf_amd._lib import DsdfError
     with pytest.raises(DsdfError, match="dw_phase"):
-        two.eng.train_forward_backward(two.lat, two.dlat, sc, so, xc, gc, dw_phase=1, accumulate=True, **kw)
+        two.eng.train_forward_backward(two.lat, two.dlat, sc, so, xc, gc, dw_phase=1, dw_buckets=K, accumulate=True, **kw)
     with pytest.raises(DsdfError, match="dw_phase"):
-        two.eng.train_forward_backward(two.lat, two.dlat, sc, so, xc, gc, dw_phase=2, frozen_decoder=True, **kw)
+        two.eng.train_forward_backward(two.lat, two.dlat, sc, so, xc, gc, dw_phase=2, dw_buckets=K, frozen_decoder=True, **kw)
+    with pytest.raises(DsdfError, match="dw_phase"):
+        two.eng.train_forward_backward(two.lat, two.dlat, sc, so, xc, gc, dw_phase=K + 1, dw_buckets=K, **kw)
+    with pytest.raises(DsdfError, match="dw_phase"):
+        two.eng.train_forward_backward(two.lat, two.dlat, sc, so, xc, gc, dw_phase=1, dw_buckets=1, **kw)

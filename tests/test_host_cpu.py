@@ -50,9 +50,9 @@ def test_data_pipeline(tmp_path, caplog):
     assert int((s[:, 3] > 0).sum()) == 30 and s.shape[0] == 100    # 30 pos + 70 neg
     full = data.unpack_sdf_samples(os.path.join(root, "SdfSamples", files[0]), 3)
     assert full.shape[0] == 500 - 7 + 400
-    ds = data.SDFSamples(root, {"ds": {"cls": ["a", "b"]}}, 64, 3)
-    smp, idx = ds[1]
-    assert smp.shape == (64, 4) and idx == 1
+    pos, neg = data.load_scene(os.path.join(root, "SdfSamples", files[0]), 3)
+    assert pos.shape == (493, 4) and neg.shape == (400, 4) and pos.dtype == neg.dtype == torch.float32
+    assert not hasattr(data, "SDFSamples")                        # no host-side Dataset: the trainer samples on the device
     cache = data.DeviceSampleCache.from_files(root, files[:2], 3, "cpu")   # bookkeeping only: sampling is a HIP kernel
     assert (cache.n_pos, cache.n_neg) == ([493, 30], [400, 600]) and cache.pos_start == [0, 893] and cache.neg_start == [493, 923]
     assert cache.data.shape == (1523, 4)

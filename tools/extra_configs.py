@@ -1,5 +1,5 @@
-"""Non-headline configurations quoted in DESIGN.md: BASELINE config 4 (latent-only reconstruction, 8000 pts/iter per shape,
-batched over shapes) and the locality extreme of config 2 (ONE scene x 16384 points per step)."""
+"""Non-headline configurations quoted in DESIGN.md: BASELINE config 4 (latent-only reconstruction, 8000 = 125 x 64 pts/iter per
+shape: segment mode; batched over shapes) and the locality extreme of config 2 (ONE scene x 16384 points per step)."""
 import math, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
@@ -9,9 +9,8 @@ from deepsdf_amd.reconstruct import reconstruct
 dev = torch.device("cuda", 0)
 eng = Engine(NetSpec(bench.L, **bench.NET), dev)
 eng.init_like_reference(torch.Generator().manual_seed(0))
-# config 4: B shapes x 8000 (-> 7936 = 124 x 64) points, frozen decoder, 100 iterations
-for B in (1, 16, 64):
-    S = 7936
+# config 4: B shapes x 8000 (= 125 x 64: segment mode) points, frozen decoder, 100 iterations; 8001: the ragged path
+for B, S in ((1, 8000), (1, 8001), (16, 8000), (64, 8000)):
     xyz = torch.rand(B, S, 3, device=dev) * 2 - 1
     sdf = xyz.norm(dim=2) - 0.5
     reconstruct(eng, xyz, sdf, num_iterations=20)
