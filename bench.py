@@ -42,6 +42,19 @@ PEAK_TFLOPS = 157.3          # fp32 MFMA dense peak, MI355X_MICROARCH.md "Peak F
 NET = dict(dims=[512] * 8, dropout=list(range(8)), dropout_prob=0.2, norm_layers=list(range(8)), latent_in=[4],
            xyz_in_all=False, use_tanh=False, latent_dropout=False, weight_norm=True, geom_dimension=3)
 HEADLINE = dict(code_length=256, scenes_per_batch=64, samples=256)     # 64 scenes x 256 samples = 16384 pts/step
+# --network: the NetworkSpecs the reference SHIPS beside the 8x512 headline net, each with its own CodeLength and the
+# shipped batch shape (SamplesPerScene 16000, ScenesPerBatch 10).  NOT the headline: these nets are HBM / latency bound, not MFMA bound.
+_SHIPPED = dict(dropout=list(range(8)), dropout_prob=0.2, norm_layers=list(range(8)), xyz_in_all=False, latent_dropout=False,
+                weight_norm=True, geom_dimension=3)
+NETWORKS = {
+    "8x512": dict(net=NET, defaults=HEADLINE, ref="examples/sofas/specs.json:8-43"),
+    "6x128": dict(net=dict(_SHIPPED, dims=[128] * 6, latent_in=[2], use_tanh=False), ref="experiments/round_cross_big_network/specs.json:8-19",
+                  defaults=dict(code_length=1, scenes_per_batch=10, samples=16000)),
+    "4x64": dict(net=dict(_SHIPPED, dims=[64] * 4, latent_in=[1], use_tanh=True), ref="experiments/corner_spheres_only_small_network/specs.json",
+                 defaults=dict(code_length=2, scenes_per_batch=10, samples=16000)),
+    "4x32": dict(net=dict(_SHIPPED, dims=[32] * 4, latent_in=[2], use_tanh=False), ref="experiments/double_lattice_3D_small_network/specs.json",
+                 defaults=dict(code_length=2, scenes_per_batch=10, samples=16000)),
+}
 L = HEADLINE["code_length"]      # (tools/ scripts that build the headline net import this)
 
 
@@ -78,7 +91,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(L, B, S, headline):
+def cpu_baseline(L, B, S, headline, NET=NET):
     """The reference's CPU path restated in stock torch ops (oracle/torch_native.py: F.linear + autograd + nn.Embedding(max_norm)
     + torch.optim.Adam, hash dropout masks injected) timed on this host on a bounded sample of the SAME workload (full 16384-pt
     config-2 optimiser steps), with NO child process alive (the PMC passes have been joined before this is called):
@@ -158,10 +171,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--scenes-per-batch", type=int, default=64,
-                    help="NOT the headline config: scale the batch (x --samples) to see other batch shapes")
-    ap.add_argument("--samples", type=int, default=256, help="samples per scene (headline: 256)")
-    ap.add_argument("--code-length", type=int, default=256,
+    ap.add_argument("--network", choices=sorted(NETWORKS), default="8x512",
+                    help="8x512 = the headline decoder.  NOT the headline otherwise: a NetworkSpecs the reference ships (6x128 latent_in [2]; "
+                         "4x64 latent_in [1] use_tanh; 4x32 latent_in [2]), with that experiment's CodeLength and batch shape as the defaults "
+                         "of --code-length / --scenes-per-batch / --samples")
+    ap.add_argument("--scenes-per-batch", type=int, default=None,
+                    help="NOT the headline config: scale the batch (x --samples) to see other batch shapes (headline: 64)")
+    ap.add_argument("--samples", type=int, default=None, help="samples per scene (headline: 256)")
+    ap.add_argument("--code-length", type=int, default=None,
                     help="CodeLength L (headline: 256).  NOT the headline otherwise: the reference's shipped 8x512 experiments use 2 and 16 "
                          "with --scenes-per-batch 10 --samples 16000 (experiments/double_lattice_3D/specs.json:9-38, simple_geom/specs.json:20)")
     ap.add_argument("--config", choices=["fp32", "bf16", "f32split", "bf16split"], default="fp32",
@@ -186,8 +203,14 @@ def main():
     from deepsdf_amd.net import NetSpec
     from deepsdf_amd.train import FusedTrainStep
 
-    B, S, L = args.scenes_per_batch, args.samples, args.code_length
-    headline = dict(code_length=L, scenes_per_batch=B, samples=S) == HEADLINE
+    nw = NETWORKS[args.network]
+    NET = nw["net"]
+    B = nw["defaults"]["scenes_per_batch"] if args.scenes_per_batch is None else args.scenes_per_batch
+    S = nw["defaults"]["samples"] if args.samples is None else args.samples
+    L = nw["defaults"]["code_length"] if args.code_length is None else args.code_length
+    headline = args.network == "8x512" and dict(code_length=L, scenes_per_batch=B, samples=S) == HEADLINE
+    if args.network != "8x512" and args.config != "fp32":
+        raise SystemExit("--network " + args.network + " runs with --config fp32 only")
     # rehearsal knobs (1-GPU box): DSDF_DIST_BACKEND=gloo + DSDF_SINGLE_DEVICE=1 run several ranks on ONE card to exercise
     # the multi-process logic; the driver's real multi-GPU runs use neither (backend nccl = RCCL, one rank per GPU)
     rank, local, world = dist.init()
@@ -321,7 +344,7 @@ def main():
 
     # ---- headline config only: the same step with NetworkSpecs gemm_split (opt-in), so that the record carries both ----
     split_extra = None
-    if rank == 0 and world == 1 and args.config == "fp32" and not args.no_extras:
+    if rank == 0 and world == 1 and args.config == "fp32" and not args.no_extras and args.network == "8x512":
         n_it = max(10, min(100, (100 * 16384) // n_local))
         seng = Engine(NetSpec(L, gemm_split=True, **NET), dev)
         seng.init_like_reference(torch.Generator().manual_seed(0))
@@ -371,12 +394,12 @@ def main():
 
     # ---- PMC child passes (GPU, child processes), THEN the CPU baseline on an otherwise idle host; both after all GPU timing ----
     if want_pmc:
-        extra = ["--scenes-per-batch", str(B), "--samples", str(S), "--config", args.config, "--code-length", str(L)]
+        extra = ["--scenes-per-batch", str(B), "--samples", str(S), "--config", args.config, "--code-length", str(L), "--network", args.network]
         pmc_children(pmc_res, extra)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not bf16:
         torch.cuda.synchronize()
-        cpu = cpu_baseline(L, B, S, headline)
+        cpu = cpu_baseline(L, B, S, headline, NET)
     if roofline is not None:
         dom = roofline["kernel"]
         if split:      # the profiling class keeps its name; the launched kernel is the split twin
@@ -403,13 +426,27 @@ def main():
         if "error" in pmc_res:
             roofline["pmc_error"] = pmc_res["error"]
 
+    if rank == 0 and roofline is not None and args.network != "8x512":
+        # The shipped small nets are not MFMA bound: algorithmic HBM bytes per point-sample per step in the SURVEY 8(d) convention --
+        # the batch stream (xyz + sdf: 16 B) plus, per hidden layer, the activation and the dP of the layer's output written once and
+        # read once (4 x 4 B x width; the design materialises both for the weight-gradient pass) -- against the 8 TB/s HBM peak.
+        hidden = sum(NET["dims"])
+        alg_bytes = 16 + 16 * hidden
+        gbs = alg_bytes * value / 1e9
+        roofline = dict(bound="hbm", achieved=gbs, peak=8000.0, unit="GB/s", frac=gbs / 8000.0, traffic=None,
+                        algorithmic_bytes_per_point=alg_bytes, mfma_step_tflops=step_tflops, mfma_step_frac=step_tflops / PEAK_TFLOPS,
+                        kernels=roofline["kernels"], flop_per_point=flop_per_pt,
+                        note="WHOLE STEP (all launches), not one kernel: achieved = algorithmic bytes per point x points/s; "
+                             "mfma_* = 6 W_mac x points/s against the fp32 MFMA peak, for scale")
     if rank == 0:
         cfg = {"workload": ((f"configs[4]: configs[1] with the hidden-layer FORWARD GEMMs on bf16 inputs / fp32 accumulate; backward, dW, "
                              f"Adam fp32; {n_local} pts/step ({B} scenes x {S} samples)" if bf16 else
                              f"configs[1] with NetworkSpecs gemm_split (opt-in): the fused forward/backward GEMMs as 6 bf16 MFMAs on 3-way "
                              f"split fp32 operands; {n_local} pts/step ({B} scenes x {S} samples)" if split else
                              f"{'configs[1]' if headline else 'NOT the headline (configs[1] at another batch shape / code length)'}: {B} synthetic sphere-SDF scenes, latent_dim={L}, 8x512 decoder + layer-4 skip, "
-                             f"weight-norm, dropout 0.2, {n_local} pts/step ({B} scenes x {S} samples), fp32") if world == 1 else
+                             f"weight-norm, dropout 0.2, {n_local} pts/step ({B} scenes x {S} samples), fp32" if args.network == "8x512" else
+                             f"NOT the headline: the reference's shipped NetworkSpecs {args.network} ({nw['ref']}: dims {NET['dims']}, latent_in "
+                             f"{NET['latent_in']}, use_tanh {NET['use_tanh']}), CodeLength {L}, {n_local} pts/step ({B} scenes x {S} samples), fp32") if world == 1 else
                             f"configs[2]: {total_scenes} scenes sharded over {world} ranks, {n_local} pts/step/rank, RCCL all-reduce of "
                             "decoder grads (asynchronous, latent Adam under it)"),
                "points_per_step_per_gpu": n_local, "headline_config": headline and args.config == "fp32", "parallelism": f"dp{world}", "final_loss": loss}

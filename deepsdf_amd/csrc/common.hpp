@@ -63,6 +63,27 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Sums of SIXTEEN per-lane values over the 64 lanes of a wave with 17 shuffles instead of 16 x 6: in every step a lane keeps the half
+// of the values its lane-id bit selects and hands the other half to its partner.  Every lane returns the total of value index
+//   wave_sum16_index(lane) = 8 b5 + 4 b4 + 2 b3 + b2          (b_i = bit i of the lane id)
+// -- four lanes per index; lane wave_sum16_lane(q) is one that holds value q's total.  Fixed order (not wave_sum's).
+__device__ __forceinline__ int wave_sum16_index(int lane) { return ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1); }
+__device__ __forceinline__ constexpr int wave_sum16_lane(int q) { return 32 * ((q >> 3) & 1) + 16 * ((q >> 2) & 1) + 8 * ((q >> 1) & 1) + 4 * (q & 1); }
+__device__ __forceinline__ float wave_sum16(const float (&a)[16], int lane) {
+  float b8[8], b4[4], b2[2];
+  const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) b8[j] = (h5 ? a[8 + j] : a[j]) + __shfl_xor(h5 ? a[j] : a[8 + j], 32, 64);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b4[j] = (h4 ? b8[4 + j] : b8[j]) + __shfl_xor(h4 ? b8[j] : b8[4 + j], 16, 64);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) b2[j] = (h3 ? b4[2 + j] : b4[j]) + __shfl_xor(h3 ? b4[j] : b4[2 + j], 8, 64);
+  float r = (h2 ? b2[1] : b2[0]) + __shfl_xor(h2 ? b2[0] : b2[1], 4, 64);
+  r += __shfl_xor(r, 2, 64);
+  r += __shfl_xor(r, 1, 64);
+  return r;
+}
+
 // deterministic block-wide sum for 256-thread blocks; result valid in every thread
 __device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 floats of LDS */) {
   v = wave_sum(v);

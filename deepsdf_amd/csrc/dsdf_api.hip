@@ -10,6 +10,7 @@
 
 #include <stdlib.h>
 
+#include <algorithm>
 #include <atomic>
 
 #include "dwstream.hpp"
@@ -235,7 +236,7 @@ DwSched dw_schedule(const DsdfNet* n, int64_t N, const int* ld_in, bool segmode,
   DwSched S;
   memset(&S, 0, sizeof(S));
   const int nh = n->n_layers - 1;
-  int Tfull = 0;
+  int Tfull = 0, Tnarrow = 0;
   for (int l = 0; l < nh; ++l) {
     const int nc = (l >= l0 && l < l1) ? dw_cols(n, l, segmode) : 0;
     S.slab[l] = rup((int64_t)n->out_dim[l] * ld_in[l], 64);
@@ -245,9 +246,13 @@ DwSched dw_schedule(const DsdfNet* n, int64_t N, const int* ld_in, bool segmode,
     S.last_nj[l] = ((nc - (S.tiles_n[l] - 1) * 128) + 31) / 32;
     S.nfull_n[l] = S.last_nj[l] == 4 ? S.tiles_n[l] : S.tiles_n[l] - 1;
     Tfull += S.tiles_m[l] * S.nfull_n[l];
+    if (S.last_nj[l] != 4) Tnarrow += S.tiles_m[l];
   }
-  // one K-split count for every layer: the largest that still gives every wave of the chip at most one full item
-  int ns = Tfull > 0 && chip_waves() / Tfull > 0 ? chip_waves() / Tfull : 1;
+  // one K-split count for every layer: the largest that still gives every wave of the chip at most one full item.  A net WITHOUT
+  // full-width tiles (every layer narrower than 128: the reference's shipped 4 x 64 / 4 x 32 specs) is split by its narrow items
+  // instead -- round 3 left such nets at ONE split, i.e. one wave contracting all the points of a layer.
+  const int Tsplit = Tfull > 0 ? Tfull : Tnarrow;
+  int ns = Tsplit > 0 && chip_waves() / Tsplit > 0 ? chip_waves() / Tsplit : 1;
   const int maxsplit = N / 64 > 0 ? (int)(N / 64) : 1;
   if (ns > maxsplit) ns = maxsplit;
   int kchunk = (int)rup((N + ns - 1) / ns, 2);
@@ -284,21 +289,22 @@ struct Plan {
   size_t lnx_off[DSDF_MAX_LAYERS], lnr_off[DSDF_MAX_LAYERS];   // LayerNorm: xhat [N][ld_in[l+1]] (the Linear's output in place), rstd [N]
   // fused backward: per hidden layer l a global dP_l buffer, the forward's mask bits and per-workgroup column sums
   size_t dpl_off[DSDF_MAX_LAYERS], mask_off[DSDF_MAX_LAYERS], cs_off[DSDF_MAX_LAYERS], dwslab_off[DSDF_MAX_LAYERS];
-  int nwg;
+  int nwg, frows;    // workgroups of the fused kernels and their rows (64; 32 for batches that would leave CUs idle: pick_frows)
   DwSched dw;
   DwSched dwph[DSDF_MAX_BUCKETS];   // phased backward: the schedule of bucket b's layers [dw_cut[b + 1], dw_cut[b])
   int dw_nb, dw_cut[DSDF_MAX_BUCKETS + 1];   // dw_bucket_cuts
   // segment mode: U[R][2][ldu] of the hoisted layers, per-workgroup xyz sums [nwg][4][ldcs] for each of them
   int segmode, ldu, ldh;
   long long hstride;
-  size_t hoistU_off, xsum_off[2], hs_off;   // hs: [2][maxout][ldh] x0 columns of the hoisted layers' weight gradients
+  size_t hoistU_off, xsum_off[2], hs_off, zr_off;   // hs: [2][maxout][ldh] x0 columns of the hoisted layers' weight gradients
 };
 
 // nb: the bucket count the workspace is laid out for (DsdfLossCfg.dw_buckets; every call of one step passes the same one).
 // 2 also serves the un-phased step, so dsdf_workspace_bytes' answer covers K <= 2.
-Plan make_plan(const DsdfNet* n, int64_t N, int64_t R, bool inference, bool segmode = false, int nb = 2) {
+Plan make_plan(const DsdfNet* n, int64_t N, int64_t R, bool inference, bool segmode = false, int nb = 2, int frows = FROWS) {
   Plan P;
   memset(&P, 0, sizeof(P));
+  P.frows = frows;
   P.nl = n->n_layers; P.W0 = n->latent_size + n->geom_dim; P.N = (int)N; P.R = (int)R;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += (size_t)rup((int64_t)bytes, 256); return r; };
@@ -358,14 +364,18 @@ Plan make_plan(const DsdfNet* n, int64_t N, int64_t R, bool inference, bool segm
   if (P.last_blocks > LAST_BLOCKS_MAX) P.last_blocks = LAST_BLOCKS_MAX;
   if (P.last_blocks < 1) P.last_blocks = 1;
   P.ld_part = 2 * P.ld_in[P.nl - 1];  // [dW_last | colsum_prev]
-  P.part_off = take((size_t)P.last_blocks * P.ld_part * 4);
+  // one row of head partials per block of last_layer_kernel (<= LAST_BLOCKS_MAX) OR per workgroup of the fused backward (N / 64,
+  // unbounded): sized for the larger.  (Rounds 1-3 sized them by last_blocks alone: batches of more than 65536 points -- the shipped
+  // 10 x 16000 -- let the fused head write its partials past these buffers, into part2 / partdb / partloss and the dP_0 buffer.)
+  const size_t part_rows = (size_t)std::max<int64_t>(P.last_blocks, (N + frows - 1) / frows);
+  P.part_off = take(part_rows * P.ld_part * 4);
   P.part2_off = take((size_t)LAST_GROUPS * P.ld_part * 4);
-  P.partdb_off = take((size_t)P.last_blocks * 4);
-  P.partloss_off = take((size_t)P.last_blocks * 4);
+  P.partdb_off = take(part_rows * 4);
+  P.partloss_off = take(part_rows * 4);
   P.segpart_off = take((size_t)(R > 0 ? R : 1) * (n->latent_size > 0 ? n->latent_size : 1) * 4);
   P.segnorm_off = take((size_t)(R > 0 ? R : 1) * 4);
   P.gnorm_off = take(1024 * 4);
-  P.nwg = (int)((N + FROWS - 1) / FROWS);
+  P.nwg = (int)((N + frows - 1) / frows);
   for (int l = 0; l < P.nl - 1; ++l) {
     P.dpl_off[l] = take((size_t)N * maxw * 4 + 4096);
     P.mask_off[l] = take((size_t)P.nwg * 256 * 16);
@@ -389,6 +399,7 @@ Plan make_plan(const DsdfNet* n, int64_t N, int64_t R, bool inference, bool segm
     P.ldh = (int)rup(n->latent_size + n->geom_dim, 4);
     P.hstride = (long long)P.ldcs * P.ldh;
     P.hs_off = take((size_t)2 * P.hstride * 4);
+    P.zr_off = take((size_t)(R > 0 ? R : 1) * (n->latent_size > 0 ? n->latent_size : 1) * 4);   // renormed latent row of every segment
   }
   P.total = o;
   return P;
@@ -535,12 +546,25 @@ bool fused_eligible(const DsdfNet* net) {
   return net->in_dim[net->n_layers - 1] <= FMAXW;
 }
 
+// Rows per workgroup of the fused kernels: 64, or 32 (fused_*_h32_kernel: fp32 MFMA, merged forward + backward or forward alone) when
+// 32-row workgroups still fit one per CU -- i.e. when 64-row workgroups would leave at least half of the chip idle (BASELINE config 4:
+// one shape x 8000 points).  DSDF_FROWS=64 switches it off (A/B).
+int pick_frows(const DsdfNet* net, int64_t n) {
+  const char* e = getenv("DSDF_FROWS");      // read per call: the tests switch it inside one process
+  const bool off = e && !strcmp(e, "64");
+  if (off || !fused_enabled() || !fused_eligible(net) || net->gemm_split || net->fwd_bf16) return FROWS;
+  return n > 0 && n <= 32ll * (chip_waves() / 4) ? 32 : FROWS;
+}
+
 // all hidden layers + the last layer's forward in ONE launch (fused.hpp).  store_act: keep global copies of the
 // activations (training / module path) or not (inference).
 // Segment mode: U[s][t][:] = W_t[:, latent columns] latent_s for layer 0 (t = 0) and the skip layer (t = 1), and the
 // descriptor the fused forward needs to start its accumulators from them.
+// renorm != nullptr (training steps): the launch also does the max-norm renorm of the looked-up rows into zr (max_norm <= 0: a plain
+// copy) and zeroes the dense latent gradient (nzero floats of dlat; 0: leaves it) -- no latent_renorm_kernel launch in segment mode
+struct HoistRenorm { float max_norm; float* dlat; long long nzero; };
 int run_hoist(const DsdfNet* net, const Plan& P, void* ws, const float* packed, const float* table, const DsdfBatch* b,
-              FusedSeg* seg, hipStream_t st) {
+              FusedSeg* seg, hipStream_t st, const HoistRenorm* renorm = nullptr) {
   const Packed pk = packed_layout(net);
   const int ks = skip_layer(net);
   HoistArgs h;
@@ -557,10 +581,20 @@ int run_hoist(const DsdfNet* net, const Plan& P, void* ws, const float* packed, 
   h.L = net->latent_size; h.seg_scene = b->seg_scene; h.table = table; h.R = (int)b->n_segments;
   h.U = at<float>(ws, P.hoistU_off); h.ldu = P.ldu;
   h.bf16 = net->fwd_bf16 ? 1 : 0;
+  if (renorm != nullptr) {
+    h.max_norm = renorm->max_norm; h.zr = at<float>(ws, P.zr_off);
+    h.dlat = renorm->nzero > 0 ? renorm->dlat : nullptr; h.nzero = renorm->nzero;
+  }
   const int rows = h.out[0] + (ks > 0 ? h.out[1] : 0);
-  hipLaunchKernelGGL(seg_hoist_kernel, dim3((unsigned)((rows + 3) / 4), (unsigned)((h.R + HOIST_SC - 1) / HOIST_SC)), dim3(256), 0, st, h);
+  const dim3 hgrid((unsigned)((rows + 3) / 4), (unsigned)((h.R + HOIST_SC - 1) / HOIST_SC));
+  switch ((h.L + 63) >> 6) {               // k-units of 64 latent columns per lane (HOIST_MAXL = 512)
+    case 1: hipLaunchKernelGGL(seg_hoist_kernel<1>, hgrid, dim3(256), 0, st, h); break;
+    case 2: hipLaunchKernelGGL(seg_hoist_kernel<2>, hgrid, dim3(256), 0, st, h); break;
+    case 3: case 4: hipLaunchKernelGGL(seg_hoist_kernel<4>, hgrid, dim3(256), 0, st, h); break;
+    default: hipLaunchKernelGGL(seg_hoist_kernel<8>, hgrid, dim3(256), 0, st, h); break;
+  }
   LAUNCH_OK("seg_hoist_kernel");
-  seg->wg_per_seg = (int)(b->seg_len / FROWS);
+  seg->wg_per_seg = (int)(b->seg_len / P.frows);
   seg->xyz = b->xyz; seg->G = net->geom_dim; seg->U = h.U; seg->ldu = h.ldu;
   return 0;
 }
@@ -619,8 +653,10 @@ int run_fused_forward(const DsdfNet* net, const Plan& P, void* ws, const float* 
   if (!dbg && getenv("DSDF_LAB_DBG")) { (void)hipMalloc(&dbg, 8192 * 64 * 8); }
   a.dbg = dbg;
 #endif
-  const dim3 grid((unsigned)((n + FROWS - 1) / FROWS));
-  if (net->fwd_bf16 && !store_act)   // config 5, inference form: 8 staggered waves, transposed accumulators (fused_bf16x8.hpp)
+  const dim3 grid((unsigned)((n + P.frows - 1) / P.frows));
+  if (P.frows == 32)                 // small batch: 32 points per workgroup (pick_frows: fp32 MFMA only)
+    hipLaunchKernelGGL(fused_forward_h32_kernel, grid, dim3(256), 0, st, a);
+  else if (net->fwd_bf16 && !store_act)   // config 5, inference form: 8 staggered waves, transposed accumulators (fused_bf16x8.hpp)
     hipLaunchKernelGGL(fused_forward_bf16x8_kernel, grid, dim3(F8_THREADS), 0, st, a);
   else if (net->fwd_bf16)            // with activation copies (module path; training goes out merged with the backward)
     hipLaunchKernelGGL(fused_forward_bf16_kernel, grid, dim3(256), 0, st, a);
@@ -826,7 +862,8 @@ struct FuseAdam { const DsdfAdamCfg* cfg; float* params; float* exp_avg; float* 
 // dX chain (writes every dP_l, column sums, latent-gradient inputs), then dW (split-K) + finalize per layer.
 // Segment mode (sb != nullptr): what the weight gradients of the hoisted layers need from the batch
 struct SegBwd { const FusedSeg* seg; const int64_t* seg_scene; const float* table; int R;
-                const ScatterArgs* scatter; bool* scatter_done; };   // the dense latent-gradient scatter may ride on the finalize launch
+                const ScatterArgs* scatter; bool* scatter_done;
+                const float* zr; };   // the segments' renormed latent rows (run_hoist), or nullptr: read table[seg_scene[r]]   // the dense latent-gradient scatter may ride on the finalize launch
 
 int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float* packed, const float* params, int64_t n,
                        int training, float* grads, int accumulate, int ncols_dz, bool* used_dzB, hipStream_t st,
@@ -885,10 +922,12 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
       if (net->fwd_bf16 && net->gemm_split) hipLaunchKernelGGL(fused_fwd_bf16_bwd_split_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
       else if (net->fwd_bf16) hipLaunchKernelGGL(fused_fwd_bf16_bwd_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
       else if (net->gemm_split) hipLaunchKernelGGL(fused_fwd_bwd_split_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
+      else if (P.frows == 32) hipLaunchKernelGGL(fused_fwd_bwd_h32_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
       else hipLaunchKernelGGL(fused_fwd_bwd_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
       LAUNCH_OK("fused_fwd_bwd_kernel");
     } else {
       ProfScope ps(DSDF_PROF_FUSED_BWD, 2.0 * (double)n * amac, st);
+      if (P.frows != FROWS) return fail(DSDF_E_LAUNCH, "internal: the separate backward kernel has 64-row workgroups only");
       if (net->gemm_split) hipLaunchKernelGGL(fused_backward_split_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, a);
       else hipLaunchKernelGGL(fused_backward_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, a);
       LAUNCH_OK("fused_backward_kernel");
@@ -915,7 +954,7 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
       d.cs[0] = at<float>(ws, P.cs_off[0]); d.xsum[0] = at<float>(ws, P.xsum_off[0]); d.out[0] = net->out_dim[0];
       if (ks > 0) { d.cs[1] = at<float>(ws, P.cs_off[ks]); d.xsum[1] = at<float>(ws, P.xsum_off[1]); d.out[1] = net->out_dim[ks]; }
       d.ldcs = P.ldcs; d.nwg = P.nwg; d.wg_per_seg = sb->seg->wg_per_seg; d.R = sb->R; d.L = net->latent_size; d.G = net->geom_dim;
-      d.seg_scene = sb->seg_scene; d.table = sb->table;
+      d.seg_scene = sb->seg_scene; d.table = sb->table; d.zr = sb->zr;
       d.HS = at<float>(ws, P.hs_off); d.ldh = P.ldh; d.hstride = P.hstride;
       q.dw_n = (d.out[0] + SDW_ROWS - 1) / SDW_ROWS + (ks > 0 ? (d.out[1] + SDW_ROWS - 1) / SDW_ROWS : 0);
     }
@@ -927,7 +966,7 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
       g.Wk = packed + pk.w_off[ks]; g.ldwk = pk.ldw[ks]; g.koff = net->out_dim[ks - 1];
     }
     g.wg_per_seg = sb->seg->wg_per_seg; g.R = sb->R; g.L = net->latent_size;
-    g.seg_scene = sb->seg_scene; g.table = sb->table;
+    g.seg_scene = sb->seg_scene; g.table = sb->table; g.zr = sb->zr;
     g.segpart = at<float>(ws, P.segpart_off); g.segnorm = at<float>(ws, P.segnorm_off);
     q.lat_bx = sb->R;
     lat_n = sb->R * ((net->latent_size + 15) / 16);
@@ -939,12 +978,20 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
   // workgroup per CU (measured: 16384 points, 1168 role blocks on 16 workgroups, dW time unchanged); larger batches put
   // the roles on the critical path (65536 points: -5 %), so they get their own (wide) launch there
   static const bool no_ride = [] { const char* e = getenv("DSDF_NO_RIDE"); return e && e[0] == '1'; }();   // A/B switch
-  // (gemm_split: the dW items finish in ~60 % of the time the riding roles need on the 16 spare workgroups -- they would be the
-  // launch's tail, 462 us against 227; there the roles go out as a launch of their own, 18 us)
+  // Round 4: stamps inside the launch (profiles/r04_dw_stamps_before.log) showed the riding roles to be its TAIL -- 391 us of role
+  // blocks on the 16 spare workgroups against 377 us of MFMA items -- and their latency-bound chains to be what made the launch
+  // 388 us on one box and 403 us on the next.  The roles were rebuilt for few workgroups (seg_dw_body: 32 rows per block;
+  // seg_latgrad_all_body: one block per 16 latent columns takes all segments): they now end 242 us into the launch.
+  // (gemm_split: measured again with the rebuilt roles -- they end 242 us into the launch, the split items 174 us: riding there made
+  // the launch 253 us instead of 174 + 18 for a launch of their own, so they still do not ride in split mode)
   const bool post_rides = segmode && want_dw && cus - dw_busy >= 8 && P.nwg <= cus && !no_ride && !net->gemm_split && phase <= 1 &&
                           dw_items > 0;
+  if (post_rides) {   // the per-segment latent gradient in its few-workgroups form
+    q.lat_bx = 0;
+    lat_n = (net->latent_size + 15) / 16;
+  }
   if (segmode && !post_rides && phase <= 1) {
-    hipLaunchKernelGGL(post_bwd_kernel, dim3((unsigned)(q.rr_n + q.dw_n + lat_n)), dim3(256), 0, st, q);
+    hipLaunchKernelGGL(post_bwd_kernel, dim3((unsigned)(q.rr_n + q.dw_n + lat_n)), dim3(256), 0, st, q, lat_n);
     LAUNCH_OK("post_bwd_kernel");
   }
   if (want_dw && dw_items > 0) {   // all dW_l = dP_l^T a_l (of this phase's layers) in one launch
@@ -1027,7 +1074,7 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
         f.step_size = (float)((double)c->lr_decoder / bc1); f.bc2_sqrt = (float)sqrt(bc2); f.eps = c->eps;
       }
       fa.row0[fa.n] = rows;
-      rows += f.out;
+      rows += fin_blocks(f.out, f.in);     // (`rows` counts BLOCKS of the finalize launch)
       ++fa.n;
     }
     fa.row0[fa.n] = rows;
@@ -1098,9 +1145,11 @@ int dsdf_workspace_bytes(const DsdfNet* net, int64_t n_points, int64_t n_segment
   TRY(validate(net));
   if (!bytes || n_points < 0 || n_segments < 0) return fail(DSDF_E_INVALID, "bad arguments");
   if (n_points > (1ll << 30)) return fail(DSDF_E_INVALID, "n_points too large");
-  const size_t a = make_plan(net, n_points, n_segments, false, false).total;
-  const size_t b = make_plan(net, n_points, n_segments, false, true).total;   // segment mode lays the workspace out differently
-  *bytes = a > b ? a : b;
+  size_t best = 0;
+  for (int fr = 32; fr <= FROWS; fr += 32)      // (32-row workgroups double the per-workgroup partials: pick_frows decides per call)
+    for (int seg = 0; seg < 2; ++seg)           // segment mode lays the workspace out differently
+      best = std::max(best, make_plan(net, n_points, n_segments, false, seg != 0, 2, fr).total);
+  *bytes = best;
   return 0;
 }
 
@@ -1109,9 +1158,10 @@ int dsdf_workspace_bytes_buckets(const DsdfNet* net, int64_t n_points, int64_t n
   if (!bytes || n_points < 0 || n_segments < 0) return fail(DSDF_E_INVALID, "bad arguments");
   if (n_points > (1ll << 30)) return fail(DSDF_E_INVALID, "n_points too large");
   if (n_buckets < 0 || n_buckets > DSDF_MAX_BUCKETS) return fail(DSDF_E_INVALID, "n_buckets %d out of range [0, %d]", n_buckets, DSDF_MAX_BUCKETS);
-  const size_t a = make_plan(net, n_points, n_segments, false, false, n_buckets).total;
-  const size_t b = make_plan(net, n_points, n_segments, false, true, n_buckets).total;
-  *bytes = a > b ? a : b;
+  size_t best = 0;
+  for (int fr = 32; fr <= FROWS; fr += 32)
+    for (int seg = 0; seg < 2; ++seg) best = std::max(best, make_plan(net, n_points, n_segments, false, seg != 0, n_buckets, fr).total);
+  *bytes = best;
   return 0;
 }
 
@@ -1159,7 +1209,7 @@ int dsdf_decode(const DsdfNet* net, const float* packed, const float* params, co
   TRY(check_common(net, packed, params, ws));
   if (n == 0) return 0;
   if (!input || !sdf_out || n < 0 || ld_in < net->in_dim[0]) return fail(DSDF_E_INVALID, "bad input/sdf_out/ld_in");
-  const Plan P = make_plan(net, n, 0, true);
+  const Plan P = make_plan(net, n, 0, true, false, 2, pick_frows(net, n));
   if (ws_bytes < P.total) return fail(DSDF_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, P.total);
   hipStream_t st = (hipStream_t)stream;
   TRY(run_gather(net, P, ws, nullptr, nullptr, input, ld_in, n, st));
@@ -1197,7 +1247,7 @@ int dsdf_decode_latent(const DsdfNet* net, const float* packed, const float* par
   if (!latent || !xyz || !sdf_out || n < 0) return fail(DSDF_E_INVALID, "bad latent/xyz/sdf_out");
   if (!decode_latent_ok(net))
     return fail(DSDF_E_INVALID, "dsdf_decode_latent needs the fused forward (widths <= 512, geom_dim <= 4): use dsdf_decode");
-  Plan P = make_plan(net, n, 0, true);
+  Plan P = make_plan(net, n, 0, true, false, 2, pick_frows(net, n));
   const size_t need = P.total > 16384 ? P.total : 16384;
   if (ws_bytes < need) return fail(DSDF_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, need);
   hipStream_t st = (hipStream_t)stream;
@@ -1209,7 +1259,7 @@ int dsdf_decode_latent(const DsdfNet* net, const float* packed, const float* par
   b.seg_scene = at<int64_t>(ws, 0); b.n_segments = 1; b.xyz = xyz; b.n_points = n; b.seg_len = n;
   FusedSeg seg;
   TRY(run_hoist(net, P, ws, packed, latent, &b, &seg, st));
-  seg.wg_per_seg = (int)((n + FROWS - 1) / FROWS);      // every workgroup belongs to segment 0
+  seg.wg_per_seg = (int)((n + P.frows - 1) / P.frows);  // every workgroup belongs to segment 0
   return run_fused_forward(net, P, ws, packed, params, n, 0, nullptr, 0, false, sdf_out, nullptr, st, &seg);
 }
 
@@ -1414,7 +1464,14 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
   // and the latent gradient / the x0 columns of the weight gradients come from per-workgroup column sums.
   const bool fusedb = fused_enabled() && fused_eligible(net);
   const int skip_l = skip_layer(net);
-  const bool segsum = fusedb && b->seg_len > 0 && b->seg_len % FROWS == 0 && b->seg_len * R == n && net->n_layers > 2 &&
+  // (32-row workgroups exist for the merged forward + backward launch only)
+  const bool can_merge = fusedb && !getenv("DSDF_NO_MERGE")
+#ifdef DSDF_LAB
+                         && !getenv("DSDF_LAB_DBG")
+#endif
+      ;
+  const int frows = can_merge ? pick_frows(net, n) : FROWS;
+  const bool segsum = fusedb && b->seg_len > 0 && b->seg_len % frows == 0 && b->seg_len * R == n && net->n_layers > 2 &&
                       skip_l != net->n_layers - 2 &&   // the deepest hidden layer's dP column sums live in the head's partials
                       net->geom_dim <= FGEO && net->latent_size <= HOIST_MAXL;   // (config 5 too: bf16 rounding is element-wise
                                                                                   // on the operands, so the latent products still hoist)
@@ -1422,7 +1479,7 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
   if (nbk < 0 || nbk > DSDF_MAX_BUCKETS) return fail(DSDF_E_INVALID, "dw_buckets %d out of range [0, %d]", nbk, DSDF_MAX_BUCKETS);
   if (phase < 0 || (nbk <= 1 ? phase != 0 : phase < 1 || phase > nbk))
     return fail(DSDF_E_INVALID, "dw_phase %d out of range for dw_buckets %d (0 without buckets, 1..K with K >= 2)", phase, nbk);
-  const Plan P = make_plan(net, n, R, false, segsum, nbk);
+  const Plan P = make_plan(net, n, R, false, segsum, nbk, frows);
   if (ws_bytes < P.total) return fail(DSDF_E_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, P.total);
   hipStream_t st = (hipStream_t)stream;
   const int Lc = net->latent_size;
@@ -1432,13 +1489,14 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
     FusedSeg seg0;
     memset(&seg0, 0, sizeof(seg0));
     const FusedBwdHead h0 = make_head(net, P, ws, packed, params, HEAD_TRAIN, cfg->training);
-    const SegBwd sb0{&seg0, b->seg_scene, latent_table, (int)R, nullptr, nullptr};
+    const SegBwd sb0{&seg0, b->seg_scene, latent_table, (int)R, nullptr, nullptr, nullptr};
     bool used = false;
     return run_backward_fused(net, P, ws, packed, params, n, cfg->training, grads, 0, segsum ? 0 : Lc, &used, st, true, h0, nullptr,
                               segsum ? &sb0 : nullptr, nullptr, phase);
   }
 
-  if (cfg->code_bound > 0.f || !accumulate) {   // max-norm renorm of the looked-up rows + zero of the dense latent gradient
+  if (!segsum && (cfg->code_bound > 0.f || !accumulate)) {   // max-norm renorm of the looked-up rows + zero of the dense latent gradient
+    // (segment mode: both are part of the hoist launch -- seg_hoist_kernel)
     const long long nzero = accumulate ? 0 : (long long)n_scenes * Lc;
     long long blocks = (R + 3) / 4, zb = (nzero + 4095) / 4096;
     if (zb > 2048) zb = 2048;
@@ -1450,13 +1508,11 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
   FusedSeg seg;
   memset(&seg, 0, sizeof(seg));
   FusedFwdArgs fwd_args;                                   // fp32 fused path: forward + backward go out as ONE launch below
-  bool merged = fusedb;
-  if (getenv("DSDF_NO_MERGE")) merged = false;   // lab / tests: forward and backward as two launches in fp32 too
-#ifdef DSDF_LAB
-  if (getenv("DSDF_LAB_DBG")) merged = false;   // lab builds: per-layer stamps are dumped after a forward launch of its own
-#endif
+  const bool merged = can_merge;   // (DSDF_NO_MERGE -- lab / tests: forward and backward as two launches in fp32 too; lab builds with
+                                   // DSDF_LAB_DBG: per-layer stamps are dumped after a forward launch of its own)
   if (segsum) {
-    TRY(run_hoist(net, P, ws, packed, latent_table, b, &seg, st));
+    const HoistRenorm hr{cfg->code_bound > 0.f ? cfg->code_bound : 0.f, dlat, accumulate ? 0 : (long long)n_scenes * Lc};
+    TRY(run_hoist(net, P, ws, packed, latent_table, b, &seg, st, &hr));
     TRY(run_fused_forward(net, P, ws, packed, params, n, cfg->training, cfg->dropout_key, (uint32_t)b->row_offset, true,
                           nullptr, nullptr, st, &seg, merged ? &fwd_args : nullptr));
   } else {
@@ -1491,6 +1547,7 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
   sc.segpart = at<float>(ws, P.segpart_off); sc.segnorm = at<float>(ws, P.segnorm_off);
   sc.seg_scene = b->seg_scene; sc.seg_offset = b->seg_offset;
   sc.R = (int)R; sc.L = Lc; sc.table = latent_table; sc.dlat = dlat;
+  sc.zr = segsum ? at<float>(ws, P.zr_off) : nullptr;
   sc.creg = cfg->reg_coef / (float)b->n_norm;
   sc.part_loss = at<float>(ws, P.partloss_off); sc.n_part = fusedb ? P.nwg : P.last_blocks;
   sc.loss_scale = 1.0f / (float)b->n_norm; sc.loss_out = loss_out; sc.accumulate = accumulate;
@@ -1499,7 +1556,7 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
     FusedBwdHead h = make_head(net, P, ws, packed, params, HEAD_TRAIN, cfg->training);
     h.gt = b->sdf_gt; h.delta = cfg->clamp_dist; h.inv_n = 1.0f / (float)b->n_norm; h.y_out = sdf_out;
     const FuseAdam* use = (fz != nullptr && want_dw && !accumulate) ? fz : nullptr;
-    const SegBwd sb{&seg, b->seg_scene, latent_table, (int)R, &sc, &scatter_done};
+    const SegBwd sb{&seg, b->seg_scene, latent_table, (int)R, &sc, &scatter_done, sc.zr};
     TRY(run_backward_fused(net, P, ws, packed, params, n, cfg->training, grads, accumulate, segsum ? 0 : Lc, &used_dzB, st, want_dw, h,
                            use, segsum ? &sb : nullptr, merged ? &fwd_args : nullptr, phase));
     if (use != nullptr && adam_fused) *adam_fused = 1;

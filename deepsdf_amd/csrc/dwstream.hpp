@@ -519,7 +519,8 @@ __device__ __forceinline__ void dw_block_split(const DwLayer& L, int split, int 
 // the post-backward roles of kernels.hpp (head partials, x0 columns of dW, per-segment latent gradient) meanwhile, so
 // those cost no launch of their own on the critical path.  post.rr_n + post.dw_n + post_lat_n == 0: nothing to do.
 template <bool SPLIT>
-__device__ __forceinline__ void dw_stream_body(const DwArgs& p, const PostBwdArgs& post, const int post_lat_n, const int busy_wg, float* ring) {
+__device__ __forceinline__ void dw_stream_body(const DwArgs& p, const PostBwdArgs& post, const int post_lat_n, const int busy_wg,
+                                               float* ring) {   // ring: the split kernel's LDS ring; both kernels: the roles' scratch
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: item, K range and the
   const int fr = lane & 31, fh = lane >> 5;                                                  // ring's bounds checks stay scalar
   const int lwg = xcd_remap(blockIdx.x, gridDim.x);
@@ -538,7 +539,7 @@ __device__ __forceinline__ void dw_stream_body(const DwArgs& p, const PostBwdArg
 #ifdef DSDF_LAB
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
 #endif
-      post_bwd_role(post, i);
+      post_bwd_role(post, i, post_lat_n, ring);
 #ifdef DSDF_LAB
       tk[i < post.rr_n ? 0 : (i < post.rr_n + post.dw_n ? 1 : 2)] += __builtin_amdgcn_s_memrealtime() - t0;
 #endif
@@ -617,13 +618,15 @@ __device__ __forceinline__ void dw_stream_body(const DwArgs& p, const PostBwdArg
 
 __global__ __launch_bounds__(256, 1) void dw_stream_kernel(const DwArgs p, const PostBwdArgs post, const int post_lat_n,
                                                            const int busy_wg) {
-  dw_stream_body<false>(p, post, post_lat_n, busy_wg, nullptr);
+  __shared__ __attribute__((aligned(16))) float role_lds[ROLE_LDS_FLOATS];     // only the riding roles use LDS here (37 KB)
+  dw_stream_body<false>(p, post, post_lat_n, busy_wg, role_lds);
 }
 // DsdfNet.gemm_split: blocks of full-width items on the bf16 pipe (dw_block_split); everything else (items that do not form a 2 x 2
 // block, narrow edge items, the riding roles) as above.  A kernel of its own so that the fp32 kernel keeps its register allocation.
 __global__ __launch_bounds__(256, 1) void dw_stream_split_kernel(const DwArgs p, const PostBwdArgs post, const int post_lat_n,
                                                                  const int busy_wg) {
-  __shared__ __attribute__((aligned(16))) float ring[DWS_RING * DWS_SLOT];     // 128 KB
+  __shared__ __attribute__((aligned(16))) float ring[DWS_RING * DWS_SLOT];     // 128 KB (role workgroups use it as their scratch)
+  static_assert(DWS_RING * DWS_SLOT >= ROLE_LDS_FLOATS, "the roles' scratch must fit the ring");
   dw_stream_body<true>(p, post, post_lat_n, busy_wg, ring);
 }
 

@@ -87,10 +87,11 @@ struct FusedFwdArgs {
 
 // rows of x0 into slab columns [col0, col0 + W0).  All 16-byte loads of a pass are issued back-to-back BEFORE the
 // first LDS write: a load-use-load-use loop would pay the HBM latency dozens of times in a row.
+template <int ROWS = FROWS>
 __device__ __forceinline__ void fused_load_x0(float* S, const float* x0, int ldx0, int W0, int row0, int N, int col0) {
   constexpr int XCH = 20;                   // float4 chunks per thread per pass
   const int cpr = (W0 + 3) >> 2;            // chunks per row (ldx0 is a multiple of 4: the tail chunk is in bounds)
-  const int total = FROWS * cpr;
+  const int total = ROWS * cpr;
   for (int base = 0; base < total; base += 256 * XCH) {
     float4 v[XCH];
 #pragma unroll
@@ -128,11 +129,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int FLDH = 520;        // slab row stride in bf16 elements (bf16 forward, fused_bf16x8.hpp)
 
 // HS: the slab holds bf16 (row stride FLDH) instead of fp32 (row stride FLD); the global activation copy stays fp32.
-template <bool DROP, bool EVEN, bool HS = false>
-__device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[2][4], const float (&biasv)[4], float* S,
+// MT: m-tiles of 32 rows per workgroup (2 = the 64-row workgroup; 1 = the 32-row one of small batches, fused_*_h32_kernel).
+template <bool DROP, bool EVEN, bool HS = false, int MT = 2>
+__device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[MT][4], const float (&biasv)[4], float* S,
                                                    const FusedLayer& L, int w, int fr, int fh, int row0, int N,
                                                    uint32_t row_offset) {
-  const int rows_here = min(FROWS, N - row0);
+  const int rows_here = min(32 * MT, N - row0);
   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       L.out != nullptr ? (void*)(L.out + (size_t)row0 * L.ld_out) : (void*)S, 0,
       L.out != nullptr ? rows_here * L.ld_out * 4 : 0, 0x00020000);
@@ -154,7 +156,7 @@ __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[2][4], co
     }
     if (cok) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
+      for (int m = 0; m < MT; ++m) {
 #pragma unroll
         for (int rp = 0; rp < 8; ++rp) {
           const int rc = 32 * m + crow(2 * rp);    // compile-time local row (without the 4*fh lane term); even
@@ -275,8 +277,8 @@ __device__ __forceinline__ float4 fused_bload(const FusedBView& B, int ni, int u
 }
 #endif
 
-template <int NACT>
-__device__ __forceinline__ void fused_kloop(f32x16 (&acc)[2][4], const float* ap, const FusedBView& bv, int nu,
+template <int NACT, int MT = 2>
+__device__ __forceinline__ void fused_kloop(f32x16 (&acc)[MT][4], const float* ap, const FusedBView& bv, int nu,
                                             FusedBSets& PB) {
   // Three named register sets rotate over the k-units: the WEIGHTS of unit u+2 (global, fragment order) and the
   // ACTIVATIONS of unit u+1 (LDS slab) are requested before the 16 NACT MFMAs of unit u issue, so neither the L2
@@ -287,7 +289,7 @@ __device__ __forceinline__ void fused_kloop(f32x16 (&acc)[2][4], const float* ap
     b0[ni][0] = PB.b0[ni][0]; b0[ni][1] = PB.b0[ni][1];
     b1[ni][0] = PB.b1[ni][0]; b1[ni][1] = PB.b1[ni][1];
   }
-  float4 a0[4], a1[4], a2[4];   // [m-tile + 2 * half]: 4 consecutive k of rows fr and 32 + fr
+  float4 a0[2 * MT], a1[2 * MT], a2[2 * MT];   // [m-tile + MT * half]: 4 consecutive k of rows fr (and 32 + fr)
   const int rot = fused_rot(nu);
   auto loadB = [&](float4 (&b)[NACT][2], int q) {
     const int u = fused_unit(q, rot, nu);
@@ -297,26 +299,27 @@ __device__ __forceinline__ void fused_kloop(f32x16 (&acc)[2][4], const float* ap
       b[ni][1] = fused_bload(bv, ni, u, 1);
     }
   };
-  auto readA = [&](float4 (&a)[4], int q) {
+  auto readA = [&](float4 (&a)[2 * MT], int q) {
     const int u = fused_unit(q, rot, nu);
-    a[0] = *reinterpret_cast<const float4*>(ap + 16 * u);
-    a[1] = *reinterpret_cast<const float4*>(ap + 32 * FLD + 16 * u);
-    a[2] = *reinterpret_cast<const float4*>(ap + 16 * u + 4);
-    a[3] = *reinterpret_cast<const float4*>(ap + 32 * FLD + 16 * u + 4);
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[m + MT * hf] = *reinterpret_cast<const float4*>(ap + 32 * m * FLD + 16 * u + 4 * hf);
   };
-  auto mma = [&](const float4 (&a)[4], const float4 (&b)[NACT][2]) {
+  auto mma = [&](const float4 (&a)[2 * MT], const float4 (&b)[NACT][2]) {
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
-      const float av0[4] = {a[2 * hf].x, a[2 * hf].y, a[2 * hf].z, a[2 * hf].w};
-      const float av1[4] = {a[2 * hf + 1].x, a[2 * hf + 1].y, a[2 * hf + 1].z, a[2 * hf + 1].w};
+      float av[MT][4];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) { av[m][0] = a[m + MT * hf].x; av[m][1] = a[m + MT * hf].y; av[m][2] = a[m + MT * hf].z; av[m][3] = a[m + MT * hf].w; }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
 #pragma unroll
         for (int ni = 0; ni < NACT; ++ni) {
           const float4 bq = b[ni][hf];
           const float bv = e == 0 ? bq.x : (e == 1 ? bq.y : (e == 2 ? bq.z : bq.w));
-          acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv, acc[0][ni], 0, 0, 0);
-          acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv, acc[1][ni], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][e], bv, acc[m][ni], 0, 0, 0);
         }
       }
     }
@@ -325,7 +328,7 @@ __device__ __forceinline__ void fused_kloop(f32x16 (&acc)[2][4], const float* ap
   // must be SPREAD over the MFMA stream: the wave is alone on its SIMD, and a cluster of 12 loads at the top of a step
   // keeps the (in-order) wave from issuing the next MFMA for ~400 cycles.  sched_group_barrier pins the interleave:
   // one memory op, then MPG MFMAs, ... (prefetch indices are clamped instead of branched so a step is one region).
-  constexpr int NMEM = 2 * NACT + 4, MPG = (16 * NACT) / NMEM, MREST = 16 * NACT - NMEM * MPG;
+  constexpr int NMEM = 2 * NACT + 2 * MT, MPG = (8 * MT * NACT) / NMEM, MREST = 8 * MT * NACT - NMEM * MPG;
   auto interleave = [&]() {
 #pragma unroll
     for (int q = 0; q < 2 * NACT; ++q) {
@@ -333,7 +336,7 @@ __device__ __forceinline__ void fused_kloop(f32x16 (&acc)[2][4], const float* ap
       __builtin_amdgcn_sched_group_barrier(0x008, MPG, 0); // MFMA
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 2 * MT; ++q) {
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
       __builtin_amdgcn_sched_group_barrier(0x008, MPG, 0);
     }
@@ -782,9 +785,10 @@ __device__ __forceinline__ void kl_prefetch(typename KlSets<SPLIT>::type& PB, co
   if constexpr (SPLIT) split_prefetch_b(PB, wf, wplane, wf32, U, w, lane, nact, nu);
   else fused_prefetch_b(PB, wf, U, w, lane, nact, nu);
 }
-template <bool SPLIT>
-__device__ __forceinline__ void fused_kloop_dispatch(f32x16 (&acc)[2][4], const float* ap, const float* wf, int wplane, const float* wf32, int U,
+template <bool SPLIT, int MT = 2>
+__device__ __forceinline__ void fused_kloop_dispatch(f32x16 (&acc)[MT][4], const float* ap, const float* wf, int wplane, const float* wf32, int U,
                                                      int w, int lane, int nu, int nact, typename KlSets<SPLIT>::type& PB) {
+  static_assert(!SPLIT || MT == 2, "the split k-loops exist for 64-row workgroups only");
   if constexpr (SPLIT) {
     const SplitBView bv = split_bview(wf, wplane, wf32, U, w, lane);
     switch (nact) {
@@ -801,10 +805,10 @@ __device__ __forceinline__ void fused_kloop_dispatch(f32x16 (&acc)[2][4], const 
   } else {
     const FusedBView bv = fused_bview(wf, U, w, lane);
     switch (nact) {
-      case 4: fused_kloop<4>(acc, ap, bv, nu, PB); break;
-      case 3: fused_kloop<3>(acc, ap, bv, nu, PB); break;
-      case 2: fused_kloop<2>(acc, ap, bv, nu, PB); break;
-      case 1: fused_kloop<1>(acc, ap, bv, nu, PB); break;
+      case 4: fused_kloop<4, MT>(acc, ap, bv, nu, PB); break;
+      case 3: fused_kloop<3, MT>(acc, ap, bv, nu, PB); break;
+      case 2: fused_kloop<2, MT>(acc, ap, bv, nu, PB); break;
+      case 1: fused_kloop<1, MT>(acc, ap, bv, nu, PB); break;
       default: break;
     }
   }
@@ -815,13 +819,15 @@ __device__ __forceinline__ int fused_nact(int ncols, int w) {   // how many of t
   return ntl > w ? min(4, (ntl - w + 3) >> 2) : 0;
 }
 
+template <int ROWS = FROWS>
 __device__ __forceinline__ void fused_zero_pad(float* S, int nin) {   // columns [nin, roundup16(nin)) of every slab row
   const int zc = ((nin + 15) & ~15) - nin;
-  for (int i = threadIdx.x; i < FROWS * zc; i += 256) S[(i / zc) * FLD + nin + (i % zc)] = 0.f;
+  for (int i = threadIdx.x; i < ROWS * zc; i += 256) S[(i / zc) * FLD + nin + (i % zc)] = 0.f;
 }
 
 // accumulators of a hoisted layer start at  U_s[col] + <xyz[row], W[col, xyz]>  (all operands staged in LDS)
-__device__ __forceinline__ void fused_hoist_init(f32x16 (&acc)[2][4], const float* hu, const float4* hwx, const float4* xs,
+template <int MT = 2>
+__device__ __forceinline__ void fused_hoist_init(f32x16 (&acc)[MT][4], const float* hu, const float4* hwx, const float4* xs,
                                                  int out_dim, int w, int fr, int fh) {
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {   // one n-tile at a time (few live registers); the xyz rows are re-read from LDS (broadcast)
@@ -830,7 +836,7 @@ __device__ __forceinline__ void fused_hoist_init(f32x16 (&acc)[2][4], const floa
     const float ub = ok ? hu[col] : 0.f;
     const float4 wq = ok ? hwx[col] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float4 x = xs[32 * m + crow(r) + 4 * fh];
@@ -841,12 +847,13 @@ __device__ __forceinline__ void fused_hoist_init(f32x16 (&acc)[2][4], const floa
 
 // S: the slab; xs: segment mode, xyz of the 64 points (zero padded); hu / hwx: segment mode, U_s of the hoisted layers and
 // their xyz weight columns.  On return in the training form (no y_out / u_out) the slab holds the last hidden activation.
-template <bool SPLIT = false>
+template <bool SPLIT = false, int MT = 2>
 __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float* S, float4* xs, float (*hu)[FMAXW],
                                                    float4 (*hwx)[FMAXW], int warm_bytes) {
+  constexpr int ROWS = 32 * MT;      // points per workgroup
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
-  const int row0 = blockIdx.x * FROWS;
+  const int row0 = blockIdx.x * ROWS;
   const bool segm = p.seg.wg_per_seg > 0;
   const uint32_t warm = warm_own_code(warm_bytes);
   if (warm == 0x9E3779B1u && p.N < 0) S[0] = 1.f;   // never true: keeps the loads
@@ -855,7 +862,7 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
   const int lfirst = (segm && p.n_hidden > 1) ? 1 : 0;   // first layer with an MFMA pass (segment mode: layer 0 has none)
   kl_prefetch<SPLIT>(PB, p.ly[lfirst].wf, p.ly[lfirst].wplane, p.ly[lfirst].wf32, p.ly[lfirst].U, w, lane, fused_nact(p.ly[lfirst].out_dim, w), (p.ly[lfirst].in + 15) >> 4);
   if (segm) {
-    if (tid < FROWS) {
+    if (tid < ROWS) {
       float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row0 + tid < p.N) {
         const float* q = p.seg.xyz + (size_t)(row0 + tid) * p.seg.G;
@@ -883,8 +890,8 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
       }
     }
   } else {
-    fused_load_x0(S, p.x0, p.ldx0, p.W0, row0, p.N, 0);
-    fused_zero_pad(S, p.W0);
+    fused_load_x0<ROWS>(S, p.x0, p.ldx0, p.W0, row0, p.N, 0);
+    fused_zero_pad<ROWS>(S, p.W0);
   }
   __syncthreads();
 #ifdef DSDF_LAB
@@ -894,7 +901,7 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
   for (int l = 0; l < p.n_hidden; ++l) {
     const FusedLayer& L = p.ly[l];
     const int nu = (L.in + 15) >> 4;   // segment mode: 0 for layer 0, only the previous layer's columns for the skip layer
-    f32x16 acc[2][4];
+    f32x16 acc[MT][4];
     // epilogue operands are fetched BEFORE the k-loop: a load issued after the epilogue's global stores would have
     // to wait for them (vmcnt is in-order and counts stores)
     float biasv[4];
@@ -906,10 +913,10 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
     int hidx = -1;
     if (segm) hidx = l == p.seg.h[0].layer ? 0 : (l == p.seg.h[1].layer ? 1 : -1);
     if (hidx >= 0) {
-      fused_hoist_init(acc, hu[hidx], hwx[hidx], xs, L.out_dim, w, fr, fh);
+      fused_hoist_init<MT>(acc, hu[hidx], hwx[hidx], xs, L.out_dim, w, fr, fh);
     } else {
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -917,7 +924,7 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
     }
     const float* ap = S + fr * FLD + 8 * fh;
     if (nu > 0) {
-      fused_kloop_dispatch<SPLIT>(acc, ap, L.wf, L.wplane, L.wf32, L.U, w, lane, nu, fused_nact(L.out_dim, w), PB);
+      fused_kloop_dispatch<SPLIT, MT>(acc, ap, L.wf, L.wplane, L.wf32, L.U, w, lane, nu, fused_nact(L.out_dim, w), PB);
       if (l + 1 < p.n_hidden) {   // next layer's first weights travel while this layer's epilogue runs
         const FusedLayer& Ln = p.ly[l + 1];
         kl_prefetch<SPLIT>(PB, Ln.wf, Ln.wplane, Ln.wf32, Ln.U, w, lane, fused_nact(Ln.out_dim, w), (Ln.in + 15) >> 4);
@@ -930,15 +937,15 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
 #ifdef DSDF_LAB
     if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 2 + 3 * l] = __builtin_amdgcn_s_memtime();
 #endif
-    if (L.x0_col >= 0) fused_load_x0(S, p.x0, p.ldx0, p.W0, row0, p.N, L.x0_col);  // loads first, stores after
+    if (L.x0_col >= 0) fused_load_x0<ROWS>(S, p.x0, p.ldx0, p.W0, row0, p.N, L.x0_col);  // loads first, stores after
     {
       const bool drop = L.drop_thr != 0u;
       const bool even = ((p.row_offset + (uint32_t)row0) & 1u) == 0u;   // 4*fh and crow(2rp) are even
-      if (!drop) fused_fwd_epilogue<false, true>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
-      else if (even) fused_fwd_epilogue<true, true>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
-      else fused_fwd_epilogue<true, false>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+      if (!drop) fused_fwd_epilogue<false, true, false, MT>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+      else if (even) fused_fwd_epilogue<true, true, false, MT>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+      else fused_fwd_epilogue<true, false, false, MT>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
     }
-    fused_zero_pad(S, L.x0_col >= 0 ? L.x0_col + p.W0 : L.out_dim);
+    fused_zero_pad<ROWS>(S, L.x0_col >= 0 ? L.x0_col + p.W0 : L.out_dim);
     __syncthreads();
 #ifdef DSDF_LAB
     if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 3 + 3 * l] = __builtin_amdgcn_s_memtime();
@@ -954,8 +961,8 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
     qv[cc] = c < p.in_last ? *reinterpret_cast<const float4*>(p.w_last + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const float blast = p.b_last[0];
-  for (int rr = 0; rr < FROWS / 4; ++rr) {
-    const int row = (FROWS / 4) * w + rr;
+  for (int rr = 0; rr < ROWS / 4; ++rr) {
+    const int row = (ROWS / 4) * w + rr;
     float dot = 0.f;
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
@@ -980,6 +987,16 @@ __global__ __launch_bounds__(256, 2) void fused_forward_kernel(const FusedFwdArg
   __shared__ float hu[FHOIST][FMAXW];
   __shared__ float4 hwx[FHOIST][FMAXW];
   fused_forward_body(p, S, xs, hu, hwx, 80 * 1024);
+}
+// 32 points per workgroup (MT = 1): a batch of at most 32 x #CUs points fills twice as many CUs as 64-point workgroups would, and
+// each workgroup does half the MFMA work (BASELINE config 4: ONE shape x 8000 points = 125 workgroups of 64 on 256 CUs).  Each weight
+// fragment feeds one MFMA instead of two, so per FLOP the k-loop issues twice the loads -- only worth it while CUs would idle.
+__global__ __launch_bounds__(256, 1) void fused_forward_h32_kernel(const FusedFwdArgs p) {
+  __shared__ __attribute__((aligned(16))) float S[32 * FLD];
+  __shared__ float4 xs[32];
+  __shared__ float hu[FHOIST][FMAXW];
+  __shared__ float4 hwx[FHOIST][FMAXW];
+  fused_forward_body<false, 1>(p, S, xs, hu, hwx, 80 * 1024);
 }
 // the same with the hidden GEMMs in split mode (fused_kloop_split); a kernel of its own so that the fp32 kernel keeps its registers
 __global__ __launch_bounds__(256, 1) void fused_forward_split_kernel(const FusedFwdArgs p) {
@@ -1366,10 +1383,10 @@ struct FusedBwdArgs {
   FusedBwdLayer ly[DSDF_MAX_LAYERS];
 };
 
-template <bool XS>
-__device__ __forceinline__ void fused_bwd_epilogue(const f32x16 (&acc)[2][4], float* S, const FusedBwdLayer& L, int w, int fr,
+template <bool XS, int MT = 2>
+__device__ __forceinline__ void fused_bwd_epilogue(const f32x16 (&acc)[MT][4], float* S, const FusedBwdLayer& L, int w, int fr,
                                                    int fh, int row0, int N, const uint4 mq, const float4* xs) {
-  const int rows_here = min(FROWS, N - row0);
+  const int rows_here = min(32 * MT, N - row0);
   __amdgpu_buffer_rsrc_t rdp = __builtin_amdgcn_make_buffer_rsrc(
       L.dp_out != nullptr ? (void*)(L.dp_out + (size_t)row0 * L.ld_dp) : (void*)S, 0,
       L.dp_out != nullptr ? rows_here * L.ld_dp * 4 : 0, 0x00020000);
@@ -1387,7 +1404,7 @@ __device__ __forceinline__ void fused_bwd_epilogue(const f32x16 (&acc)[2][4], fl
       const uint32_t voff = (uint32_t)((4 * fh) * ldb + col * 4);
       float* sp = S + (4 * fh) * FLD + col;
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
+      for (int m = 0; m < MT; ++m) {
         const uint32_t bits = mw[2 * m + (ni >> 1)] >> (16 * (ni & 1));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1405,7 +1422,7 @@ __device__ __forceinline__ void fused_bwd_epilogue(const f32x16 (&acc)[2][4], fl
     } else if (col - L.mask_cols < L.dz_cols) {
       const uint32_t voff = (uint32_t)((4 * fh) * ldzb + (col - L.mask_cols) * 4);
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][ni][r]), rdz, voff, (32 * m + crow(r)) * ldzb, 0);
@@ -1427,17 +1444,18 @@ __device__ __forceinline__ void fused_bwd_epilogue(const f32x16 (&acc)[2][4], fl
 
 // slab_ready: the slab already holds the last hidden activation (the merged forward+backward kernel) -- no reload, no code
 // warm-up; hred / hsc: scratch of the head's cross-wave reductions.
-template <bool SPLIT = false>
+template <bool SPLIT = false, int MT = 2>
 __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float* S, float4* xs, float (*hred)[2 * FMAXW],
                                                     float (*hsc)[2], bool slab_ready) {
+  constexpr int ROWS = 32 * MT;      // points per workgroup
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
-  const int row0 = blockIdx.x * FROWS;
+  const int row0 = blockIdx.x * ROWS;
   if (!slab_ready) {
     const uint32_t warm = warm_own_code(64 * 1024);
     if (warm == 0x9E3779B1u && p.N < 0) S[0] = 1.f;   // never true: keeps the loads
   }
-  if (p.xyz != nullptr && tid < FROWS) {
+  if (p.xyz != nullptr && tid < ROWS) {
     float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row0 + tid < p.N) {
       const float* q = p.xyz + (size_t)(row0 + tid) * p.G;
@@ -1450,11 +1468,11 @@ __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float
   }
 
   if (p.head.mode == HEAD_DP_GIVEN) {
-    fused_load_x0(S, p.dp_in, p.ld_in, p.w_in, row0, p.N, 0);
-    fused_zero_pad(S, p.w_in);
+    fused_load_x0<ROWS>(S, p.dp_in, p.ld_in, p.w_in, row0, p.N, 0);
+    fused_zero_pad<ROWS>(S, p.w_in);
   } else {
     const FusedBwdHead& H = p.head;
-    if (!slab_ready) fused_load_x0(S, H.a_last, H.ld_a, H.in_last, row0, p.N, 0);
+    if (!slab_ready) fused_load_x0<ROWS>(S, H.a_last, H.ld_a, H.in_last, row0, p.N, 0);
     float4 qv[2], dwa[2], csa[2];
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
@@ -1465,8 +1483,8 @@ __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float
     const float blast = H.b_last[0];
     float lossacc = 0.f, dbacc = 0.f;
     __syncthreads();
-    for (int rr = 0; rr < FROWS / 4; ++rr) {
-      const int row = (FROWS / 4) * w + rr, grow = row0 + row;
+    for (int rr = 0; rr < ROWS / 4; ++rr) {
+      const int row = (ROWS / 4) * w + rr, grow = row0 + row;
       float4 av[2];
       float dot = 0.f;
 #pragma unroll
@@ -1530,7 +1548,7 @@ __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float
       H.part_loss[blockIdx.x] = (hsc[0][0] + hsc[1][0]) + (hsc[2][0] + hsc[3][0]);
       H.part_db[blockIdx.x] = (hsc[0][1] + hsc[1][1]) + (hsc[2][1] + hsc[3][1]);
     }
-    fused_zero_pad(S, H.in_last);
+    fused_zero_pad<ROWS>(S, H.in_last);
   }
   typename KlSets<SPLIT>::type PB;
   if (p.n_layers > 0) kl_prefetch<SPLIT>(PB, p.ly[0].wtf, p.ly[0].wplane, p.ly[0].wtf32, p.ly[0].U, w, lane, fused_nact(p.ly[0].ncols, w), (p.ly[0].K + 15) >> 4);
@@ -1539,9 +1557,9 @@ __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float
   for (int i = 0; i < p.n_layers; ++i) {
     const FusedBwdLayer& L = p.ly[i];
     const int nu = (L.K + 15) >> 4;
-    f32x16 acc[2][4];
+    f32x16 acc[MT][4];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -1549,15 +1567,15 @@ __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float
     const float* ap = S + fr * FLD + 8 * fh;
     uint4 mq = make_uint4(0u, 0u, 0u, 0u);
     if (L.maskbits != nullptr) mq = *reinterpret_cast<const uint4*>(L.maskbits + ((size_t)blockIdx.x * 256 + tid) * 4);
-    fused_kloop_dispatch<SPLIT>(acc, ap, L.wtf, L.wplane, L.wtf32, L.U, w, lane, nu, fused_nact(L.ncols, w), PB);
+    fused_kloop_dispatch<SPLIT, MT>(acc, ap, L.wtf, L.wplane, L.wtf32, L.U, w, lane, nu, fused_nact(L.ncols, w), PB);
     if (i + 1 < p.n_layers) {
       const FusedBwdLayer& Ln = p.ly[i + 1];
       kl_prefetch<SPLIT>(PB, Ln.wtf, Ln.wplane, Ln.wtf32, Ln.U, w, lane, fused_nact(Ln.ncols, w), (Ln.K + 15) >> 4);
     }
     __syncthreads();
-    if (L.xsum != nullptr) fused_bwd_epilogue<true>(acc, S, L, w, fr, fh, row0, p.N, mq, xs);
-    else fused_bwd_epilogue<false>(acc, S, L, w, fr, fh, row0, p.N, mq, xs);
-    fused_zero_pad(S, L.mask_cols);
+    if (L.xsum != nullptr) fused_bwd_epilogue<true, MT>(acc, S, L, w, fr, fh, row0, p.N, mq, xs);
+    else fused_bwd_epilogue<false, MT>(acc, S, L, w, fr, fh, row0, p.N, mq, xs);
+    fused_zero_pad<ROWS>(S, L.mask_cols);
     __syncthreads();
   }
 }
@@ -1591,6 +1609,19 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_bwd_kernel(const FusedFwdArg
   fused_forward_body(f, S, xs, hu, hwx, 150 * 1024);
   __syncthreads();
   fused_backward_body(b, S, xs, hred, hsc, true);
+}
+// ... with 32 points per workgroup (see fused_forward_h32_kernel)
+__global__ __launch_bounds__(256, 1) void fused_fwd_bwd_h32_kernel(const FusedFwdArgs f, const FusedBwdArgs b) {
+  __shared__ __attribute__((aligned(16))) float S[32 * FLD];
+  __shared__ float4 xs[32];
+  __shared__ float4 scratch[FHOIST * FMAXW + FHOIST * FMAXW / 4];
+  float (*hu)[FMAXW] = reinterpret_cast<float (*)[FMAXW]>(scratch);
+  float4 (*hwx)[FMAXW] = reinterpret_cast<float4 (*)[FMAXW]>(scratch + FHOIST * FMAXW / 4);
+  float (*hred)[2 * FMAXW] = reinterpret_cast<float (*)[2 * FMAXW]>(scratch);
+  float (*hsc)[2] = reinterpret_cast<float (*)[2]>(scratch + 4 * 2 * FMAXW / 4);
+  fused_forward_body<false, 1>(f, S, xs, hu, hwx, 150 * 1024);
+  __syncthreads();
+  fused_backward_body<false, 1>(b, S, xs, hred, hsc, true);
 }
 __global__ __launch_bounds__(256, 1) void fused_fwd_bwd_split_kernel(const FusedFwdArgs f, const FusedBwdArgs b) {
   __shared__ __attribute__((aligned(16))) float S[FROWS * FLD];

@@ -131,39 +131,98 @@ struct HoistArgs {
   int L; const int64_t* seg_scene; const float* table; int R;
   float* U; int ldu;                       // [R][2][ldu]
   int bf16;                                // config 5: both operands rounded to bf16 (RNE), fp32 accumulation
+  // training steps: the max-norm renorm of the looked-up rows (K0a, embedding_renorm_, train_deep_sdf.py:385,509) is folded in.
+  // Every wave computes the scale of its segments' rows from the RAW table (same arithmetic in every wave: the lane-strided sum
+  // of squares + wave_sum of latent_renorm_kernel) and contracts the scaled values; nobody writes the table here -- other blocks
+  // are reading it.  The scaled rows go to zr [R][L] (written by the first block row, read by everything downstream of this
+  // launch instead of table[seg_scene[r]]); seg_scatter_body writes them back into the table.
+  float max_norm;                          // <= 0: no renorm (zr, if given, is a plain copy)
+  float* zr;                               // or nullptr (inference: dsdf_decode_latent)
+  float* dlat; long long nzero;            // the dense latent gradient, zeroed here (grid-stride), or nullptr
 };
-__global__ __launch_bounds__(256) void seg_hoist_kernel(const HoistArgs p) {   // grid (rows / 4, ceil(R / HOIST_SC))
+// KU = ceil(L / 64) as a compile-time constant: every load of the wave (the weight row's and the 16 latent rows' columns lane + 64 k)
+// is unconditional -- lanes past L read column L - 1 and drop it -- and goes out before the first use: ONE wait.  (Loads under a
+// per-lane or per-k condition each became a branch with a wait of its own: 36 us for this kernel instead of 10.)
+template <int KU>
+__device__ __forceinline__ void seg_hoist_body(const HoistArgs& p, const int n, const int t) {
   const int lane = threadIdx.x & 63;
+  const int s0 = blockIdx.y * HOIST_SC;
+  const long long myscene = (long long)p.seg_scene[min(s0 + (lane & (HOIST_SC - 1)), p.R - 1)];   // one load; broadcast below
+  const float* wrow = p.W[t] + (size_t)n * p.ldw[t] + p.c0[t];
+  float wv[KU], v[HOIST_SC][KU];
+#pragma unroll
+  for (int k = 0; k < KU; ++k) wv[k] = wrow[min(lane + 64 * k, p.L - 1)];
+#pragma unroll
+  for (int q = 0; q < HOIST_SC; ++q) {
+    const float* row = p.table + (size_t)__shfl(myscene, q, 64) * p.L;
+#pragma unroll
+    for (int k = 0; k < KU; ++k) v[q][k] = row[min(lane + 64 * k, p.L - 1)];
+  }
+#pragma unroll
+  for (int k = 0; k < KU; ++k) {
+    const bool ok = lane + 64 * k < p.L;
+    wv[k] = ok ? wv[k] : 0.f;
+#pragma unroll
+    for (int q = 0; q < HOIST_SC; ++q) v[q][k] = ok ? v[q][k] : 0.f;
+  }
+  static_assert(HOIST_SC == 16, "wave_sum16");
+  if (p.max_norm > 0.f) {     // (the 16 + 16 reductions of this kernel as 16 x 6 shuffles each were two thirds of its time)
+    float ss[HOIST_SC];
+#pragma unroll
+    for (int q = 0; q < HOIST_SC; ++q) {
+      ss[q] = 0.f;
+#pragma unroll
+      for (int k = 0; k < KU; ++k) ss[q] += v[q][k] * v[q][k];    // (columns >= L hold 0)
+    }
+    const float mine = wave_sum16(ss, lane);
+#pragma unroll
+    for (int q = 0; q < HOIST_SC; ++q) {
+      const float nu = sqrtf(__shfl(mine, wave_sum16_lane(q), 64));
+      if (nu > p.max_norm) {
+        const float sc = p.max_norm / (nu + 1e-7f);
+#pragma unroll
+        for (int k = 0; k < KU; ++k) v[q][k] *= sc;
+      }
+    }
+  }
+  if (p.zr != nullptr && blockIdx.x == 0 && threadIdx.x < 64) {
+#pragma unroll
+    for (int q = 0; q < HOIST_SC; ++q)
+      if (s0 + q < p.R)
+#pragma unroll
+        for (int k = 0; k < KU; ++k)
+          if (lane + 64 * k < p.L) p.zr[(size_t)(s0 + q) * p.L + lane + 64 * k] = v[q][k];
+  }
+  float a[HOIST_SC];
+#pragma unroll
+  for (int q = 0; q < HOIST_SC; ++q) a[q] = 0.f;
+#pragma unroll
+  for (int k = 0; k < KU; ++k) {
+    const float w = p.bf16 ? (float)(__bf16)wv[k] : wv[k];
+#pragma unroll
+    for (int q = 0; q < HOIST_SC; ++q) {
+      const float x = p.bf16 ? (float)(__bf16)v[q][k] : v[q][k];
+      if (lane + 64 * k < p.L) a[q] = fmaf(w, x, a[q]);
+    }
+  }
+  const float r = wave_sum16(a, lane);
+  const int qi = wave_sum16_index(lane);
+  if ((lane & 3) == 0 && s0 + qi < p.R) p.U[((size_t)(s0 + qi) * 2 + t) * p.ldu + n] = r;
+}
+template <int KU>    // one kernel per KU: the 8-unit body's 206 VGPRs would otherwise set the occupancy of every latent size
+__global__ __launch_bounds__(256) void seg_hoist_kernel(const HoistArgs p) {   // grid (rows / 4, ceil(R / HOIST_SC)); needs L <= 64 KU
+  if (p.dlat != nullptr) {
+    const long long nb = (long long)gridDim.x * gridDim.y, b = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+    for (long long i = (b * 256 + threadIdx.x) * 4; i < p.nzero; i += nb * 256 * 4) {
+      if (i + 3 < p.nzero) *reinterpret_cast<float4*>(p.dlat + i) = make_float4(0.f, 0.f, 0.f, 0.f);   // dlat is 16-byte aligned
+      else for (long long q = i; q < p.nzero; ++q) p.dlat[q] = 0.f;
+    }
+  }
   int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   int t = 0;
   if (n >= p.out[0]) { n -= p.out[0]; t = 1; }
   if (t >= p.nh || n >= p.out[t]) return;
-  const int s0 = blockIdx.y * HOIST_SC;
-  const float* rows[HOIST_SC];
-#pragma unroll
-  for (int q = 0; q < HOIST_SC; ++q) rows[q] = p.table + (size_t)p.seg_scene[min(s0 + q, p.R - 1)] * p.L;
-  const float* wrow = p.W[t] + (size_t)n * p.ldw[t] + p.c0[t];
-  float a[HOIST_SC];
-#pragma unroll
-  for (int q = 0; q < HOIST_SC; ++q) a[q] = 0.f;
-  for (int c = lane; c < p.L; c += 64) {
-    float wv = wrow[c];
-    float v[HOIST_SC];
-#pragma unroll
-    for (int q = 0; q < HOIST_SC; ++q) v[q] = rows[q][c];
-    if (p.bf16) {
-      wv = (float)(__bf16)wv;
-#pragma unroll
-      for (int q = 0; q < HOIST_SC; ++q) v[q] = (float)(__bf16)v[q];
-    }
-#pragma unroll
-    for (int q = 0; q < HOIST_SC; ++q) a[q] = fmaf(wv, v[q], a[q]);
-  }
-#pragma unroll
-  for (int q = 0; q < HOIST_SC; ++q) {
-    const float r = wave_sum(a[q]);
-    if (lane == 0 && s0 + q < p.R) p.U[((size_t)(s0 + q) * 2 + t) * p.ldu + n] = r;
-  }
+  seg_hoist_body<KU>(p, n, t);
 }
 
 // K5c (segment mode): the x0 columns of the hoisted layers' weight gradients, from per-workgroup sums of the fused
@@ -171,31 +230,48 @@ __global__ __launch_bounds__(256) void seg_hoist_kernel(const HoistArgs p) {   /
 //   HS[t][i][c]     = sum_s (sum of segment s's workgroup column sums of dP_t[:, i]) * latent[scene_s][c]     c < L
 //   HS[t][i][L + j] = sum_wg xsum_t[wg][j][i]                                                                 j < G
 // finalize_row adds HS to the row's columns [lat0, lat0 + L + G).  Block = 8 output rows x all columns; fixed order.
-constexpr int SDW_ROWS = 8;
+// Round 4: 32 output rows per block instead of 8 (a quarter of the blocks, each with the same number of memory round trips) and every
+// run of dependent loads batched -- as riding roles on the dW launch's 16 spare workgroups these blocks were 115 us of a 391 us role
+// chain that outlasted the launch's MFMA items (377 us: profiles/r04_dw_stamps_before.log).
+constexpr int SDW_ROWS = 32;
+constexpr int SDW_SLOTS = 256 / SDW_ROWS;   // loader mapping: SDW_ROWS consecutive rows x SDW_SLOTS segments / workgroup slices
+constexpr int SDW_LDS_FLOATS = 64 * SDW_ROWS + SDW_SLOTS * SDW_ROWS * 4 + 2 * 64;
 struct SegDwArgs {
   int nh; const float* cs[2]; const float* xsum[2]; int out[2];   // per-workgroup sums [nwg][ldcs] / [nwg][4][ldcs]
   int ldcs, nwg, wg_per_seg, R, L, G;
   const int64_t* seg_scene; const float* table;
+  const float* zr;                                                // non-null: segment r's latent row is zr + r L (seg_hoist_kernel)
   float* HS; int ldh; long long hstride;                          // HS[t] = HS + t * hstride, [out_t][ldh]
 };
-__device__ __forceinline__ void seg_dw_body(const SegDwArgs& p, int bidx) {
-  __shared__ __attribute__((aligned(16))) float css[64][SDW_ROWS];
-  __shared__ long long srow[64];
-  __shared__ float xred[32][SDW_ROWS][4];
+__device__ __forceinline__ void seg_dw_body(const SegDwArgs& p, int bidx, float* lds) {
+  float (*css)[SDW_ROWS] = reinterpret_cast<float (*)[SDW_ROWS]>(lds);                               // [64 segments][rows]
+  float (*xred)[SDW_ROWS][4] = reinterpret_cast<float (*)[SDW_ROWS][4]>(lds + 64 * SDW_ROWS);          // [slots][rows][4]
+  long long* srow = reinterpret_cast<long long*>(lds + 64 * SDW_ROWS + SDW_SLOTS * SDW_ROWS * 4);      // [64]
   const int tid = threadIdx.x;
   int blk = bidx, t = 0;
   const int b0 = (p.out[0] + SDW_ROWS - 1) / SDW_ROWS;
   if (blk >= b0) { blk -= b0; t = 1; }
   const int i0 = blk * SDW_ROWS;
   const float* cs = p.cs[t];
-  const int r_ld = tid & (SDW_ROWS - 1), s_ld = tid / SDW_ROWS;   // loader mapping: 8 consecutive rows x 32 segments / slices
-  // xyz columns first (independent loads, in flight under everything else): 32 slices of the workgroups
+  const int r_ld = tid & (SDW_ROWS - 1), s_ld = tid / SDW_ROWS;
+  const bool rok = i0 + r_ld < p.out[t];
+  const int ird = min(i0 + r_ld, p.out[t] - 1);    // (loads are unconditional on clamped, valid addresses; the values are dropped by selects)
+  // xyz columns first (independent loads, in flight under everything else): SDW_SLOTS slices of the workgroups, 8 loads per batch
   float xa[4] = {0.f, 0.f, 0.f, 0.f};
-  if (i0 + r_ld < p.out[t])
-    for (int wg = s_ld; wg < p.nwg; wg += 32)
+  for (int wg0 = s_ld; wg0 < p.nwg; wg0 += 8 * SDW_SLOTS) {
+    float tx[8][4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int wg = wg0 + u * SDW_SLOTS;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (j < p.G) xa[j] += p.xsum[t][((size_t)wg * 4 + j) * p.ldcs + i0 + r_ld];
+        tx[u][j] = p.xsum[t][((size_t)min(wg, p.nwg - 1) * 4 + j) * p.ldcs + ird];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xa[j] += (rok && wg0 + u * SDW_SLOTS < p.nwg && j < p.G) ? tx[u][j] : 0.f;
+  }
   constexpr int NC = HOIST_MAXL / 256;       // column passes of 256
   float acc[NC][SDW_ROWS];
 #pragma unroll
@@ -204,45 +280,62 @@ __device__ __forceinline__ void seg_dw_body(const SegDwArgs& p, int bidx) {
     for (int r = 0; r < SDW_ROWS; ++r) acc[k][r] = 0.f;
   for (int s0 = 0; s0 < p.R; s0 += 64) {
     __syncthreads();
-    if (p.wg_per_seg <= 2 * min(64, p.R - s0)) {   // many short segments: one thread per (row, segment), its workgroups one after the other
+    if (p.wg_per_seg <= 16) {      // many short segments: one thread per (row, segment), its workgroups in order (all loads in flight)
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int sl = s_ld + 32 * q, sg = s0 + sl;
+      for (int q = 0; q < 64 / SDW_SLOTS; ++q) {
+        const int sl = s_ld + SDW_SLOTS * q, sg = s0 + sl;
+        float tg[16];
+#pragma unroll
+        for (int g = 0; g < 16; ++g)
+          tg[g] = cs[(size_t)(min(sg, p.R - 1) * p.wg_per_seg + min(g, p.wg_per_seg - 1)) * p.ldcs + ird];
         float a = 0.f;
-        if (sg < p.R && i0 + r_ld < p.out[t])
-          for (int g = 0; g < p.wg_per_seg; ++g) a += cs[(size_t)(sg * p.wg_per_seg + g) * p.ldcs + i0 + r_ld];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) a += (sg < p.R && rok && g < p.wg_per_seg) ? tg[g] : 0.f;
         css[sl][r_ld] = a;
       }
-    } else {                       // few long segments (up to 16384 samples per scene): 32 threads share a segment's workgroups
+    } else {                       // longer segments (up to 16384 samples per scene): SDW_SLOTS threads share a segment's workgroups
       for (int sl = 0; sl < 64; ++sl) {
         const int sg = s0 + sl;
         float a = 0.f;
-        if (sg < p.R && i0 + r_ld < p.out[t])
-          for (int g = s_ld; g < p.wg_per_seg; g += 32) a += cs[(size_t)(sg * p.wg_per_seg + g) * p.ldcs + i0 + r_ld];
+        if (sg < p.R && rok)
+          for (int g0 = s_ld; g0 < p.wg_per_seg; g0 += 8 * SDW_SLOTS) {
+            float tg[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int g = g0 + u * SDW_SLOTS;
+              tg[u] = g < p.wg_per_seg ? cs[(size_t)(sg * p.wg_per_seg + g) * p.ldcs + i0 + r_ld] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += tg[u];
+          }
         xred[s_ld][r_ld][0] = a;   // (xred is free here: its xyz partials are written after this loop)
         __syncthreads();
         if (tid < SDW_ROWS) {
           float v = 0.f;
 #pragma unroll
-          for (int q = 0; q < 32; ++q) v += xred[q][tid][0];
+          for (int q = 0; q < SDW_SLOTS; ++q) v += xred[q][tid][0];
           css[sl][tid] = v;
         }
         __syncthreads();
         if (sg + 1 >= p.R) {       // the remaining slots of this pass are empty
-          for (int z = sl + 1 + (tid >> 3); z < 64; z += 32) css[z][r_ld] = 0.f;
+          for (int z = sl + 1 + s_ld; z < 64; z += SDW_SLOTS) css[z][r_ld] = 0.f;
           break;
         }
       }
     }
-    if (tid < 64) srow[tid] = s0 + tid < p.R ? (long long)p.seg_scene[s0 + tid] * p.L : 0;
+    if (tid < 64) {
+      const int sg = min(s0 + tid, p.R - 1);                       // segments beyond R: a valid row, css == 0
+      srow[tid] = p.zr != nullptr ? (long long)sg * p.L : (long long)p.seg_scene[sg] * p.L;
+    }
     __syncthreads();
+    const float* lat = p.zr != nullptr ? p.zr : p.table;
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
       const int c = tid + 256 * k;
       if (c < p.L) {
         float v[64];                          // every latent value of this column for the 64 segments: one wait
 #pragma unroll
-        for (int u = 0; u < 64; ++u) v[u] = p.table[srow[u] + c];   // segments beyond R: row 0 (valid), css == 0
+        for (int u = 0; u < 64; ++u) v[u] = lat[srow[u] + c];
 #pragma unroll
         for (int u = 0; u < 64; ++u) {
           const float4* cq = reinterpret_cast<const float4*>(css[u]);   // broadcast 16-byte reads
@@ -267,15 +360,16 @@ __device__ __forceinline__ void seg_dw_body(const SegDwArgs& p, int bidx) {
       for (int r = 0; r < SDW_ROWS; ++r)
         if (i0 + r < p.out[t]) hs[(size_t)(i0 + r) * p.ldh + c] = acc[k][r];
   }
+  __syncthreads();
 #pragma unroll
   for (int j = 0; j < 4; ++j) xred[s_ld][r_ld][j] = xa[j];
   __syncthreads();
-  if (tid < SDW_ROWS * 4) {                  // fixed-order sum of the 32 slices
+  if (tid < SDW_ROWS * 4) {                  // fixed-order sum of the slices
     const int r = tid >> 2, j = tid & 3;
     if (j < p.G && i0 + r < p.out[t]) {
       float v = 0.f;
 #pragma unroll
-      for (int q = 0; q < 32; ++q) v += xred[q][r][j];
+      for (int q = 0; q < SDW_SLOTS; ++q) v += xred[q][r][j];
       hs[(size_t)(i0 + r) * p.ldh + p.L + j] = v;
     }
   }
@@ -639,13 +733,128 @@ __global__ __launch_bounds__(256) void finalize_layer_kernel(const FinArgs p) {
   finalize_row(p, blockIdx.x, red);
 }
 
-// every layer in ONE launch: block -> (layer, output row)
-struct FinAll { int n; int row0[DSDF_MAX_LAYERS + 1]; FinArgs f[DSDF_MAX_LAYERS]; };
+// The same row by ONE WAVE (rows of at most 64 * FW_MAXK = 512 inputs: every fused-path layer), four rows per block.  The block form
+// above walks a chain of dependent memory round trips with three block barriers in it (slab sums -> v -> Adam state -> stores); here a
+// lane requests EVERYTHING its columns need before the first use -- the split-K partials, v, both Adam moments, the bias partials -- and
+// the three reductions are wave shuffles.  Same per-element slab order (sp = 0 .. nsplit - 1), its own (fixed) order for the row
+// reductions.  Round 4: the finalize launch 34 -> see profiles/r04_bench_kernel_stats.csv.
+constexpr int FW_MAXK = 8;
+__device__ __forceinline__ void finalize_row_wave(const FinArgs& p, const int i) {
+  const int lane = threadIdx.x & 63;
+  float vv[FW_MAXK], mo[FW_MAXK], so[FW_MAXK], dwr[FW_MAXK];
+  const size_t ro = (size_t)i * p.in;
+  // (every load is UNCONDITIONAL -- out-of-range lanes read a clamped, valid address and drop the value with a select: a load under a
+  // per-lane condition becomes a branch of its own with its own wait)
+  const float* mp = p.adam ? p.mv : p.v;
+  const float* sp_ = p.adam ? p.sv : p.v;
+#pragma unroll
+  for (int k = 0; k < FW_MAXK; ++k) {
+    const int c = lane + 64 * k, cc = min(c, p.in - 1);
+    const float a0 = p.v[ro + cc], a1 = mp[ro + cc], a2 = sp_[ro + cc];
+    const bool ok = c < p.in;
+    vv[k] = ok ? a0 : 0.f; mo[k] = ok ? a1 : 0.f; so[k] = ok ? a2 : 0.f;
+  }
+  float bs = 0.f;                                  // bias gradient: fixed-order sum of the column partials
+  for (int q0 = lane; q0 < p.npart; q0 += 256) {
+    float t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[u] = p.colsum[(size_t)min(q0 + 64 * u, p.npart - 1) * p.ldcs + i];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bs += q0 + 64 * u < p.npart ? t[u] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < FW_MAXK; ++k) dwr[k] = 0.f;
+  for (int sp = 0; sp < p.nsplit; sp += 4) {       // 4 splits x 8 columns in flight per batch; per element the order sp = 0, 1, ... of finalize_row
+    float t[4][FW_MAXK];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < FW_MAXK; ++k)
+        if (64 * k < p.in)                         // (wave-uniform)
+          t[u][k] = p.slabs[(size_t)min(sp + u, p.nsplit - 1) * p.slab + (size_t)i * p.ldc + min(lane + 64 * k, p.in - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < FW_MAXK; ++k) {
+        const int c = lane + 64 * k;
+        if (64 * k < p.in) dwr[k] += (sp + u < p.nsplit && c < p.in && (!p.hoist || c < p.lat0)) ? t[u][k] : 0.f;
+      }
+  }
+  if (p.hoist) {   // x0 columns of a hoisted layer: computed by seg_dw_body
+#pragma unroll
+    for (int k = 0; k < FW_MAXK; ++k) {
+      const int c = lane + 64 * k - p.lat0;
+      if (c >= 0 && c < p.hW) dwr[k] += p.hs[(size_t)i * p.ldh + c];
+    }
+  }
+  bs = wave_sum(bs);
+  if (p.g) {
+    float dot = 0.f, ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < FW_MAXK; ++k) { dot += dwr[k] * vv[k]; ss += vv[k] * vv[k]; }     // (columns >= in hold zeros)
+    dot = wave_sum(dot);
+    ss = wave_sum(ss);
+    const float nrm = sqrtf(ss);
+    const float gi = p.g[i];
+    const float dgi = dot / nrm;
+    const float a = gi / nrm, b = gi * dgi / (nrm * nrm);
+    float ssn = 0.f;
+#pragma unroll
+    for (int k = 0; k < FW_MAXK; ++k) {
+      const int c = lane + 64 * k;
+      if (c < p.in) {
+        const float d = a * dwr[k] - b * vv[k];
+        if (p.adam) {
+          float pn = vv[k];
+          const float vn = adam_elem(pn, d, mo[k], so[k], p);
+          p.pv[ro + c] = vn; p.mv[ro + c] = mo[k]; p.sv[ro + c] = so[k];
+          ssn += vn * vn;
+        } else p.dv[ro + c] = p.accumulate ? p.dv[ro + c] + d : d;
+      }
+    }
+    if (p.adam) {
+      ssn = wave_sum(ssn);
+      if (lane == 0) {
+        const float gn = adam_elem(p.pg[i], dgi, p.mg[i], p.sg[i], p);
+        p.scale_out[i] = gn / sqrtf(ssn);
+      }
+    } else if (lane == 0) p.dg[i] = p.accumulate ? p.dg[i] + dgi : dgi;
+  } else {
+#pragma unroll
+    for (int k = 0; k < FW_MAXK; ++k) {
+      const int c = lane + 64 * k;
+      if (c < p.in) {
+        if (p.adam) {
+          float pn = vv[k];
+          adam_elem(pn, dwr[k], mo[k], so[k], p);
+          p.pv[ro + c] = pn; p.mv[ro + c] = mo[k]; p.sv[ro + c] = so[k];
+        } else p.dv[ro + c] = p.accumulate ? p.dv[ro + c] + dwr[k] : dwr[k];
+      }
+    }
+    if (p.adam && lane == 0) p.scale_out[i] = 1.f;
+  }
+  if (lane == 0) {
+    if (p.adam) adam_elem(p.pb[i], bs, p.mb[i], p.sb[i], p);
+    else p.db[i] = p.accumulate ? p.db[i] + bs : bs;
+  }
+}
+
+// every layer in ONE launch: block -> (layer, output rows).  Layers of at most 512 inputs: four rows per block, one wave each
+// (finalize_row_wave); wider ones (layer-by-layer path only): one row per block (finalize_row).
+struct FinAll { int n; int row0[DSDF_MAX_LAYERS + 1]; FinArgs f[DSDF_MAX_LAYERS]; };   // row0: first BLOCK of each layer
+__host__ __device__ inline int fin_blocks(int out, int in) { return in <= 64 * FW_MAXK ? (out + 3) / 4 : out; }
+__device__ __forceinline__ void finalize_block(const FinAll& p, const int b, float* red) {
+  int l = 0;
+  while (l + 1 < p.n && b >= p.row0[l + 1]) ++l;
+  const FinArgs& f = p.f[l];
+  if (f.in <= 64 * FW_MAXK) {
+    const int i = (b - p.row0[l]) * 4 + (int)(threadIdx.x >> 6);
+    if (i < f.out) finalize_row_wave(f, i);
+  } else finalize_row(f, b - p.row0[l], red);
+}
 __global__ __launch_bounds__(256) void finalize_all_kernel(const FinAll p) {
   __shared__ float red[4];
-  int l = 0;
-  while (l + 1 < p.n && (int)blockIdx.x >= p.row0[l + 1]) ++l;
-  finalize_row(p.f[l], blockIdx.x - p.row0[l], red);
+  finalize_block(p, (int)blockIdx.x, red);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -694,12 +903,14 @@ struct SegLatArgs {
   const float* csk; int outk; const float* Wk; int ldwk; int koff;        // skip layer (csk may be null)
   int wg_per_seg; int R; int L;
   const int64_t* seg_scene; const float* table;
+  const float* zr;                                                         // non-null: segment r's latent row is zr + r L
   float* segpart; float* segnorm;
 };
-__device__ __forceinline__ void seg_latgrad_body(const SegLatArgs& p, int bx, int by) {
+constexpr int SLAT_LDS_FLOATS = 2 * FSEG_MAXW + 16 * 17;
+__device__ __forceinline__ void seg_latgrad_body(const SegLatArgs& p, int bx, int by, float* lds) {
   // (bx, by) in (R, ceil(L/16)); block = 16 columns x 16 k-slices: 1024+ blocks of short dot products instead of 256 long ones
-  __shared__ float ss[2][FSEG_MAXW];
-  __shared__ float red[16][17];
+  float (*ss)[FSEG_MAXW] = reinterpret_cast<float (*)[FSEG_MAXW]>(lds);
+  float (*red)[17] = reinterpret_cast<float (*)[17]>(lds + 2 * FSEG_MAXW);
   const int r = bx, c0 = by * 16, tid = threadIdx.x, cx = tid & 15, ks = tid >> 4;
   // a segment's column sums = the sum of its workgroups' column sums, in workgroup order.  The loads go out 32 at a time (the adds
   // keep their order, so the result bits do not change): one load per add left a 256-workgroup segment -- one scene x 16384
@@ -750,7 +961,7 @@ __device__ __forceinline__ void seg_latgrad_body(const SegLatArgs& p, int bx, in
     p.segpart[(size_t)r * p.L + col] = s;
   }
   if (by == 0 && tid < 64) {
-    const float* row = p.table + (size_t)p.seg_scene[r] * p.L;
+    const float* row = p.zr != nullptr ? p.zr + (size_t)r * p.L : p.table + (size_t)p.seg_scene[r] * p.L;
     float q = 0.f;
     for (int c = tid; c < p.L; c += 64) { const float v = row[c]; q += v * v; }
     q = wave_sum(q);
@@ -758,10 +969,125 @@ __device__ __forceinline__ void seg_latgrad_body(const SegLatArgs& p, int bx, in
   }
 }
 
+// The same result computed the other way round, for batches of at most 256 workgroups (the ones whose roles ride on the dW
+// launch's spare workgroups): ONE block per 16-column chunk of the latent takes ALL segments --
+//   segpart[R][16] = css_0[R][out0] W_0[:, chunk] + css_k[R][outk] W_k[:, chunk],   css_t[r] = sum of segment r's workgroup column sums
+// as a small tiled GEMM: per chunk of 64 rows of W the block stages the 64 x 16 weights and the 64 segments x 64 column sums in LDS
+// (every load of the chunk in flight at once: one memory round trip per chunk), then thread (segment, 4 columns) adds its 64 x 4
+// products.  16 blocks of ~16 round trips replace the 1024 blocks of ~6 that took 251 us on 16 workgroups (r04_dw_stamps_before.log).
+// Fixed summation order (not the order of seg_latgrad_body: the two forms agree to rounding).  Needs R * wg_per_seg <= 256.
+constexpr int SLA_LDS_FLOATS = 64 * 65 + 64 * 16 + 4 * 16 * 64;
+__device__ __forceinline__ void seg_latgrad_all_body(const SegLatArgs& p, int by, int nby, float* lds) {
+  float (*css)[65] = reinterpret_cast<float (*)[65]>(lds);                  // [64 segments][64 rows of the chunk] (+1: banks)
+  float (*wch)[16] = reinterpret_cast<float (*)[16]>(lds + 64 * 65);        // [64 rows][16 columns]
+  float* part = lds + 64 * 65 + 64 * 16;                                    // [4 slices][16 segments][64 rows]: long segments
+  const int tid = threadIdx.x, c0 = by * 16;
+  const int li = tid & 63, lq = tid >> 6;                                   // loader: row of the chunk, quarter
+  const int sr = tid >> 2, cq = tid & 3;                                    // adder: segment of the group, its 4 columns
+  const int wps = p.wg_per_seg;
+  for (int s0 = 0; s0 < p.R; s0 += 64) {
+    const int ng = min(64, p.R - s0);
+    const bool sliced = ng <= 16;       // few segments (of up to 256 workgroups): the 4 quarters share every segment's workgroups
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 2; ++t) {
+      const float* cs = t == 0 ? p.cs0 : p.csk;
+      if (cs == nullptr) continue;
+      const int n = t == 0 ? p.out0 : p.outk, ldw = t == 0 ? p.ldw0 : p.ldwk;
+      const float* W = (t == 0 ? p.W0 : p.Wk + p.koff) + c0;
+      for (int i0 = 0; i0 < n; i0 += 64) {
+        __syncthreads();                                                    // the previous chunk has been consumed
+        {   // weights of the chunk: thread (row sr, columns 4 cq ..)
+          const int i = i0 + sr;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float wl = W[(size_t)min(i, n - 1) * ldw + min(4 * cq + e, p.L - 1 - c0)];
+            wch[sr][4 * cq + e] = (i < n && c0 + 4 * cq + e < p.L) ? wl : 0.f;
+          }
+        }
+        const bool iok = i0 + li < n;
+        const float* qs = cs + (size_t)s0 * wps * p.ldcs + min(i0 + li, n - 1);   // workgroup row wg of this group: qs + wg ldcs
+        const int lastwg = ng * wps - 1;
+        if (!sliced) {      // thread (lq, li): segments sl = lq, lq + 4, ...; each one's workgroups in order; flat batches of 32 loads
+          const int mine = lq < ng ? (ng - lq + 3) >> 2 : 0, total = mine * wps;
+          int sl = lq, g = 0;
+          float a = 0.f;
+          for (int e0 = 0; e0 < total; e0 += 32) {
+            float tv[32];
+            {
+              int sl2 = sl, g2 = g;
+#pragma unroll
+              for (int u = 0; u < 32; ++u) {     // (unconditional loads: past the end a lane re-reads its last valid workgroup row)
+                tv[u] = qs[(size_t)min(sl2 * wps + g2, lastwg) * p.ldcs];
+                if (++g2 == wps) { g2 = 0; sl2 += 4; }
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+              if (e0 + u < total) {
+                a += iok ? tv[u] : 0.f;
+                if (++g == wps) { css[sl][li] = a; a = 0.f; g = 0; sl += 4; }
+              }
+            }
+          }
+        } else {            // thread (lq, li): workgroups g = lq, lq + 4, ... of EVERY segment; partial sums, combined in fixed order
+          const int gq = lq < wps ? (wps - lq + 3) >> 2 : 0, total = ng * gq;
+          int sl = 0, k = 0;
+          float a = 0.f;
+          for (int e0 = 0; e0 < total; e0 += 32) {
+            float tv[32];
+            {
+              int sl2 = sl, k2 = k;
+#pragma unroll
+              for (int u = 0; u < 32; ++u) {
+                tv[u] = qs[(size_t)min(sl2 * wps + lq + 4 * k2, lastwg) * p.ldcs];
+                if (++k2 == gq) { k2 = 0; ++sl2; }
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+              if (e0 + u < total) {
+                a += iok ? tv[u] : 0.f;
+                if (++k == gq) { part[(lq * 16 + sl) * 64 + li] = a; a = 0.f; k = 0; ++sl; }
+              }
+            }
+          }
+          if (gq == 0)
+            for (int z = 0; z < ng; ++z) part[(lq * 16 + z) * 64 + li] = 0.f;
+          __syncthreads();
+          for (int z = lq; z < ng; z += 4)
+            css[z][li] = (part[(0 * 16 + z) * 64 + li] + part[(1 * 16 + z) * 64 + li]) + (part[(2 * 16 + z) * 64 + li] + part[(3 * 16 + z) * 64 + li]);
+        }
+        __syncthreads();
+        if (sr < ng) {
+#pragma unroll 8
+          for (int i = 0; i < 64; ++i) {
+            const float a = css[sr][i];
+            const float4 w4 = *reinterpret_cast<const float4*>(&wch[i][4 * cq]);
+            acc[0] = fmaf(a, w4.x, acc[0]); acc[1] = fmaf(a, w4.y, acc[1]);
+            acc[2] = fmaf(a, w4.z, acc[2]); acc[3] = fmaf(a, w4.w, acc[3]);
+          }
+        }
+      }
+    }
+    if (sr < ng)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c0 + 4 * cq + e < p.L) p.segpart[(size_t)(s0 + sr) * p.L + c0 + 4 * cq + e] = acc[e];
+  }
+  // the segments' latent norms (regulariser): block by takes segments by, by + nby, ...; one wave each
+  for (int r = by + nby * lq; r < p.R; r += 4 * nby) {
+    const float* row = p.zr != nullptr ? p.zr + (size_t)r * p.L : p.table + (size_t)p.seg_scene[r] * p.L;
+    float q = 0.f;
+    for (int c = li; c < p.L; c += 64) { const float v = row[c]; q += v * v; }
+    q = wave_sum(q);
+    if (li == 0) p.segnorm[r] = sqrtf(q);
+  }
+}
+
 // rows [g*P/G, (g+1)*P/G) of part[P][ld] summed into out[g][ld] (fixed order): second stage of the head's partials
 struct ReduceRowsArgs { const float* part; int P, ld, n; float* out; int G; };
-__device__ __forceinline__ void reduce_rows_body(const ReduceRowsArgs& a, int bx, int g) {
-  __shared__ float red[4][64];
+__device__ __forceinline__ void reduce_rows_body(const ReduceRowsArgs& a, int bx, int g, float* lds) {
+  float (*red)[64] = reinterpret_cast<float (*)[64]>(lds);
   const int c = bx * 64 + (threadIdx.x & 63), ry = threadIdx.x >> 6;
   const int beg = (int)((long long)g * a.P / a.G), end = (int)((long long)(g + 1) * a.P / a.G);
   float s = 0.f;
@@ -774,23 +1100,33 @@ __device__ __forceinline__ void reduce_rows_body(const ReduceRowsArgs& a, int bx
     a.out[(size_t)g * a.ld + c] = (red[0][x] + red[1][x]) + (red[2][x] + red[3][x]);
   }
 }
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const ReduceRowsArgs a) { reduce_rows_body(a, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const ReduceRowsArgs a) {
+  __shared__ float red[4 * 64];
+  reduce_rows_body(a, blockIdx.x, blockIdx.y, red);
+}
 
 // Segment mode: everything that consumes only the fused backward's per-workgroup partials, in ONE launch -- the head's
 // second reduction stage, the hoisted layers' x0 weight-gradient columns and the per-segment latent gradient.
 struct PostBwdArgs {
   ReduceRowsArgs rr; int rr_bx, rr_n;        // blocks [0, rr_n): (bx, g) = (i % rr_bx, i / rr_bx)
   SegDwArgs dw; int dw_n;                    // next dw_n blocks (0: weights frozen)
-  SegLatArgs lat; int lat_bx;                // the rest: (bx, by) = (i % lat_bx, i / lat_bx)
-};
-__device__ __forceinline__ void post_bwd_role(const PostBwdArgs& p, int i) {
-  if (i < p.rr_n) { reduce_rows_body(p.rr, i % p.rr_bx, i / p.rr_bx); return; }
+  SegLatArgs lat; int lat_bx;                // the rest: (bx, by) = (i % lat_bx, i / lat_bx); lat_bx == 0: the all-segments form,
+};                                           // one block per 16-column chunk of the latent (seg_latgrad_all_body)
+// LDS scratch of the roles comes from the caller (the dW kernels lend theirs): the largest role's need
+constexpr int ROLE_LDS_FLOATS = SLA_LDS_FLOATS > SDW_LDS_FLOATS ? SLA_LDS_FLOATS : SDW_LDS_FLOATS;
+static_assert(ROLE_LDS_FLOATS >= SLAT_LDS_FLOATS && ROLE_LDS_FLOATS >= 4 * 64, "role scratch");
+__device__ __forceinline__ void post_bwd_role(const PostBwdArgs& p, int i, int lat_n, float* lds) {
+  if (i < p.rr_n) { reduce_rows_body(p.rr, i % p.rr_bx, i / p.rr_bx, lds); return; }
   i -= p.rr_n;
-  if (i < p.dw_n) { seg_dw_body(p.dw, i); return; }
+  if (i < p.dw_n) { seg_dw_body(p.dw, i, lds); return; }
   i -= p.dw_n;
-  seg_latgrad_body(p.lat, i % p.lat_bx, i / p.lat_bx);
+  if (p.lat_bx == 0) seg_latgrad_all_body(p.lat, i, lat_n, lds);
+  else seg_latgrad_body(p.lat, i % p.lat_bx, i / p.lat_bx, lds);
 }
-__global__ __launch_bounds__(256) void post_bwd_kernel(const PostBwdArgs p) { post_bwd_role(p, blockIdx.x); }
+__global__ __launch_bounds__(256) void post_bwd_kernel(const PostBwdArgs p, const int lat_n) {
+  __shared__ __attribute__((aligned(16))) float lds[ROLE_LDS_FLOATS];
+  post_bwd_role(p, blockIdx.x, lat_n, lds);
+}
 
 // K5b: dlat[scene] += sum over the segments of that scene (in segment order) of
 //   segpart[r] + reg_coef/n_norm * count_r * E/||E||.   One block per segment; the FIRST segment of a scene owns
@@ -798,7 +1134,9 @@ __global__ __launch_bounds__(256) void post_bwd_kernel(const PostBwdArgs p) { po
 // Block 0 also emits the regulariser loss  sum_r reg_coef/n_norm * count_r * ||E_r||  (train_deep_sdf.py:523-531).
 struct ScatterArgs {
   const float* segpart; const float* segnorm; const int64_t* seg_scene; const int64_t* seg_offset; int R; int L;
-  const float* table; float* dlat; float creg;
+  float* table; float* dlat; float creg;
+  const float* zr;             // non-null (segment-mode training steps): segment r's renormed latent row (seg_hoist_kernel); the owner
+                               // block of a scene writes it back into the table here -- the in-place embedding_renorm_ of the step
   // block 0: loss_out (+)= sum(part_loss[0..n_part)) * loss_scale + regulariser loss
   const float* part_loss; int n_part; float loss_scale; float* loss_out; int accumulate;
 };
@@ -828,17 +1166,19 @@ __device__ __forceinline__ void seg_scatter_body(const ScatterArgs& p, int r) {
   __syncthreads();
   if (dup) return;
   for (int c = tid; c < p.L; c += 256) {
+    const float z = p.zr != nullptr ? p.zr[(size_t)r * p.L + c] : p.table[(size_t)j * p.L + c];   // (duplicates of a scene hold the same row)
     float acc = 0.f;
     for (int q = r; q < p.R; ++q) {
       if (q != r && p.seg_scene[q] != j) continue;
       float v = p.segpart[(size_t)q * p.L + c];
       if (p.creg != 0.f) {
         const float nrm = p.segnorm[q];
-        if (nrm > 0.f) v += p.creg * (float)(p.seg_offset[q + 1] - p.seg_offset[q]) * p.table[(size_t)j * p.L + c] / nrm;
+        if (nrm > 0.f) v += p.creg * (float)(p.seg_offset[q + 1] - p.seg_offset[q]) * z / nrm;
       }
       acc += v;
     }
     p.dlat[(size_t)j * p.L + c] += acc;
+    if (p.zr != nullptr) p.table[(size_t)j * p.L + c] = z;
   }
 }
 
@@ -851,10 +1191,7 @@ __global__ __launch_bounds__(256) void finalize_scatter_kernel(const FinAll p, c
   // only after every finalize block has been dispatched, as the tail of the launch
   if ((int)blockIdx.x < sc.R) { seg_scatter_body(sc, (int)blockIdx.x); return; }
   __shared__ float red[4];
-  const int b = (int)blockIdx.x - sc.R;
-  int l = 0;
-  while (l + 1 < p.n && b >= p.row0[l + 1]) ++l;
-  finalize_row(p.f[l], b - p.row0[l], red);
+  finalize_block(p, (int)blockIdx.x - sc.R, red);
 }
 
 // ---------------------------------------------------------------------------------------------------
