@@ -546,6 +546,16 @@ bool fused_eligible(const DsdfNet* net) {
   return net->in_dim[net->n_layers - 1] <= FMAXW;
 }
 
+// Narrow nets (every layer input and hidden width <= 128): the fused kernels' n128 variants, two workgroups per CU (fused.hpp).
+// fp32 MFMA only; DSDF_NO_NARROW=1 switches it off (A/B).
+bool net_narrow(const DsdfNet* net) {
+  const char* e = getenv("DSDF_NO_NARROW");
+  if ((e && e[0] == '1') || !fused_enabled() || !fused_eligible(net) || net->gemm_split || net->fwd_bf16) return false;
+  for (int l = 0; l < net->n_layers; ++l)
+    if (net->in_dim[l] > 128 || (l < net->n_layers - 1 && net->out_dim[l] > 128)) return false;
+  return true;
+}
+
 // Rows per workgroup of the fused kernels: 64, or 32 (fused_*_h32_kernel: fp32 MFMA, merged forward + backward or forward alone) when
 // 32-row workgroups still fit one per CU -- i.e. when 64-row workgroups would leave at least half of the chip idle (BASELINE config 4:
 // one shape x 8000 points).  DSDF_FROWS=64 switches it off (A/B).
@@ -656,6 +666,8 @@ int run_fused_forward(const DsdfNet* net, const Plan& P, void* ws, const float* 
   const dim3 grid((unsigned)((n + P.frows - 1) / P.frows));
   if (P.frows == 32)                 // small batch: 32 points per workgroup (pick_frows: fp32 MFMA only)
     hipLaunchKernelGGL(fused_forward_h32_kernel, grid, dim3(256), 0, st, a);
+  else if (net_narrow(net))          // every layer <= 128 wide: two workgroups per CU
+    hipLaunchKernelGGL(fused_forward_n128_kernel, grid, dim3(256), 0, st, a);
   else if (net->fwd_bf16 && !store_act)   // config 5, inference form: 8 staggered waves, transposed accumulators (fused_bf16x8.hpp)
     hipLaunchKernelGGL(fused_forward_bf16x8_kernel, grid, dim3(F8_THREADS), 0, st, a);
   else if (net->fwd_bf16)            // with activation copies (module path; training goes out merged with the backward)
@@ -923,6 +935,7 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
       else if (net->fwd_bf16) hipLaunchKernelGGL(fused_fwd_bf16_bwd_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
       else if (net->gemm_split) hipLaunchKernelGGL(fused_fwd_bwd_split_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
       else if (P.frows == 32) hipLaunchKernelGGL(fused_fwd_bwd_h32_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
+      else if (net_narrow(net)) hipLaunchKernelGGL(fused_fwd_bwd_n128_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
       else hipLaunchKernelGGL(fused_fwd_bwd_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
       LAUNCH_OK("fused_fwd_bwd_kernel");
     } else {

@@ -87,7 +87,7 @@ struct FusedFwdArgs {
 
 // rows of x0 into slab columns [col0, col0 + W0).  All 16-byte loads of a pass are issued back-to-back BEFORE the
 // first LDS write: a load-use-load-use loop would pay the HBM latency dozens of times in a row.
-template <int ROWS = FROWS>
+template <int ROWS = FROWS, int LDSW = FLD>
 __device__ __forceinline__ void fused_load_x0(float* S, const float* x0, int ldx0, int W0, int row0, int N, int col0) {
   constexpr int XCH = 20;                   // float4 chunks per thread per pass
   const int cpr = (W0 + 3) >> 2;            // chunks per row (ldx0 is a multiple of 4: the tail chunk is in bounds)
@@ -108,7 +108,7 @@ __device__ __forceinline__ void fused_load_x0(float* S, const float* x0, int ldx
       const int ci = base + threadIdx.x + 256 * k;
       if (ci < total) {
         const int r = ci / cpr, c = ci - r * cpr;
-        float* d = S + r * FLD + col0 + 4 * c;
+        float* d = S + r * LDSW + col0 + 4 * c;
         const int rem = W0 - 4 * c;
         d[0] = v[k].x;
         if (rem > 1) d[1] = v[k].y;
@@ -130,8 +130,9 @@ constexpr int FLDH = 520;        // slab row stride in bf16 elements (bf16 forwa
 
 // HS: the slab holds bf16 (row stride FLDH) instead of fp32 (row stride FLD); the global activation copy stays fp32.
 // MT: m-tiles of 32 rows per workgroup (2 = the 64-row workgroup; 1 = the 32-row one of small batches, fused_*_h32_kernel).
-template <bool DROP, bool EVEN, bool HS = false, int MT = 2>
-__device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[MT][4], const float (&biasv)[4], float* S,
+// NT: n-tiles a wave can own (4; 1 in the narrow-net kernels, widths <= 128); LDSW: slab row stride in floats.
+template <bool DROP, bool EVEN, bool HS = false, int MT = 2, int NT = 4, int LDSW = FLD>
+__device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[MT][NT], const float (&biasv)[NT], float* S,
                                                    const FusedLayer& L, int w, int fr, int fh, int row0, int N,
                                                    uint32_t row_offset) {
   const int rows_here = min(32 * MT, N - row0);
@@ -142,11 +143,11 @@ __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[MT][4], c
   const bool has_out = L.out != nullptr;
   uint32_t mq[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
+  for (int ni = 0; ni < NT; ++ni) {
     const int col = 32 * (w + 4 * ni) + fr;
     const bool cok = col < L.out_dim;
     const uint32_t voff = cok ? (uint32_t)((4 * fh) * ldb + col * 4) : 0x7FFFFFFFu;
-    float* sp = S + (4 * fh) * FLD + col;
+    float* sp = S + (4 * fh) * LDSW + col;
     const float bv = biasv[ni];
     uint32_t mb[2] = {0u, 0u};   // this n-tile's keep bits for m = 0, 1
     uint32_t ck = 0, pm = 0;
@@ -178,8 +179,8 @@ __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[MT][4], c
             hp[rc * FLDH] = (__bf16)v0;
             hp[(rc + 1) * FLDH] = (__bf16)v1;
           } else {
-            sp[rc * FLD] = v0;
-            sp[(rc + 1) * FLD] = v1;
+            sp[rc * LDSW] = v0;
+            sp[(rc + 1) * LDSW] = v1;
           }
           if (has_out) {   // (inference keeps no copies: 128 dropped stores per lane and layer still cost their issue)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rsrc, voff, rc * ldb, FUSED_STORE_AUX);
@@ -218,13 +219,15 @@ __device__ __forceinline__ int fused_unit(int u, int rot, int nu) {
 }
 
 // The shared k-loop: acc[m][ni] += S[64 rows][K] * Bf[n-tiles of this wave][K]; NACT = existing n-tiles of this wave.
-struct FusedBSets { float4 b0[4][2], b1[4][2]; };   // weights of k-units 0 and 1 of the NEXT layer, requested before the epilogue
+template <int NT> struct FusedBSetsT { float4 b0[NT][2], b1[NT][2]; };   // weights of k-units 0 and 1 of the NEXT layer, requested before the epilogue
+typedef FusedBSetsT<4> FusedBSets;
 
-__device__ __forceinline__ void fused_prefetch_b(FusedBSets& B, const float* wf, int U, int w, int lane, int nact, int nu) {
+template <int NT>
+__device__ __forceinline__ void fused_prefetch_b(FusedBSetsT<NT>& B, const float* wf, int U, int w, int lane, int nact, int nu) {
   const int rot = fused_rot(nu);
   const int u0 = fused_unit(0, rot, nu), u1 = fused_unit(nu > 1 ? 1 : 0, rot, nu);
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
+  for (int ni = 0; ni < NT; ++ni) {
     if (ni < nact) {
       const float* q = wf + (size_t)(w + 4 * ni) * U * 512 + lane * 4;
       B.b0[ni][0] = *reinterpret_cast<const float4*>(q + 512 * u0);
@@ -277,9 +280,10 @@ __device__ __forceinline__ float4 fused_bload(const FusedBView& B, int ni, int u
 }
 #endif
 
-template <int NACT, int MT = 2>
-__device__ __forceinline__ void fused_kloop(f32x16 (&acc)[MT][4], const float* ap, const FusedBView& bv, int nu,
-                                            FusedBSets& PB) {
+template <int NACT, int MT = 2, int NT = 4, int LDSW = FLD>
+__device__ __forceinline__ void fused_kloop(f32x16 (&acc)[MT][NT], const float* ap, const FusedBView& bv, int nu,
+                                            FusedBSetsT<NT>& PB) {
+  static_assert(NACT <= NT, "n-tiles");
   // Three named register sets rotate over the k-units: the WEIGHTS of unit u+2 (global, fragment order) and the
   // ACTIVATIONS of unit u+1 (LDS slab) are requested before the 16 NACT MFMAs of unit u issue, so neither the L2
   // latency nor the LDS latency is exposed (the wave is alone on its SIMD: nothing else would hide them).
@@ -304,7 +308,7 @@ __device__ __forceinline__ void fused_kloop(f32x16 (&acc)[MT][4], const float* a
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) a[m + MT * hf] = *reinterpret_cast<const float4*>(ap + 32 * m * FLD + 16 * u + 4 * hf);
+      for (int m = 0; m < MT; ++m) a[m + MT * hf] = *reinterpret_cast<const float4*>(ap + 32 * m * LDSW + 16 * u + 4 * hf);
   };
   auto mma = [&](const float4 (&a)[2 * MT], const float4 (&b)[NACT][2]) {
 #pragma unroll
@@ -777,18 +781,18 @@ __device__ __forceinline__ void fused_kloop_split_asm4(f32x16 (&acc)[2][4], cons
 }
 
 // what a body needs from the k-loop, in either mode: the carried prefetch set, the prefetch, the loop
-template <bool SPLIT> struct KlSets { typedef FusedBSets type; };
-template <> struct KlSets<true> { typedef SplitBSet type; };
-template <bool SPLIT>
-__device__ __forceinline__ void kl_prefetch(typename KlSets<SPLIT>::type& PB, const float* wf, int wplane, const float* wf32, int U, int w, int lane,
+template <bool SPLIT, int NT = 4> struct KlSets { typedef FusedBSetsT<NT> type; };
+template <int NT> struct KlSets<true, NT> { typedef SplitBSet type; };
+template <bool SPLIT, int NT = 4>
+__device__ __forceinline__ void kl_prefetch(typename KlSets<SPLIT, NT>::type& PB, const float* wf, int wplane, const float* wf32, int U, int w, int lane,
                                             int nact, int nu) {
   if constexpr (SPLIT) split_prefetch_b(PB, wf, wplane, wf32, U, w, lane, nact, nu);
-  else fused_prefetch_b(PB, wf, U, w, lane, nact, nu);
+  else fused_prefetch_b<NT>(PB, wf, U, w, lane, nact, nu);
 }
-template <bool SPLIT, int MT = 2>
-__device__ __forceinline__ void fused_kloop_dispatch(f32x16 (&acc)[MT][4], const float* ap, const float* wf, int wplane, const float* wf32, int U,
-                                                     int w, int lane, int nu, int nact, typename KlSets<SPLIT>::type& PB) {
-  static_assert(!SPLIT || MT == 2, "the split k-loops exist for 64-row workgroups only");
+template <bool SPLIT, int MT = 2, int NT = 4, int LDSW = FLD>
+__device__ __forceinline__ void fused_kloop_dispatch(f32x16 (&acc)[MT][NT], const float* ap, const float* wf, int wplane, const float* wf32, int U,
+                                                     int w, int lane, int nu, int nact, typename KlSets<SPLIT, NT>::type& PB) {
+  static_assert(!SPLIT || (MT == 2 && NT == 4 && LDSW == FLD), "the split k-loops exist for the full-size workgroup only");
   if constexpr (SPLIT) {
     const SplitBView bv = split_bview(wf, wplane, wf32, U, w, lane);
     switch (nact) {
@@ -804,12 +808,17 @@ __device__ __forceinline__ void fused_kloop_dispatch(f32x16 (&acc)[MT][4], const
     }
   } else {
     const FusedBView bv = fused_bview(wf, U, w, lane);
-    switch (nact) {
-      case 4: fused_kloop<4, MT>(acc, ap, bv, nu, PB); break;
-      case 3: fused_kloop<3, MT>(acc, ap, bv, nu, PB); break;
-      case 2: fused_kloop<2, MT>(acc, ap, bv, nu, PB); break;
-      case 1: fused_kloop<1, MT>(acc, ap, bv, nu, PB); break;
-      default: break;
+    if constexpr (NT == 4) {
+      switch (nact) {
+        case 4: fused_kloop<4, MT, NT, LDSW>(acc, ap, bv, nu, PB); break;
+        case 3: fused_kloop<3, MT, NT, LDSW>(acc, ap, bv, nu, PB); break;
+        case 2: fused_kloop<2, MT, NT, LDSW>(acc, ap, bv, nu, PB); break;
+        case 1: fused_kloop<1, MT, NT, LDSW>(acc, ap, bv, nu, PB); break;
+        default: break;
+      }
+    } else {
+      static_assert(NT == 1, "n-tiles per wave: 4 or 1");
+      if (nact == 1) fused_kloop<1, MT, NT, LDSW>(acc, ap, bv, nu, PB);
     }
   }
 }
@@ -819,18 +828,18 @@ __device__ __forceinline__ int fused_nact(int ncols, int w) {   // how many of t
   return ntl > w ? min(4, (ntl - w + 3) >> 2) : 0;
 }
 
-template <int ROWS = FROWS>
+template <int ROWS = FROWS, int LDSW = FLD>
 __device__ __forceinline__ void fused_zero_pad(float* S, int nin) {   // columns [nin, roundup16(nin)) of every slab row
   const int zc = ((nin + 15) & ~15) - nin;
-  for (int i = threadIdx.x; i < ROWS * zc; i += 256) S[(i / zc) * FLD + nin + (i % zc)] = 0.f;
+  for (int i = threadIdx.x; i < ROWS * zc; i += 256) S[(i / zc) * LDSW + nin + (i % zc)] = 0.f;
 }
 
 // accumulators of a hoisted layer start at  U_s[col] + <xyz[row], W[col, xyz]>  (all operands staged in LDS)
-template <int MT = 2>
-__device__ __forceinline__ void fused_hoist_init(f32x16 (&acc)[MT][4], const float* hu, const float4* hwx, const float4* xs,
+template <int MT = 2, int NT = 4>
+__device__ __forceinline__ void fused_hoist_init(f32x16 (&acc)[MT][NT], const float* hu, const float4* hwx, const float4* xs,
                                                  int out_dim, int w, int fr, int fh) {
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {   // one n-tile at a time (few live registers); the xyz rows are re-read from LDS (broadcast)
+  for (int ni = 0; ni < NT; ++ni) {   // one n-tile at a time (few live registers); the xyz rows are re-read from LDS (broadcast)
     const int col = 32 * (w + 4 * ni) + fr;
     const bool ok = col < out_dim;
     const float ub = ok ? hu[col] : 0.f;
@@ -847,7 +856,7 @@ __device__ __forceinline__ void fused_hoist_init(f32x16 (&acc)[MT][4], const flo
 
 // S: the slab; xs: segment mode, xyz of the 64 points (zero padded); hu / hwx: segment mode, U_s of the hoisted layers and
 // their xyz weight columns.  On return in the training form (no y_out / u_out) the slab holds the last hidden activation.
-template <bool SPLIT = false, int MT = 2>
+template <bool SPLIT = false, int MT = 2, int NT = 4, int LDSW = FLD>
 __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float* S, float4* xs, float (*hu)[FMAXW],
                                                    float4 (*hwx)[FMAXW], int warm_bytes) {
   constexpr int ROWS = 32 * MT;      // points per workgroup
@@ -858,9 +867,9 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
   const uint32_t warm = warm_own_code(warm_bytes);
   if (warm == 0x9E3779B1u && p.N < 0) S[0] = 1.f;   // never true: keeps the loads
 
-  typename KlSets<SPLIT>::type PB;
+  typename KlSets<SPLIT, NT>::type PB;
   const int lfirst = (segm && p.n_hidden > 1) ? 1 : 0;   // first layer with an MFMA pass (segment mode: layer 0 has none)
-  kl_prefetch<SPLIT>(PB, p.ly[lfirst].wf, p.ly[lfirst].wplane, p.ly[lfirst].wf32, p.ly[lfirst].U, w, lane, fused_nact(p.ly[lfirst].out_dim, w), (p.ly[lfirst].in + 15) >> 4);
+  kl_prefetch<SPLIT, NT>(PB, p.ly[lfirst].wf, p.ly[lfirst].wplane, p.ly[lfirst].wf32, p.ly[lfirst].U, w, lane, fused_nact(p.ly[lfirst].out_dim, w), (p.ly[lfirst].in + 15) >> 4);
   if (segm) {
     if (tid < ROWS) {
       float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -890,8 +899,8 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
       }
     }
   } else {
-    fused_load_x0<ROWS>(S, p.x0, p.ldx0, p.W0, row0, p.N, 0);
-    fused_zero_pad<ROWS>(S, p.W0);
+    fused_load_x0<ROWS, LDSW>(S, p.x0, p.ldx0, p.W0, row0, p.N, 0);
+    fused_zero_pad<ROWS, LDSW>(S, p.W0);
   }
   __syncthreads();
 #ifdef DSDF_LAB
@@ -901,33 +910,33 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
   for (int l = 0; l < p.n_hidden; ++l) {
     const FusedLayer& L = p.ly[l];
     const int nu = (L.in + 15) >> 4;   // segment mode: 0 for layer 0, only the previous layer's columns for the skip layer
-    f32x16 acc[MT][4];
+    f32x16 acc[MT][NT];
     // epilogue operands are fetched BEFORE the k-loop: a load issued after the epilogue's global stores would have
     // to wait for them (vmcnt is in-order and counts stores)
-    float biasv[4];
+    float biasv[NT];
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
+    for (int ni = 0; ni < NT; ++ni) {
       const int col = 32 * (w + 4 * ni) + fr;
       biasv[ni] = col < L.out_dim ? L.bias[col] : 0.f;
     }
     int hidx = -1;
     if (segm) hidx = l == p.seg.h[0].layer ? 0 : (l == p.seg.h[1].layer ? 1 : -1);
     if (hidx >= 0) {
-      fused_hoist_init<MT>(acc, hu[hidx], hwx[hidx], xs, L.out_dim, w, fr, fh);
+      fused_hoist_init<MT, NT>(acc, hu[hidx], hwx[hidx], xs, L.out_dim, w, fr, fh);
     } else {
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+        for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[m][ni][r] = 0.f;
     }
-    const float* ap = S + fr * FLD + 8 * fh;
+    const float* ap = S + fr * LDSW + 8 * fh;
     if (nu > 0) {
-      fused_kloop_dispatch<SPLIT, MT>(acc, ap, L.wf, L.wplane, L.wf32, L.U, w, lane, nu, fused_nact(L.out_dim, w), PB);
+      fused_kloop_dispatch<SPLIT, MT, NT, LDSW>(acc, ap, L.wf, L.wplane, L.wf32, L.U, w, lane, nu, fused_nact(L.out_dim, w), PB);
       if (l + 1 < p.n_hidden) {   // next layer's first weights travel while this layer's epilogue runs
         const FusedLayer& Ln = p.ly[l + 1];
-        kl_prefetch<SPLIT>(PB, Ln.wf, Ln.wplane, Ln.wf32, Ln.U, w, lane, fused_nact(Ln.out_dim, w), (Ln.in + 15) >> 4);
+        kl_prefetch<SPLIT, NT>(PB, Ln.wf, Ln.wplane, Ln.wf32, Ln.U, w, lane, fused_nact(Ln.out_dim, w), (Ln.in + 15) >> 4);
       }
     }
 #ifdef DSDF_LAB
@@ -937,15 +946,15 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
 #ifdef DSDF_LAB
     if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 2 + 3 * l] = __builtin_amdgcn_s_memtime();
 #endif
-    if (L.x0_col >= 0) fused_load_x0<ROWS>(S, p.x0, p.ldx0, p.W0, row0, p.N, L.x0_col);  // loads first, stores after
+    if (L.x0_col >= 0) fused_load_x0<ROWS, LDSW>(S, p.x0, p.ldx0, p.W0, row0, p.N, L.x0_col);  // loads first, stores after
     {
       const bool drop = L.drop_thr != 0u;
       const bool even = ((p.row_offset + (uint32_t)row0) & 1u) == 0u;   // 4*fh and crow(2rp) are even
-      if (!drop) fused_fwd_epilogue<false, true, false, MT>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
-      else if (even) fused_fwd_epilogue<true, true, false, MT>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
-      else fused_fwd_epilogue<true, false, false, MT>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+      if (!drop) fused_fwd_epilogue<false, true, false, MT, NT, LDSW>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+      else if (even) fused_fwd_epilogue<true, true, false, MT, NT, LDSW>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
+      else fused_fwd_epilogue<true, false, false, MT, NT, LDSW>(acc, biasv, S, L, w, fr, fh, row0, p.N, p.row_offset);
     }
-    fused_zero_pad<ROWS>(S, L.x0_col >= 0 ? L.x0_col + p.W0 : L.out_dim);
+    fused_zero_pad<ROWS, LDSW>(S, L.x0_col >= 0 ? L.x0_col + p.W0 : L.out_dim);
     __syncthreads();
 #ifdef DSDF_LAB
     if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 3 + 3 * l] = __builtin_amdgcn_s_memtime();
@@ -968,7 +977,7 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
     for (int cc = 0; cc < 2; ++cc) {
       const int c = 4 * lane + 256 * cc;
       if (c < p.in_last) {
-        const float4 a = *reinterpret_cast<const float4*>(S + row * FLD + c);
+        const float4 a = *reinterpret_cast<const float4*>(S + row * LDSW + c);
         dot += a.x * qv[cc].x + a.y * qv[cc].y + a.z * qv[cc].z + a.w * qv[cc].w;
       }
     }
@@ -997,6 +1006,19 @@ __global__ __launch_bounds__(256, 1) void fused_forward_h32_kernel(const FusedFw
   __shared__ float hu[FHOIST][FMAXW];
   __shared__ float4 hwx[FHOIST][FMAXW];
   fused_forward_body<false, 1>(p, S, xs, hu, hwx, 80 * 1024);
+}
+// Narrow nets (every layer at most 128 wide: the reference's shipped 6 x 128, 4 x 64 and 4 x 32 specs): one n-tile per wave at most
+// (NT = 1: 32 accumulator registers instead of 128) and a 132-float slab row (34 KB instead of 132 KB), so that TWO workgroups fit a
+// CU.  These nets are not MFMA bound: a 32-wide layer is 2 k cycles of MFMAs inside ~12 k cycles of dependent latencies (weights
+// from L2, the epilogue's store acknowledgements in front of the next layer's loads, two barriers); a second resident workgroup
+// overlaps them.
+constexpr int FLDN = 132;
+__global__ __launch_bounds__(256, 2) void fused_forward_n128_kernel(const FusedFwdArgs p) {
+  __shared__ __attribute__((aligned(16))) float S[FROWS * FLDN];
+  __shared__ float4 xs[FROWS];
+  __shared__ float hu[FHOIST][FMAXW];
+  __shared__ float4 hwx[FHOIST][FMAXW];
+  fused_forward_body<false, 2, 1, FLDN>(p, S, xs, hu, hwx, 48 * 1024);
 }
 // the same with the hidden GEMMs in split mode (fused_kloop_split); a kernel of its own so that the fp32 kernel keeps its registers
 __global__ __launch_bounds__(256, 1) void fused_forward_split_kernel(const FusedFwdArgs p) {
@@ -1383,8 +1405,8 @@ struct FusedBwdArgs {
   FusedBwdLayer ly[DSDF_MAX_LAYERS];
 };
 
-template <bool XS, int MT = 2>
-__device__ __forceinline__ void fused_bwd_epilogue(const f32x16 (&acc)[MT][4], float* S, const FusedBwdLayer& L, int w, int fr,
+template <bool XS, int MT = 2, int NT = 4, int LDSW = FLD>
+__device__ __forceinline__ void fused_bwd_epilogue(const f32x16 (&acc)[MT][NT], float* S, const FusedBwdLayer& L, int w, int fr,
                                                    int fh, int row0, int N, const uint4 mq, const float4* xs) {
   const int rows_here = min(32 * MT, N - row0);
   __amdgpu_buffer_rsrc_t rdp = __builtin_amdgcn_make_buffer_rsrc(
@@ -1396,13 +1418,13 @@ __device__ __forceinline__ void fused_bwd_epilogue(const f32x16 (&acc)[MT][4], f
   const int ldb = L.ld_dp * 4, ldzb = L.ldz * 4;
   const uint32_t mw[4] = {mq.x, mq.y, mq.z, mq.w};
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
+  for (int ni = 0; ni < NT; ++ni) {
     const int col = 32 * (w + 4 * ni) + fr;
     float cs = 0.f;
     float4 cx = make_float4(0.f, 0.f, 0.f, 0.f);
     if (col < L.mask_cols) {
       const uint32_t voff = (uint32_t)((4 * fh) * ldb + col * 4);
-      float* sp = S + (4 * fh) * FLD + col;
+      float* sp = S + (4 * fh) * LDSW + col;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const uint32_t bits = mw[2 * m + (ni >> 1)] >> (16 * (ni & 1));
@@ -1410,7 +1432,7 @@ __device__ __forceinline__ void fused_bwd_epilogue(const f32x16 (&acc)[MT][4], f
         for (int r = 0; r < 16; ++r) {
           const int rc = 32 * m + crow(r);
           const float v = ((bits >> r) & 1u) ? acc[m][ni][r] * L.mask_scale : 0.f;
-          sp[rc * FLD] = v;
+          sp[rc * LDSW] = v;
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rdp, voff, rc * ldb, FUSED_STORE_AUX);
           cs += v;
           if constexpr (XS) {
@@ -1444,7 +1466,7 @@ __device__ __forceinline__ void fused_bwd_epilogue(const f32x16 (&acc)[MT][4], f
 
 // slab_ready: the slab already holds the last hidden activation (the merged forward+backward kernel) -- no reload, no code
 // warm-up; hred / hsc: scratch of the head's cross-wave reductions.
-template <bool SPLIT = false, int MT = 2>
+template <bool SPLIT = false, int MT = 2, int NT = 4, int LDSW = FLD>
 __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float* S, float4* xs, float (*hred)[2 * FMAXW],
                                                     float (*hsc)[2], bool slab_ready) {
   constexpr int ROWS = 32 * MT;      // points per workgroup
@@ -1468,11 +1490,11 @@ __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float
   }
 
   if (p.head.mode == HEAD_DP_GIVEN) {
-    fused_load_x0<ROWS>(S, p.dp_in, p.ld_in, p.w_in, row0, p.N, 0);
-    fused_zero_pad<ROWS>(S, p.w_in);
+    fused_load_x0<ROWS, LDSW>(S, p.dp_in, p.ld_in, p.w_in, row0, p.N, 0);
+    fused_zero_pad<ROWS, LDSW>(S, p.w_in);
   } else {
     const FusedBwdHead& H = p.head;
-    if (!slab_ready) fused_load_x0<ROWS>(S, H.a_last, H.ld_a, H.in_last, row0, p.N, 0);
+    if (!slab_ready) fused_load_x0<ROWS, LDSW>(S, H.a_last, H.ld_a, H.in_last, row0, p.N, 0);
     float4 qv[2], dwa[2], csa[2];
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
@@ -1490,7 +1512,7 @@ __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc) {
         const int c = 4 * lane + 256 * cc;
-        av[cc] = c < H.in_last ? *reinterpret_cast<const float4*>(S + row * FLD + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        av[cc] = c < H.in_last ? *reinterpret_cast<const float4*>(S + row * LDSW + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         dot += av[cc].x * qv[cc].x + av[cc].y * qv[cc].y + av[cc].z * qv[cc].z + av[cc].w * qv[cc].w;
       }
       const bool live = grow < p.N;
@@ -1525,7 +1547,7 @@ __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float
           d.y = av[cc].y > 0.f ? ds * qv[cc].y : 0.f;
           d.z = av[cc].z > 0.f ? ds * qv[cc].z : 0.f;
           d.w = av[cc].w > 0.f ? ds * qv[cc].w : 0.f;
-          *reinterpret_cast<float4*>(S + row * FLD + c) = d;
+          *reinterpret_cast<float4*>(S + row * LDSW + c) = d;
           if (live) *reinterpret_cast<float4*>(H.dp_out + (size_t)grow * H.ld_dp + c) = d;
           dwa[cc].x += du * av[cc].x; dwa[cc].y += du * av[cc].y; dwa[cc].z += du * av[cc].z; dwa[cc].w += du * av[cc].w;
           csa[cc].x += d.x; csa[cc].y += d.y; csa[cc].z += d.z; csa[cc].w += d.w;
@@ -1548,34 +1570,34 @@ __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float
       H.part_loss[blockIdx.x] = (hsc[0][0] + hsc[1][0]) + (hsc[2][0] + hsc[3][0]);
       H.part_db[blockIdx.x] = (hsc[0][1] + hsc[1][1]) + (hsc[2][1] + hsc[3][1]);
     }
-    fused_zero_pad<ROWS>(S, H.in_last);
+    fused_zero_pad<ROWS, LDSW>(S, H.in_last);
   }
-  typename KlSets<SPLIT>::type PB;
-  if (p.n_layers > 0) kl_prefetch<SPLIT>(PB, p.ly[0].wtf, p.ly[0].wplane, p.ly[0].wtf32, p.ly[0].U, w, lane, fused_nact(p.ly[0].ncols, w), (p.ly[0].K + 15) >> 4);
+  typename KlSets<SPLIT, NT>::type PB;
+  if (p.n_layers > 0) kl_prefetch<SPLIT, NT>(PB, p.ly[0].wtf, p.ly[0].wplane, p.ly[0].wtf32, p.ly[0].U, w, lane, fused_nact(p.ly[0].ncols, w), (p.ly[0].K + 15) >> 4);
   __syncthreads();
 
   for (int i = 0; i < p.n_layers; ++i) {
     const FusedBwdLayer& L = p.ly[i];
     const int nu = (L.K + 15) >> 4;
-    f32x16 acc[MT][4];
+    f32x16 acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
+      for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][ni][r] = 0.f;
-    const float* ap = S + fr * FLD + 8 * fh;
+    const float* ap = S + fr * LDSW + 8 * fh;
     uint4 mq = make_uint4(0u, 0u, 0u, 0u);
     if (L.maskbits != nullptr) mq = *reinterpret_cast<const uint4*>(L.maskbits + ((size_t)blockIdx.x * 256 + tid) * 4);
-    fused_kloop_dispatch<SPLIT, MT>(acc, ap, L.wtf, L.wplane, L.wtf32, L.U, w, lane, nu, fused_nact(L.ncols, w), PB);
+    fused_kloop_dispatch<SPLIT, MT, NT, LDSW>(acc, ap, L.wtf, L.wplane, L.wtf32, L.U, w, lane, nu, fused_nact(L.ncols, w), PB);
     if (i + 1 < p.n_layers) {
       const FusedBwdLayer& Ln = p.ly[i + 1];
-      kl_prefetch<SPLIT>(PB, Ln.wtf, Ln.wplane, Ln.wtf32, Ln.U, w, lane, fused_nact(Ln.ncols, w), (Ln.K + 15) >> 4);
+      kl_prefetch<SPLIT, NT>(PB, Ln.wtf, Ln.wplane, Ln.wtf32, Ln.U, w, lane, fused_nact(Ln.ncols, w), (Ln.K + 15) >> 4);
     }
     __syncthreads();
-    if (L.xsum != nullptr) fused_bwd_epilogue<true, MT>(acc, S, L, w, fr, fh, row0, p.N, mq, xs);
-    else fused_bwd_epilogue<false, MT>(acc, S, L, w, fr, fh, row0, p.N, mq, xs);
-    fused_zero_pad<ROWS>(S, L.mask_cols);
+    if (L.xsum != nullptr) fused_bwd_epilogue<true, MT, NT, LDSW>(acc, S, L, w, fr, fh, row0, p.N, mq, xs);
+    else fused_bwd_epilogue<false, MT, NT, LDSW>(acc, S, L, w, fr, fh, row0, p.N, mq, xs);
+    fused_zero_pad<ROWS, LDSW>(S, L.mask_cols);
     __syncthreads();
   }
 }
@@ -1622,6 +1644,19 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_bwd_h32_kernel(const FusedFw
   fused_forward_body<false, 1>(f, S, xs, hu, hwx, 150 * 1024);
   __syncthreads();
   fused_backward_body<false, 1>(b, S, xs, hred, hsc, true);
+}
+// ... for narrow nets (see fused_forward_n128_kernel): two workgroups per CU
+__global__ __launch_bounds__(256, 2) void fused_fwd_bwd_n128_kernel(const FusedFwdArgs f, const FusedBwdArgs b) {
+  __shared__ __attribute__((aligned(16))) float S[FROWS * FLDN];
+  __shared__ float4 xs[FROWS];
+  __shared__ float4 scratch[FHOIST * FMAXW + FHOIST * FMAXW / 4];
+  float (*hu)[FMAXW] = reinterpret_cast<float (*)[FMAXW]>(scratch);
+  float4 (*hwx)[FMAXW] = reinterpret_cast<float4 (*)[FMAXW]>(scratch + FHOIST * FMAXW / 4);
+  float (*hred)[2 * FMAXW] = reinterpret_cast<float (*)[2 * FMAXW]>(scratch);
+  float (*hsc)[2] = reinterpret_cast<float (*)[2]>(scratch + 4 * 2 * FMAXW / 4);
+  fused_forward_body<false, 2, 1, FLDN>(f, S, xs, hu, hwx, 64 * 1024);
+  __syncthreads();
+  fused_backward_body<false, 2, 1, FLDN>(b, S, xs, hred, hsc, true);
 }
 __global__ __launch_bounds__(256, 1) void fused_fwd_bwd_split_kernel(const FusedFwdArgs f, const FusedBwdArgs b) {
   __shared__ __attribute__((aligned(16))) float S[FROWS * FLD];

@@ -508,8 +508,9 @@ SEG_SHAPES = {
 def test_segment_mode_odd_shapes_vs_oracle(name, monkeypatch):
     """Two optimiser steps in segment mode (every scene a whole number of workgroups) against the float64 oracle, and the SAME
     batch through the general (ragged) path: both must meet the gradient tolerance.  Batches this small run on 32-point workgroups
-    (fused_fwd_bwd_h32_kernel: at most 32 x #CUs points); DSDF_FROWS=64 sends the same batches through the 64-point workgroups
-    of the full-size path, so every shape is checked on both."""
+    (fused_fwd_bwd_h32_kernel: at most 32 x #CUs points); DSDF_FROWS=64 sends the same batches through 64-point workgroups -- the
+    narrow-net kernels for nets of at most 128 columns, and with DSDF_NO_NARROW=1 the full-size kernels -- so every shape is
+    checked on all three kernel families."""
     c = SEG_SHAPES[name]
     L, B, S, G = c["L"], c["B"], c["S"], c["net"]["geom_dimension"]
     net = orc.make_net(L, **c["net"])
@@ -518,16 +519,22 @@ def test_segment_mode_odd_shapes_vs_oracle(name, monkeypatch):
     lat0 = torch.randn(B, L, generator=torch.Generator().manual_seed(32)) / math.sqrt(L)
     lat0[-1] *= 1.7 / lat0[-1].norm()                    # one row above the max-norm bound
     st64 = orc.TrainState.create({k: v.double() for k, v in params.items()}, lat0.double())
-    seg, rag, seg64, rag64 = (HipTrainer(spec, params, lat0) for _ in range(4))
+    seg, rag, seg64, rag64, segfull, ragfull = (HipTrainer(spec, params, lat0) for _ in range(6))
     for step in range(2):
         idx, xyz, gt = _safe_batch(net, st64, B, S, 500 + step, 0.1, 1.0, 77, G=G)
         r64 = orc.train_step(net, st64, idx, xyz.double(), gt.double(), delta=0.1, code_bound=1.0, epoch=130, seed=77,
                              batch_split=c["split"])
-        for tr, kw, rows in ((seg, {}, None), (rag, dict(force_ragged=True), None), (seg64, {}, "64"), (rag64, dict(force_ragged=True), "64")):
-            if rows is None:
-                monkeypatch.delenv("DSDF_FROWS", raising=False)
-            else:
-                monkeypatch.setenv("DSDF_FROWS", rows)
+        # rows None: 32-point workgroups (these batches are small); "64": 64-point workgroups -- for nets of at most 128 columns the
+        # narrow-net kernels (fused_fwd_bwd_n128_kernel, two workgroups per CU); "64 full": ... and those switched off, i.e. the
+        # full-size kernel the headline runs on
+        for tr, kw, rows in ((seg, {}, None), (rag, dict(force_ragged=True), None), (seg64, {}, "64"), (rag64, dict(force_ragged=True), "64"),
+                             (segfull, {}, "64 full"), (ragfull, dict(force_ragged=True), "64 full")):
+            monkeypatch.delenv("DSDF_FROWS", raising=False)
+            monkeypatch.delenv("DSDF_NO_NARROW", raising=False)
+            if rows is not None:
+                monkeypatch.setenv("DSDF_FROWS", "64")
+                if rows.endswith("full"):
+                    monkeypatch.setenv("DSDF_NO_NARROW", "1")
             rh = tr.step(idx, xyz, gt, delta=0.1, code_bound=1.0, code_reg=True, lam=1e-4, epoch=130, lr=(5e-4, 1e-3), seed=77,
                          batch_split=c["split"], **kw)
             assert abs(rh["loss"] - r64["loss"]) <= 1e-5 * abs(r64["loss"]), (step, kw, rows)
@@ -540,6 +547,7 @@ def test_segment_mode_odd_shapes_vs_oracle(name, monkeypatch):
                 assert rel_err(P[k], st64.params[k]) <= ptol, (step, k, kw, rows)
             assert rel_err(tr.lat.cpu(), st64.latents) <= ptol, (step, kw, rows)
     monkeypatch.delenv("DSDF_FROWS", raising=False)
+    monkeypatch.delenv("DSDF_NO_NARROW", raising=False)
 
 
 _CONFIG5 = {}
