@@ -6,7 +6,7 @@ import os
 from .build import LIB
 
 MAX_LAYERS = 16
-ABI_VERSION = 14
+ABI_VERSION = 15
 MAX_BUCKETS = 8
 
 
@@ -80,6 +80,7 @@ PROTOTYPES = {
     "dsdf_train_step": [_NET, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, C.POINTER(DsdfBatch), C.POINTER(DsdfLossCfg),
                         C.POINTER(DsdfAdamCfg), _P, _P, _P, _SZ, _P],
     "dsdf_adam_latent_only": [_P, _P, _P, _P, _I64, C.POINTER(DsdfAdamCfg), _P],
+    "dsdf_adam_latent_sched": [_P, _P, _P, _P, _I64, _P, _I64, _P, _F, _F, _F, _F, _P],
     "dsdf_profile_enable": [_I32],
     "dsdf_profile_read": [C.POINTER(DsdfProfile)],
     "dsdf_gemm_nt": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P],
@@ -88,6 +89,7 @@ PROTOTYPES = {
     "dsdf_decode_latent": [_NET, _P, _P, _P, _P, _I64, _P, _P, _SZ, _P],
     "dsdf_decode_latent_supported": [_NET],
     "dsdf_sample_batch": [_P, C.c_int32, _P, _P, _P, _P, _P, _I64, _I64, C.c_uint64, _P, _P, _P],
+    "dsdf_sample_batch_seq": [_P, C.c_int32, _P, _P, _P, _P, _P, _I64, _I64, C.c_uint64, C.c_uint64, _P, _P, _P, _P],
 }
 
 _lib = None

@@ -1699,9 +1699,24 @@ int dsdf_adam_latent_only(float* latent, const float* dlat, float* exp_avg, floa
   return adam_launch(latent, dlat, exp_avg, exp_avg_sq, n, cfg->lr_latent, cfg, nullptr, (hipStream_t)stream);
 }
 
-int dsdf_sample_batch(const float* data, int32_t geom_dim, const int64_t* pos_start, const int64_t* n_pos,
-                      const int64_t* neg_start, const int64_t* n_neg, const int64_t* scene_ids, int64_t n_batch_scenes,
-                      int64_t subsample, uint64_t key, float* xyz_out, float* sdf_out, void* stream) {
+int dsdf_adam_latent_sched(float* latent, const float* dlat, float* exp_avg, float* exp_avg_sq, int64_t n, const float* sched,
+                           int64_t n_steps, int64_t* step_counter, float beta1, float beta2, float eps, float l2_coef, void* stream) {
+  if (!latent || !dlat || !exp_avg || !exp_avg_sq || !sched || !step_counter || n <= 0 || n_steps <= 0)
+    return fail(DSDF_E_INVALID, "bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adam_sched_kernel, dim3(blocks), dim3(256), 0, st, latent, dlat, exp_avg, exp_avg_sq, (long long)n, sched,
+                     (long long)n_steps, (const long long*)step_counter, 1.0f - beta1, beta2, 1.0f - beta2, eps, l2_coef);
+  LAUNCH_OK("adam_sched_kernel");
+  hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(1), 0, st, (long long*)step_counter);
+  LAUNCH_OK("counter_inc_kernel");
+  return 0;
+}
+
+static int sample_launch(const float* data, int32_t geom_dim, const int64_t* pos_start, const int64_t* n_pos, const int64_t* neg_start,
+                         const int64_t* n_neg, const int64_t* scene_ids, int64_t n_batch_scenes, int64_t subsample, uint64_t key,
+                         uint64_t key_step, const int64_t* counter, float* xyz_out, float* sdf_out, void* stream) {
   if (!data || !pos_start || !n_pos || !neg_start || !n_neg || !scene_ids || !xyz_out || !sdf_out)
     return fail(DSDF_E_INVALID, "NULL argument");
   if (geom_dim < 1 || geom_dim > 16) return fail(DSDF_E_INVALID, "geom_dim %d out of range", geom_dim);
@@ -1712,10 +1727,27 @@ int dsdf_sample_batch(const float* data, int32_t geom_dim, const int64_t* pos_st
   a.data = data; a.row_floats = geom_dim + 1; a.G = geom_dim;
   a.pos_start = pos_start; a.n_pos = n_pos; a.neg_start = neg_start; a.n_neg = n_neg;
   a.scene_ids = scene_ids; a.B = (int)n_batch_scenes; a.S = (int)S; a.key = key; a.xyz = xyz_out; a.sdf = sdf_out;
+  a.counter = (const long long*)counter; a.key_step = key_step;
   const long long tot = n_batch_scenes * S;
   hipLaunchKernelGGL(sample_batch_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   LAUNCH_OK("sample_batch_kernel");
   return 0;
+}
+
+int dsdf_sample_batch(const float* data, int32_t geom_dim, const int64_t* pos_start, const int64_t* n_pos,
+                      const int64_t* neg_start, const int64_t* n_neg, const int64_t* scene_ids, int64_t n_batch_scenes,
+                      int64_t subsample, uint64_t key, float* xyz_out, float* sdf_out, void* stream) {
+  return sample_launch(data, geom_dim, pos_start, n_pos, neg_start, n_neg, scene_ids, n_batch_scenes, subsample, key, 0, nullptr, xyz_out,
+                       sdf_out, stream);
+}
+
+int dsdf_sample_batch_seq(const float* data, int32_t geom_dim, const int64_t* pos_start, const int64_t* n_pos,
+                          const int64_t* neg_start, const int64_t* n_neg, const int64_t* scene_ids, int64_t n_batch_scenes,
+                          int64_t subsample, uint64_t key0, uint64_t key_step, const int64_t* counter, float* xyz_out, float* sdf_out,
+                          void* stream) {
+  if (!counter) return fail(DSDF_E_INVALID, "counter is NULL");
+  return sample_launch(data, geom_dim, pos_start, n_pos, neg_start, n_neg, scene_ids, n_batch_scenes, subsample, key0, key_step, counter,
+                       xyz_out, sdf_out, stream);
 }
 
 int dsdf_profile_enable(int32_t on) {

@@ -1211,6 +1211,25 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// K7c: the latent-only Adam of a graph-captured loop (dsdf_adam_latent_sched): the step's scalars come from a device schedule indexed
+// by a device counter, the code regulariser's gradient l2 * z is added on the way.  adam_kernel's math otherwise.
+__global__ __launch_bounds__(256) void adam_sched_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, long long n, const float* __restrict__ sched,
+                                                         long long n_steps, const long long* __restrict__ counter, float one_minus_b1,
+                                                         float b2, float one_minus_b2, float eps, float l2) {
+  long long it = *counter;
+  if (it >= n_steps) it = n_steps - 1;
+  const float step_size = sched[2 * it], bc2_sqrt = sched[2 * it + 1];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float gi = fmaf(l2, p[i], g[i]);
+    const float mi = fmaf(one_minus_b1, gi - m[i], m[i]);
+    const float vi = b2 * v[i] + one_minus_b2 * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] = p[i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+  }
+}
+__global__ void counter_inc_kernel(long long* counter) { *counter += 1; }
+
 // K7b: Adam on the whole decoder arena, one wave per (layer, output row) -- bias, g and the v row -- which also yields
 // the row's new weight-norm scale g / ||v|| in the same pass (same summation order as wn_scale_kernel).
 struct AdamRowsLayer { long long v_off, g_off, b_off; int out, in, row0; };   // g_off < 0: plain layer

@@ -36,6 +36,7 @@ struct SampleArgs {
   const int64_t* pos_start; const int64_t* n_pos; const int64_t* neg_start; const int64_t* n_neg;   // per scene of the cache
   const int64_t* scene_ids; int B; int S;              // S = 2 * (subsample / 2) rows per scene
   uint64_t key;
+  const long long* counter; uint64_t key_step;         // optional (graph-captured loops): the draw key is key + *counter * key_step
   float* xyz; float* sdf;                              // [B*S][G], [B*S]
 };
 __global__ __launch_bounds__(256) void sample_batch_kernel(const SampleArgs p) {
@@ -48,9 +49,10 @@ __global__ __launch_bounds__(256) void sample_batch_kernel(const SampleArgs p) {
   int cp = half, cn = half;                            // deep_sdf/data.py:83-91
   if (np < half) { cp = (int)np; cn = p.S - cp; }
   else if (nn < half) { cn = (int)nn; cp = p.S - cn; }
+  const uint64_t key = p.counter != nullptr ? p.key + (uint64_t)*p.counter * p.key_step : p.key;
   int64_t row;
-  if (j < cp) row = p.pos_start[sc] + sample_perm((uint32_t)j, (uint32_t)np, sample_key(p.key, (uint32_t)sc, 0u));
-  else row = p.neg_start[sc] + sample_perm((uint32_t)(j - cp), (uint32_t)nn, sample_key(p.key, (uint32_t)sc, 1u));
+  if (j < cp) row = p.pos_start[sc] + sample_perm((uint32_t)j, (uint32_t)np, sample_key(key, (uint32_t)sc, 0u));
+  else row = p.neg_start[sc] + sample_perm((uint32_t)(j - cp), (uint32_t)nn, sample_key(key, (uint32_t)sc, 1u));
   const float* src = p.data + (size_t)row * p.row_floats;
   for (int c = 0; c < p.G; ++c) p.xyz[(size_t)t * p.G + c] = src[c];
   p.sdf[t] = src[p.G];

@@ -105,7 +105,40 @@ class DeviceSampleCache:
         """64-bit key of the next draw: the generator's seed (host value, no device sync) mixed with a draw counter."""
         seed = generator.initial_seed() if generator is not None else 0
         self._draws += 1
-        return ((seed * 0x9E3779B97F4A7C15) + self._draws * 0xD1B54A32D192ED03) & ((1 << 64) - 1)
+        return ((seed * self.KEY_SEED_MUL) + self._draws * self.KEY_DRAW_MUL) & ((1 << 64) - 1)
+
+    KEY_SEED_MUL, KEY_DRAW_MUL = 0x9E3779B97F4A7C15, 0xD1B54A32D192ED03
+
+    def _check_ids(self, scene_ids, S):
+        for k in scene_ids.tolist():
+            if not 0 <= k < len(self.n_pos):
+                raise IndexError(f"scene {k} is not in the cache")
+            if self.n_pos[k] + self.n_neg[k] < S:
+                raise ValueError(f"scene {k} has {self.n_pos[k] + self.n_neg[k]} samples, fewer than the {S} requested")
+
+    def sample_sequence(self, scene_ids, subsample, n_draws, counter, xyz_out, sdf_out, generator=None):
+        """The draws of a graph-captured loop: returns launch(), which enqueues ONE draw whose key is that of draw number `*counter`
+        (a device int64 the loop advances) of the next `n_draws` draws of this cache -- the keys, and therefore the batches, that
+        n_draws calls of sample() with the same generator would have produced.  xyz_out [B*S', G] / sdf_out [B*S'] are
+        overwritten by every launch (dsdf_sample_batch_seq)."""
+        if self.device.type != "cuda":
+            raise RuntimeError("DeviceSampleCache.sample_sequence runs on the GPU; there is no CPU path")
+        from . import _lib
+        from .engine import _ptr, _stream
+        scene_ids = torch.as_tensor(scene_ids, dtype=torch.int64)
+        S = 2 * int(subsample / 2)
+        self._check_ids(scene_ids, S)
+        B = scene_ids.numel()
+        sid = scene_ids.to(self.device)
+        seed = generator.initial_seed() if generator is not None else 0
+        key0 = (seed * self.KEY_SEED_MUL + (self._draws + 1) * self.KEY_DRAW_MUL) & ((1 << 64) - 1)
+        self._draws += int(n_draws)
+
+        def launch():
+            _lib.check(_lib.lib().dsdf_sample_batch_seq(_ptr(self.data), self.G, _ptr(self.pos_start_d), _ptr(self.n_pos_d),
+                                                        _ptr(self.neg_start_d), _ptr(self.n_neg_d), _ptr(sid), B, int(subsample), key0,
+                                                        self.KEY_DRAW_MUL, _ptr(counter), _ptr(xyz_out), _ptr(sdf_out), _stream()))
+        return launch
 
     def sample(self, scene_ids, subsample, generator=None, key=None, scene_ids_device=None):
         """scene_ids: [B] integer tensor (CPU preferred: its values are checked on the host) -> (xyz [B*S', G], sdf [B*S']).
@@ -117,11 +150,7 @@ class DeviceSampleCache:
         from .engine import _ptr, _stream
         scene_ids = torch.as_tensor(scene_ids, dtype=torch.int64)
         S = 2 * int(subsample / 2)
-        for k in scene_ids.tolist():
-            if not 0 <= k < len(self.n_pos):
-                raise IndexError(f"scene {k} is not in the cache")
-            if self.n_pos[k] + self.n_neg[k] < S:
-                raise ValueError(f"scene {k} has {self.n_pos[k] + self.n_neg[k]} samples, fewer than the {S} requested")
+        self._check_ids(scene_ids, S)
         B = scene_ids.numel()
         sid = scene_ids.to(self.device) if scene_ids_device is None else scene_ids_device
         xyz = torch.empty(B * S, self.G, dtype=torch.float32, device=self.device)

@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define DSDF_MAX_LAYERS 16
-#define DSDF_ABI_VERSION 14
+#define DSDF_ABI_VERSION 15
 #define DSDF_MAX_BUCKETS 8
 
 enum {
@@ -226,6 +226,15 @@ int dsdf_train_step(const DsdfNet* net, float* packed, float* params, float* gra
 int dsdf_adam_latent_only(float* latent, const float* dlat, float* exp_avg, float* exp_avg_sq, int64_t n,
                           const DsdfAdamCfg* cfg, void* stream);
 
+/* The same update for a loop that is CAPTURED INTO A HIP GRAPH and replayed (deepsdf_amd/reconstruct.py: the 800 iterations of a
+ * reconstruction are one captured iteration replayed, no host work per iteration): everything that changes from step to step comes
+ * from DEVICE memory.  sched [n_steps][2] = { lr_t / (1 - beta1^t), sqrt(1 - beta2^t) } for t = 1 .. n_steps (computed by the caller
+ * in double, as dsdf_adam_latent_only does on the host), indexed by the device counter *step_counter (0-based; entries past the end
+ * reuse the last one); the call increments the counter after the update (a second, one-thread launch).  The gradient it applies is
+ * dlat + l2_coef * latent (the code regulariser l2reg * mean(z^2) of the reconstruction loss; 0: none). */
+int dsdf_adam_latent_sched(float* latent, const float* dlat, float* exp_avg, float* exp_avg_sq, int64_t n, const float* sched,
+                           int64_t n_steps, int64_t* step_counter, float beta1, float beta2, float eps, float l2_coef, void* stream);
+
 /* ---- diagnostics: per-kernel-class device time from HIP events recorded on the caller's stream around every
  * launch of that class (bench.py's roofline object).  Off by default; thread-local; read synchronises. */
 #define DSDF_PROF_CLASSES 8
@@ -255,6 +264,14 @@ int dsdf_profile_read(DsdfProfile* out);
 int dsdf_sample_batch(const float* data, int32_t geom_dim, const int64_t* pos_start, const int64_t* n_pos,
                       const int64_t* neg_start, const int64_t* n_neg, const int64_t* scene_ids, int64_t n_batch_scenes,
                       int64_t subsample, uint64_t key, float* xyz_out, float* sdf_out, void* stream);
+
+/* The same draw inside a graph-captured loop (deepsdf_amd/reconstruct.py): the draw key is key0 + *counter * key_step (mod 2^64),
+ * *counter a DEVICE integer read by the kernel -- e.g. the step counter dsdf_adam_latent_sched advances -- so every replay of
+ * the captured launch draws a new batch, and the sequence equals that of dsdf_sample_batch called with those keys. */
+int dsdf_sample_batch_seq(const float* data, int32_t geom_dim, const int64_t* pos_start, const int64_t* n_pos,
+                          const int64_t* neg_start, const int64_t* n_neg, const int64_t* scene_ids, int64_t n_batch_scenes,
+                          int64_t subsample, uint64_t key0, uint64_t key_step, const int64_t* counter, float* xyz_out, float* sdf_out,
+                          void* stream);
 
 /* ---- building blocks (exported for the parity tests and profiling; not needed by a trainer) --------- */
 /* C[M,N] = A[M,K] * B[N,K]^T (+bias) */

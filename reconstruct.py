@@ -61,13 +61,10 @@ if __name__ == "__main__":
         cache = DeviceSampleCache.from_files(args.data_source, [c[0] for c in chunk], decoder.geom_dimension, eng.device)
         ids = torch.arange(len(chunk))
 
-        def fresh(it):    # upstream drew a new random subsample every iteration
-            xyz, sdf = cache.sample(ids, S, generator=gen)
-            return xyz.view(len(chunk), S, -1), sdf.view(len(chunk), S)
-
-        x0, s0 = fresh(0)
-        z, loss = reconstruct(eng, x0, s0, num_iterations=args.iterations, clamp_dist=clamp, lr=5e-3, l2reg=1e-4,
-                              init_std=0.01, callback=fresh)
+        # upstream drew a new random subsample every iteration: `resample` does it on the device, inside the captured graph
+        shape = torch.empty(len(chunk), S, decoder.geom_dimension, device=eng.device)
+        z, loss = reconstruct(eng, shape, torch.empty(len(chunk), S, device=eng.device), num_iterations=args.iterations, clamp_dist=clamp,
+                              lr=5e-3, l2reg=1e-4, init_std=0.01, resample=(cache, ids, gen))
         logging.info("batch %d: %d shapes, last loss %.5f", b0 // args.shapes_per_batch, len(chunk), float(loss))
         for (f, out), code in zip(chunk, z.cpu()):
             os.makedirs(os.path.dirname(out), exist_ok=True)

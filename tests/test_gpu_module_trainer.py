@@ -168,6 +168,66 @@ def test_latent_only_reconstruction_vs_golden():
     assert torch.equal(eng.grads, grads_before)          # the frozen decoder's gradient arena is never touched
 
 
+def test_reconstruction_as_a_captured_graph_equals_the_eager_loop(tmp_path):
+    """reconstruct(graph=True): one iteration captured into a HIP graph and replayed (Adam scalars from a device schedule, the
+    iteration counter on the device) must give the SAME BITS as the eager loop -- with fixed samples and with a fresh device-side
+    subsample per iteration (resample: the draw key follows the device counter), whose batches must also be the ones
+    DeviceSampleCache.sample() draws with the same generator."""
+    from deepsdf_amd.data import DeviceSampleCache
+    from deepsdf_amd.engine import Engine
+    from deepsdf_amd.net import NetSpec
+    from deepsdf_amd.reconstruct import reconstruct
+    kw = dict(dims=[128] * 4, dropout=[0, 1, 2, 3], dropout_prob=0.2, norm_layers=[0, 1, 2, 3], latent_in=[2],
+              weight_norm=True, geom_dimension=3)
+    eng = Engine(NetSpec(16, **kw))
+    eng.init_like_reference(torch.Generator().manual_seed(3))
+    gen = torch.Generator().manual_seed(4)
+    B, S, iters = 3, 128, 12
+    xyz = (torch.rand(B, S, 3, generator=gen) * 2 - 1).cuda()
+    sdf = (xyz.norm(dim=2) - torch.tensor([0.4, 0.5, 0.6], device="cuda")[:, None])
+    z0 = torch.randn(B, 16, generator=gen) * 0.01
+    ze, le = reconstruct(eng, xyz, sdf, num_iterations=iters, z0=z0, lr_drop_every=5, graph=False)
+    le = le.clone()
+    zg, lg = reconstruct(eng, xyz, sdf, num_iterations=iters, z0=z0, lr_drop_every=5, graph=True)
+    torch.cuda.synchronize()
+    assert torch.equal(ze, zg) and torch.equal(le, lg) and float((ze - z0.cuda()).abs().max()) > 0
+    # fresh samples per iteration from a device cache
+    scenes = []
+    for k in range(B):
+        g = torch.Generator().manual_seed(50 + k)
+        p = torch.rand(900, 3, generator=g) * 2 - 1
+        d = p.norm(dim=1, keepdim=True) - (0.4 + 0.1 * k)
+        rows = torch.cat([p, d], 1)
+        scenes.append((rows[rows[:, 3] > 0].contiguous(), rows[rows[:, 3] <= 0].contiguous()))
+    ids = torch.arange(B)
+    runs = {}
+    for mode in (False, True):
+        cache = DeviceSampleCache(scenes, 3, "cuda")
+        gs = torch.Generator(device="cuda")
+        gs.manual_seed(7)
+        buf_x, buf_s = torch.empty(B, S, 3, device="cuda"), torch.empty(B, S, device="cuda")
+        z, _ = reconstruct(eng, buf_x, buf_s, num_iterations=iters, z0=z0, lr_drop_every=5, graph=mode, resample=(cache, ids, gs))
+        torch.cuda.synchronize()
+        runs[mode] = z.clone()
+        assert cache._draws == iters
+    assert torch.equal(runs[False], runs[True])
+    # ... and the sequence's draws are sample()'s draws: the eager loop fed by sample() through a callback lands on the same codes
+    cache = DeviceSampleCache(scenes, 3, "cuda")
+    gs = torch.Generator(device="cuda")
+    gs.manual_seed(7)
+
+    def feed(it):
+        x, s = cache.sample(ids, S, generator=gs)
+        return x.view(B, S, 3), s.view(B, S)
+
+    x0, s0 = feed(0)
+    cache._draws = 0                                            # (feed(0) above was only for the shapes)
+    zc, _ = reconstruct(eng, x0, s0, num_iterations=iters, z0=z0, lr_drop_every=5, callback=feed)
+    assert torch.equal(zc, runs[False])
+    with pytest.raises(ValueError, match="callback"):
+        reconstruct(eng, x0, s0, num_iterations=iters, z0=z0, callback=feed, graph=True)
+
+
 def test_batched_reconstruction_matches_single():
     """Many shapes at once (one code each, S a multiple of 64 -> segment-sum path) == each shape alone."""
     from deepsdf_amd.engine import Engine

@@ -13,11 +13,14 @@ eng.init_like_reference(torch.Generator().manual_seed(0))
 for B, S in ((1, 8000), (1, 8001), (16, 8000), (64, 8000)):
     xyz = torch.rand(B, S, 3, device=dev) * 2 - 1
     sdf = xyz.norm(dim=2) - 0.5
-    reconstruct(eng, xyz, sdf, num_iterations=20)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    reconstruct(eng, xyz, sdf, num_iterations=100)
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 100
-    print(f"config 4: {B:3d} shapes x {S} pts: {dt*1e3:.3f} ms/iteration = {B*S/dt/1e6:.2f} M point-samples/s ({B/dt:.0f} shape-iterations/s)")
+    for graph in (False, True) if B == 1 else (False,):
+        reconstruct(eng, xyz, sdf, num_iterations=20, graph=graph)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        reconstruct(eng, xyz, sdf, num_iterations=200, graph=graph)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 200
+        print(f"config 4: {B:3d} shapes x {S} pts{' (captured HIP graph, replayed)' if graph else ''}: {dt*1e3:.3f} ms/iteration = "
+              f"{B*S/dt/1e6:.2f} M point-samples/s ({B/dt:.0f} shape-iterations/s; {4 * 1835520 * B * S / dt / 1e12:.1f} TFLOP/s = "
+              f"{4 * 1835520 * B * S / dt / 157.3e12:.2f} of the fp32-MFMA peak)")
 # locality extreme: one scene, 16384 points per step
 lat = (torch.randn(1, bench.L) / math.sqrt(bench.L)).to(dev)
 dlat, m, v = torch.zeros_like(lat), torch.zeros_like(lat), torch.zeros_like(lat)
