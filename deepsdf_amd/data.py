@@ -160,3 +160,134 @@ class DeviceSampleCache:
                                                 _ptr(self.neg_start_d), _ptr(self.n_neg_d), _ptr(sid), B, int(subsample), key,
                                                 _ptr(xyz), _ptr(sdf), _stream()))
         return xyz, sdf
+
+
+class StagedSampleCache:
+    """DeviceSampleCache for datasets LARGER than the HBM budget (SURVEY 8 f1 beyond the resident cache; the reference's
+    `load_ram` mode of deep_sdf/data.py:142-194 is its nearest relative): every scene's filtered samples live in PINNED host
+    memory, and only the scenes of the batches in flight are on the device.  sample() uploads its batch's scenes on a COPY
+    stream into one of `depth` device windows and launches the same sampling kernel on it; the trainer draws batch i + 1 before it
+    runs step i (deepsdf_amd/train.py), so the upload of the next batch overlaps the current step's compute.
+
+    Same interface and -- for the same generator / key -- the SAME BATCHES as DeviceSampleCache: the kernel still indexes by the
+    global scene id (its permutation keys depend on it); per window a full-length pos_start / neg_start array holds window-relative
+    row offsets, of which only the batch's entries are rewritten per draw.  A window is reused only after the sampling launch that
+    read it has finished (events), so `depth` draws may be in flight.  GPU only."""
+
+    def __init__(self, tensors_pos_neg, geom_dimension, device, max_batch_scenes, depth=2):
+        self.G = geom_dimension
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("StagedSampleCache needs a CUDA/HIP device (pinned host memory + copy stream); there is no CPU path")
+        rows, self.n_pos, self.n_neg, self.host_start = [], [], [], []
+        off = 0
+        for pos, neg in tensors_pos_neg:
+            self.host_start.append(off)
+            self.n_pos.append(pos.shape[0]); self.n_neg.append(neg.shape[0])
+            off += pos.shape[0] + neg.shape[0]
+            rows += [pos[:, :geom_dimension + 1], neg[:, :geom_dimension + 1]]
+        if max(max(self.n_pos), max(self.n_neg)) > (1 << 30):
+            raise ValueError("more than 2^30 samples of one sign in a scene")
+        self.host = torch.cat(rows, 0).to(torch.float32).contiguous().pin_memory()          # [total_rows, G+1], scene after scene
+        n = len(self.n_pos)
+        as_dev = lambda x: torch.tensor(x, dtype=torch.int64, device=self.device)  # noqa: E731
+        self.n_pos_d, self.n_neg_d = as_dev(self.n_pos), as_dev(self.n_neg)
+        self.max_batch = int(max_batch_scenes)
+        per_scene = sorted((a + b for a, b in zip(self.n_pos, self.n_neg)), reverse=True)
+        cap = sum(per_scene[:self.max_batch])                                                 # rows of the largest possible batch
+        self.depth = int(depth)
+        self.windows = [torch.empty(cap, geom_dimension + 1, dtype=torch.float32, device=self.device) for _ in range(self.depth)]
+        self.pos_start_w = [torch.zeros(n, dtype=torch.int64, device=self.device) for _ in range(self.depth)]
+        self.neg_start_w = [torch.zeros(n, dtype=torch.int64, device=self.device) for _ in range(self.depth)]
+        self.stage = [torch.empty(3, self.max_batch, dtype=torch.int64).pin_memory() for _ in range(self.depth)]   # ids | pos_start | neg_start
+        self.stage_d = [torch.empty(3, self.max_batch, dtype=torch.int64, device=self.device) for _ in range(self.depth)]
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.ready = [torch.cuda.Event() for _ in range(self.depth)]
+        self.free = [None] * self.depth            # event after the sampling launch that last read the window
+        self.stage_free = [None] * self.depth      # event after the copy that last read the pinned staging rows
+        self._turn = 0
+        self._draws = 0
+        self.uploaded_bytes = 0
+
+    @staticmethod
+    def from_files(data_source, npzfiles, geom_dimension, device, max_batch_scenes, depth=2):
+        items = [load_scene(os.path.join(data_source, ws.sdf_samples_subdir, f), geom_dimension) for f in npzfiles]
+        return StagedSampleCache(items, geom_dimension, device, max_batch_scenes, depth)
+
+    def __len__(self):
+        return len(self.n_pos)
+
+    draw_key = DeviceSampleCache.draw_key
+    KEY_SEED_MUL, KEY_DRAW_MUL = DeviceSampleCache.KEY_SEED_MUL, DeviceSampleCache.KEY_DRAW_MUL
+
+    def sample(self, scene_ids, subsample, generator=None, key=None, scene_ids_device=None):
+        """As DeviceSampleCache.sample (scene_ids_device is accepted and ignored: the ids travel with the offsets)."""
+        from . import _lib
+        from .engine import _ptr, _stream
+        scene_ids = torch.as_tensor(scene_ids, dtype=torch.int64).cpu()
+        S = 2 * int(subsample / 2)
+        ids = scene_ids.tolist()
+        B = len(ids)
+        if B > self.max_batch:
+            raise ValueError(f"batch of {B} scenes, the staging windows were sized for {self.max_batch}")
+        for k in ids:
+            if not 0 <= k < len(self.n_pos):
+                raise IndexError(f"scene {k} is not in the cache")
+            if self.n_pos[k] + self.n_neg[k] < S:
+                raise ValueError(f"scene {k} has {self.n_pos[k] + self.n_neg[k]} samples, fewer than the {S} requested")
+        w = self._turn % self.depth
+        self._turn += 1
+        compute = torch.cuda.current_stream(self.device)
+        win, st, st_d = self.windows[w], self.stage[w], self.stage_d[w]
+        if self.stage_free[w] is not None:
+            self.stage_free[w].synchronize()       # the host rewrites pinned staging rows: their last upload must be done
+        off = 0
+        seen = {}
+        for b, k in enumerate(ids):                # window-relative offsets (a scene drawn twice in a batch is uploaded once)
+            if k not in seen:
+                seen[k] = off
+                off += self.n_pos[k] + self.n_neg[k]
+            st[0, b], st[1, b], st[2, b] = k, seen[k], seen[k] + self.n_pos[k]
+        with torch.cuda.stream(self.copy_stream):
+            if self.free[w] is not None:
+                self.copy_stream.wait_event(self.free[w])          # the launch that read this window has finished
+            for k, o in seen.items():
+                n = self.n_pos[k] + self.n_neg[k]
+                win[o:o + n].copy_(self.host[self.host_start[k]:self.host_start[k] + n], non_blocking=True)
+                self.uploaded_bytes += n * (self.G + 1) * 4
+            st_d[:, :B].copy_(st[:, :B], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+            self.stage_free[w] = ev
+            self.pos_start_w[w].index_copy_(0, st_d[0, :B], st_d[1, :B])
+            self.neg_start_w[w].index_copy_(0, st_d[0, :B], st_d[2, :B])
+            self.ready[w].record(self.copy_stream)
+        compute.wait_event(self.ready[w])
+        xyz = torch.empty(B * S, self.G, dtype=torch.float32, device=self.device)
+        sdf = torch.empty(B * S, dtype=torch.float32, device=self.device)
+        key = self.draw_key(generator) if key is None else int(key) & ((1 << 64) - 1)
+        _lib.check(_lib.lib().dsdf_sample_batch(_ptr(win), self.G, _ptr(self.pos_start_w[w]), _ptr(self.n_pos_d),
+                                                _ptr(self.neg_start_w[w]), _ptr(self.n_neg_d), _ptr(st_d[0]), B, int(subsample), key,
+                                                _ptr(xyz), _ptr(sdf), _stream()))
+        fe = torch.cuda.Event()
+        fe.record(compute)
+        self.free[w] = fe
+        return xyz, sdf
+
+
+def make_sample_cache(data_source, npzfiles, geom_dimension, device, max_batch_scenes):
+    """The trainer's sample cache: resident in HBM (DeviceSampleCache) when the scenes fit the budget, staged through pinned host
+    memory (StagedSampleCache) otherwise.  Budget: DSDF_SAMPLE_CACHE_GB (GiB; 0 forces staging), default 60 % of the HBM that is
+    free when the trainer starts."""
+    items = [load_scene(os.path.join(data_source, ws.sdf_samples_subdir, f), geom_dimension) for f in npzfiles]
+    need = sum((p.shape[0] + n.shape[0]) * (geom_dimension + 1) * 4 for p, n in items)
+    env = os.environ.get("DSDF_SAMPLE_CACHE_GB")
+    if env is not None:
+        budget = float(env) * (1 << 30)
+    else:
+        budget = 0.6 * torch.cuda.mem_get_info(torch.device(device))[0]
+    if need <= budget:
+        return DeviceSampleCache(items, geom_dimension, device)
+    logging.info("sample cache: {:.1f} GiB of samples exceed the {:.1f} GiB HBM budget -> staged through pinned host memory".format(
+        need / (1 << 30), budget / (1 << 30)))
+    return StagedSampleCache(items, geom_dimension, device, max_batch_scenes)

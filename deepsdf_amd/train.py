@@ -24,7 +24,7 @@ import torch
 
 from . import dist
 from . import workspace as ws
-from .data import DeviceSampleCache, get_instance_filenames
+from .data import get_instance_filenames, make_sample_cache
 from .engine import make_segments
 
 
@@ -387,7 +387,8 @@ def main_function(experiment_directory, continue_from, batch_split):
     num_scenes = len(npzfiles)
     logging.info("There are {} scenes".format(num_scenes))
     lo, hi = dist.owned_scenes(num_scenes, rank, world)
-    cache = DeviceSampleCache.from_files(data_source, npzfiles[lo:hi], geom_dimension, device)
+    # resident in HBM, or -- datasets beyond the budget -- staged through pinned host memory (same batches either way)
+    cache = make_sample_cache(data_source, npzfiles[lo:hi], geom_dimension, device, max_batch_scenes=scene_per_batch)
 
     # latent table: Embedding(num_scenes, L) ~ N(0, CodeInitStdDev/sqrt(L)) (:385-390); every rank draws the full table
     # from the same seed and keeps its own rows

@@ -148,3 +148,36 @@ def test_device_sampler_reproduces_the_reference_count_rule(tmp_path):
         assert ip.unique().numel() == n_p and iq.unique().numel() == sdf.shape[0] - n_p, c["id"]      # without replacement
         assert int(ip.min()) >= c["nan_pos"] and int(iq.min()) >= c["nan_neg"], c["id"]              # NaN rows are gone
         assert torch.equal(sdf[:n_p], ip.float() + 1) and torch.equal(sdf[n_p:], -(iq.float() + 1)), c["id"]   # rows stay intact
+
+
+def test_staged_sample_cache_draws_the_resident_cache_batches():
+    """StagedSampleCache (scenes in pinned host memory, only the batches in flight on the device; datasets beyond the HBM budget)
+    must hand out EXACTLY the batches DeviceSampleCache does for the same keys -- over more draws than it has windows (reuse),
+    with a scene repeated inside a batch, and through make_sample_cache's budget switch."""
+    import numpy as np
+    from deepsdf_amd import data
+    rng = np.random.default_rng(3)
+    scenes = []
+    for k in range(7):
+        n_pos, n_neg = int(rng.integers(150, 400)), int(rng.integers(150, 400))
+        pos = np.concatenate([rng.uniform(-1, 1, (n_pos, 3)), rng.uniform(0.01, 0.5, (n_pos, 1))], 1).astype(np.float32)
+        neg = np.concatenate([rng.uniform(-1, 1, (n_neg, 3)), -rng.uniform(0.01, 0.5, (n_neg, 1))], 1).astype(np.float32)
+        scenes.append((torch.from_numpy(pos), torch.from_numpy(neg)))
+    res = data.DeviceSampleCache(scenes, 3, "cuda")
+    stg = data.StagedSampleCache(scenes, 3, "cuda", max_batch_scenes=3, depth=2)
+    g1, g2 = torch.Generator(device="cuda"), torch.Generator(device="cuda")
+    g1.manual_seed(11); g2.manual_seed(11)
+    batches = [[0, 1, 2], [6, 3, 3], [5, 0, 4], [2, 2, 6], [1, 5, 3], [4, 6, 0]]
+    outs = []
+    for b in batches:                                   # several draws in flight before anything is read back
+        ids = torch.tensor(b)
+        outs.append((res.sample(ids, 100, generator=g1), stg.sample(ids, 100, generator=g2)))
+    torch.cuda.synchronize()
+    for b, ((xr, sr), (xs, ss)) in zip(batches, outs):
+        assert torch.equal(xr, xs) and torch.equal(sr, ss), b
+        assert xs.shape == (300, 3) and int((ss[:50] > 0).sum()) == 50 and int((ss[50:100] < 0).sum()) == 50
+    assert stg.uploaded_bytes > 0 and stg.windows[0].shape[0] < res.data.shape[0]      # a window is smaller than the dataset
+    with pytest.raises(ValueError, match="sized for"):
+        stg.sample(torch.tensor([0, 1, 2, 3]), 100)
+    with pytest.raises(IndexError):
+        stg.sample(torch.tensor([7]), 100)

@@ -107,6 +107,29 @@ def _make_experiment(root, n_scenes, specs_over=None):
     return exp
 
 
+def test_trainer_with_a_staged_sample_cache_equals_the_resident_run(tmp_path, monkeypatch):
+    """DSDF_SAMPLE_CACHE_GB=0 forces the trainer's sample cache through pinned host memory (StagedSampleCache: datasets beyond the
+    HBM budget); the batches are the resident cache's, so three epochs must end in bit-identical codes and decoder parameters."""
+    from deepsdf_amd import train
+    outs = []
+    for staged in (False, True):
+        exp = _make_experiment(os.path.join(str(tmp_path), "staged" if staged else "resident"), 4,
+                               specs_over={"NumEpochs": 3, "SnapshotFrequency": 3, "AdditionalSnapshots": [], "LogFrequency": 3})
+        if staged:
+            monkeypatch.setenv("DSDF_SAMPLE_CACHE_GB", "0")
+        else:
+            monkeypatch.delenv("DSDF_SAMPLE_CACHE_GB", raising=False)
+        torch.manual_seed(0)
+        train.main_function(exp, None, 1)
+        lc = torch.load(os.path.join(exp, "LatentCodes", "latest.pth"), weights_only=True)["latent_codes"]["weight"]
+        mo = torch.load(os.path.join(exp, "ModelParameters", "latest.pth"), weights_only=True)["model_state_dict"]
+        outs.append((lc, mo))
+    monkeypatch.delenv("DSDF_SAMPLE_CACHE_GB", raising=False)
+    assert torch.equal(outs[0][0], outs[1][0])
+    for k in outs[0][1]:
+        assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+
+
 def test_trainer_end_to_end_and_resume(tmp_path):
     from deepsdf_amd import train, workspace as ws
     from deepsdf_amd.utils import decode_sdf
