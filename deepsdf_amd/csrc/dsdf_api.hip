@@ -969,7 +969,8 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
       d.ldcs = P.ldcs; d.nwg = P.nwg; d.wg_per_seg = sb->seg->wg_per_seg; d.R = sb->R; d.L = net->latent_size; d.G = net->geom_dim;
       d.seg_scene = sb->seg_scene; d.table = sb->table; d.zr = sb->zr;
       d.HS = at<float>(ws, P.hs_off); d.ldh = P.ldh; d.hstride = P.hstride;
-      q.dw_n = (d.out[0] + SDW_ROWS - 1) / SDW_ROWS + (ks > 0 ? (d.out[1] + SDW_ROWS - 1) / SDW_ROWS : 0);
+      // (block counts of the launch-of-its-own form; the riding form below has its own)
+      q.dw_n = (d.out[0] + SDW_ROWS_WIDE - 1) / SDW_ROWS_WIDE + (ks > 0 ? (d.out[1] + SDW_ROWS_WIDE - 1) / SDW_ROWS_WIDE : 0);
     }
     SegLatArgs& g = q.lat;   // per-segment latent gradient from the column sums of dP_0 / dP_skip
     g.cs0 = at<float>(ws, P.cs_off[0]); g.ldcs = P.ldcs; g.out0 = net->out_dim[0];
@@ -999,9 +1000,10 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
   // the launch 253 us instead of 174 + 18 for a launch of their own, so they still do not ride in split mode)
   const bool post_rides = segmode && want_dw && cus - dw_busy >= 8 && P.nwg <= cus && !no_ride && !net->gemm_split && phase <= 1 &&
                           dw_items > 0;
-  if (post_rides) {   // the per-segment latent gradient in its few-workgroups form
+  if (post_rides) {   // the few-workgroups forms: 32 weight-gradient rows per block, one latent-gradient block per 16 columns
     q.lat_bx = 0;
     lat_n = (net->latent_size + 15) / 16;
+    q.dw_n = (q.dw.out[0] + SDW_ROWS_RIDE - 1) / SDW_ROWS_RIDE + (ks > 0 ? (q.dw.out[1] + SDW_ROWS_RIDE - 1) / SDW_ROWS_RIDE : 0);
   }
   if (segmode && !post_rides && phase <= 1) {
     hipLaunchKernelGGL(post_bwd_kernel, dim3((unsigned)(q.rr_n + q.dw_n + lat_n)), dim3(256), 0, st, q, lat_n);

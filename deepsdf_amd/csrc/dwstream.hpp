@@ -530,6 +530,7 @@ __device__ __forceinline__ void dw_stream_body(const DwArgs& p, const PostBwdArg
   if (dbgw && lane == 0) { dbgw[0] = __builtin_amdgcn_s_memrealtime(); dbgw[2] = lwg >= busy_wg; }
 #endif
   if (lwg >= busy_wg) {
+    if constexpr (SPLIT) return;      // (the roles do not ride in gemm_split mode: dsdf_api.hip run_backward_fused)
     const int total = post.rr_n + post.dw_n + post_lat_n;
 #ifdef DSDF_LAB
     unsigned long long tk[3] = {0, 0, 0};
@@ -539,7 +540,7 @@ __device__ __forceinline__ void dw_stream_body(const DwArgs& p, const PostBwdArg
 #ifdef DSDF_LAB
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
 #endif
-      post_bwd_role(post, i, post_lat_n, ring);
+      post_bwd_role_ride(post, i, post_lat_n, ring);
 #ifdef DSDF_LAB
       tk[i < post.rr_n ? 0 : (i < post.rr_n + post.dw_n ? 1 : 2)] += __builtin_amdgcn_s_memrealtime() - t0;
 #endif

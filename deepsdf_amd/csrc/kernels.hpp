@@ -233,9 +233,9 @@ __global__ __launch_bounds__(256) void seg_hoist_kernel(const HoistArgs p) {   /
 // Round 4: 32 output rows per block instead of 8 (a quarter of the blocks, each with the same number of memory round trips) and every
 // run of dependent loads batched -- as riding roles on the dW launch's 16 spare workgroups these blocks were 115 us of a 391 us role
 // chain that outlasted the launch's MFMA items (377 us: profiles/r04_dw_stamps_before.log).
-constexpr int SDW_ROWS = 32;
-constexpr int SDW_SLOTS = 256 / SDW_ROWS;   // loader mapping: SDW_ROWS consecutive rows x SDW_SLOTS segments / workgroup slices
-constexpr int SDW_LDS_FLOATS = 64 * SDW_ROWS + SDW_SLOTS * SDW_ROWS * 4 + 2 * 64;
+// ... which is the RIDING form; a launch of its own has the whole chip and keeps 8 rows per block (four times the blocks).
+constexpr int SDW_ROWS_RIDE = 32, SDW_ROWS_WIDE = 8;
+constexpr int SDW_LDS_FLOATS = 64 * SDW_ROWS_RIDE + 256 * 4 + 2 * 64;     // css [64][rows] + xred [256 / rows][rows][4] + srow [64]
 struct SegDwArgs {
   int nh; const float* cs[2]; const float* xsum[2]; int out[2];   // per-workgroup sums [nwg][ldcs] / [nwg][4][ldcs]
   int ldcs, nwg, wg_per_seg, R, L, G;
@@ -243,7 +243,9 @@ struct SegDwArgs {
   const float* zr;                                                // non-null: segment r's latent row is zr + r L (seg_hoist_kernel)
   float* HS; int ldh; long long hstride;                          // HS[t] = HS + t * hstride, [out_t][ldh]
 };
+template <int SDW_ROWS>
 __device__ __forceinline__ void seg_dw_body(const SegDwArgs& p, int bidx, float* lds) {
+  constexpr int SDW_SLOTS = 256 / SDW_ROWS;   // loader mapping: SDW_ROWS consecutive rows x SDW_SLOTS segments / workgroup slices
   float (*css)[SDW_ROWS] = reinterpret_cast<float (*)[SDW_ROWS]>(lds);                               // [64 segments][rows]
   float (*xred)[SDW_ROWS][4] = reinterpret_cast<float (*)[SDW_ROWS][4]>(lds + 64 * SDW_ROWS);          // [slots][rows][4]
   long long* srow = reinterpret_cast<long long*>(lds + 64 * SDW_ROWS + SDW_SLOTS * SDW_ROWS * 4);      // [64]
@@ -1110,22 +1112,29 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const ReduceRowsArgs a
 struct PostBwdArgs {
   ReduceRowsArgs rr; int rr_bx, rr_n;        // blocks [0, rr_n): (bx, g) = (i % rr_bx, i / rr_bx)
   SegDwArgs dw; int dw_n;                    // next dw_n blocks (0: weights frozen)
-  SegLatArgs lat; int lat_bx;                // the rest: (bx, by) = (i % lat_bx, i / lat_bx); lat_bx == 0: the all-segments form,
-};                                           // one block per 16-column chunk of the latent (seg_latgrad_all_body)
+  SegLatArgs lat; int lat_bx;                // the rest: (bx, by) = (i % lat_bx, i / lat_bx); riding: one block per 16-column chunk
+};                                           // of the latent takes all segments (seg_latgrad_all_body)
 // LDS scratch of the roles comes from the caller (the dW kernels lend theirs): the largest role's need
 constexpr int ROLE_LDS_FLOATS = SLA_LDS_FLOATS > SDW_LDS_FLOATS ? SLA_LDS_FLOATS : SDW_LDS_FLOATS;
 static_assert(ROLE_LDS_FLOATS >= SLAT_LDS_FLOATS && ROLE_LDS_FLOATS >= 4 * 64, "role scratch");
+// RIDE: the forms for a few workgroups beside the dW items (32 weight-gradient rows per block, all-segments latent gradient);
+// otherwise the forms of a launch of its own, which has the whole chip (8 rows per block, one block per segment and 16 columns).
+// The riding form is a NOINLINE call: inlined into the dW kernels its register needs leaked into their k-loops' allocation.
+template <bool RIDE>
 __device__ __forceinline__ void post_bwd_role(const PostBwdArgs& p, int i, int lat_n, float* lds) {
   if (i < p.rr_n) { reduce_rows_body(p.rr, i % p.rr_bx, i / p.rr_bx, lds); return; }
   i -= p.rr_n;
-  if (i < p.dw_n) { seg_dw_body(p.dw, i, lds); return; }
+  if (i < p.dw_n) { seg_dw_body<RIDE ? SDW_ROWS_RIDE : SDW_ROWS_WIDE>(p.dw, i, lds); return; }
   i -= p.dw_n;
-  if (p.lat_bx == 0) seg_latgrad_all_body(p.lat, i, lat_n, lds);
+  if constexpr (RIDE) seg_latgrad_all_body(p.lat, i, lat_n, lds);
   else seg_latgrad_body(p.lat, i % p.lat_bx, i / p.lat_bx, lds);
+}
+__device__ __attribute__((noinline)) void post_bwd_role_ride(const PostBwdArgs& p, int i, int lat_n, float* lds) {
+  post_bwd_role<true>(p, i, lat_n, lds);
 }
 __global__ __launch_bounds__(256) void post_bwd_kernel(const PostBwdArgs p, const int lat_n) {
   __shared__ __attribute__((aligned(16))) float lds[ROLE_LDS_FLOATS];
-  post_bwd_role(p, blockIdx.x, lat_n, lds);
+  post_bwd_role<false>(p, blockIdx.x, lat_n, lds);
 }
 
 // K5b: dlat[scene] += sum over the segments of that scene (in segment order) of
