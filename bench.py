@@ -390,7 +390,7 @@ def main():
         tf = 2.0 * n_local * spec.w_mac / (us * 1e-6) / 1e12
         bf16_fwd = dict(us_per_call=us, tflops=tf, frac_of_bf16_dense_peak=tf / 2500.0, points=n_local,
                         note="HIP events around 100 calls of Engine.decode_latent (seg_hoist_kernel + fused_forward_bf16x8_kernel + the "
-                             "host-side launch path); the kernel alone: profiles/r03_bf16_decode_kernel_stats.csv")
+                             "host-side launch path); the kernel alone: profiles/r03_bf16_decode_kernel_stats.csv (round 3; the kernel is unchanged)")
 
     # ---- PMC child passes (GPU, child processes), THEN the CPU baseline on an otherwise idle host; both after all GPU timing ----
     if want_pmc:
@@ -410,10 +410,10 @@ def main():
                                           "(separate passes, FETCH_SIZE x2 on gfx950), per launch")
             roofline["traffic_per_kernel_MB"] = {k: v["hbm_bytes_per_launch"] / 1e6 for k, v in pmc_res["traffic"].items()}
         else:
-            tfile = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+            tfile = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
             if os.path.exists(tfile) and dom in json.load(open(tfile)):
                 roofline["traffic"] = json.load(open(tfile))[dom]["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = "NOT measured in this run (" + pmc_res.get("error", "--no-pmc") + "): profiles/r03_pmc_traffic.json"
+                roofline["traffic_source"] = "NOT measured in this run (" + pmc_res.get("error", "--no-pmc") + "): profiles/r04_pmc_traffic.json"
         if "mfma" in pmc_res and dom in pmc_res["mfma"]:
             m = pmc_res["mfma"][dom]
             t = roofline["avg_launch_us"] * 1e-6

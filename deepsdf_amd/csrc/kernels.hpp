@@ -741,16 +741,17 @@ __global__ __launch_bounds__(256) void finalize_layer_kernel(const FinArgs p) {
 // the three reductions are wave shuffles.  Same per-element slab order (sp = 0 .. nsplit - 1), its own (fixed) order for the row
 // reductions.  Round 4: the finalize launch 34 -> see profiles/r04_bench_kernel_stats.csv.
 constexpr int FW_MAXK = 8;
+template <int FW_KU>      // columns per lane = ceil(in / 64) rounded up to 1, 2, 4 or 8: a compile-time count keeps every load unconditional
 __device__ __forceinline__ void finalize_row_wave(const FinArgs& p, const int i) {
   const int lane = threadIdx.x & 63;
-  float vv[FW_MAXK], mo[FW_MAXK], so[FW_MAXK], dwr[FW_MAXK];
+  float vv[FW_KU], mo[FW_KU], so[FW_KU], dwr[FW_KU];
   const size_t ro = (size_t)i * p.in;
   // (every load is UNCONDITIONAL -- out-of-range lanes read a clamped, valid address and drop the value with a select: a load under a
   // per-lane condition becomes a branch of its own with its own wait)
   const float* mp = p.adam ? p.mv : p.v;
   const float* sp_ = p.adam ? p.sv : p.v;
 #pragma unroll
-  for (int k = 0; k < FW_MAXK; ++k) {
+  for (int k = 0; k < FW_KU; ++k) {
     const int c = lane + 64 * k, cc = min(c, p.in - 1);
     const float a0 = p.v[ro + cc], a1 = mp[ro + cc], a2 = sp_[ro + cc];
     const bool ok = c < p.in;
@@ -765,26 +766,27 @@ __device__ __forceinline__ void finalize_row_wave(const FinArgs& p, const int i)
     for (int u = 0; u < 4; ++u) bs += q0 + 64 * u < p.npart ? t[u] : 0.f;
   }
 #pragma unroll
-  for (int k = 0; k < FW_MAXK; ++k) dwr[k] = 0.f;
-  for (int sp = 0; sp < p.nsplit; sp += 4) {       // 4 splits x 8 columns in flight per batch; per element the order sp = 0, 1, ... of finalize_row
-    float t[4][FW_MAXK];
+  for (int k = 0; k < FW_KU; ++k) dwr[k] = 0.f;
+  constexpr int FW_SB = 32 / FW_KU;                 // splits per batch: 32 loads in flight per lane (40 -- the headline's 10 splits x 8
+                                                    // columns in two batches -- costs the fourth resident wave per SIMD: 134 VGPRs)
+  for (int sp = 0; sp < p.nsplit; sp += FW_SB) {    // (per element the order sp = 0, 1, ... of finalize_row)
+    float t[FW_SB][FW_KU];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < FW_SB; ++u)
 #pragma unroll
-      for (int k = 0; k < FW_MAXK; ++k)
-        if (64 * k < p.in)                         // (wave-uniform)
-          t[u][k] = p.slabs[(size_t)min(sp + u, p.nsplit - 1) * p.slab + (size_t)i * p.ldc + min(lane + 64 * k, p.in - 1)];
+      for (int k = 0; k < FW_KU; ++k)
+        t[u][k] = p.slabs[(size_t)min(sp + u, p.nsplit - 1) * p.slab + (size_t)i * p.ldc + min(lane + 64 * k, p.in - 1)];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < FW_SB; ++u)
 #pragma unroll
-      for (int k = 0; k < FW_MAXK; ++k) {
+      for (int k = 0; k < FW_KU; ++k) {
         const int c = lane + 64 * k;
-        if (64 * k < p.in) dwr[k] += (sp + u < p.nsplit && c < p.in && (!p.hoist || c < p.lat0)) ? t[u][k] : 0.f;
+        dwr[k] += (sp + u < p.nsplit && c < p.in && (!p.hoist || c < p.lat0)) ? t[u][k] : 0.f;
       }
   }
   if (p.hoist) {   // x0 columns of a hoisted layer: computed by seg_dw_body
 #pragma unroll
-    for (int k = 0; k < FW_MAXK; ++k) {
+    for (int k = 0; k < FW_KU; ++k) {
       const int c = lane + 64 * k - p.lat0;
       if (c >= 0 && c < p.hW) dwr[k] += p.hs[(size_t)i * p.ldh + c];
     }
@@ -793,7 +795,7 @@ __device__ __forceinline__ void finalize_row_wave(const FinArgs& p, const int i)
   if (p.g) {
     float dot = 0.f, ss = 0.f;
 #pragma unroll
-    for (int k = 0; k < FW_MAXK; ++k) { dot += dwr[k] * vv[k]; ss += vv[k] * vv[k]; }     // (columns >= in hold zeros)
+    for (int k = 0; k < FW_KU; ++k) { dot += dwr[k] * vv[k]; ss += vv[k] * vv[k]; }     // (columns >= in hold zeros)
     dot = wave_sum(dot);
     ss = wave_sum(ss);
     const float nrm = sqrtf(ss);
@@ -802,7 +804,7 @@ __device__ __forceinline__ void finalize_row_wave(const FinArgs& p, const int i)
     const float a = gi / nrm, b = gi * dgi / (nrm * nrm);
     float ssn = 0.f;
 #pragma unroll
-    for (int k = 0; k < FW_MAXK; ++k) {
+    for (int k = 0; k < FW_KU; ++k) {
       const int c = lane + 64 * k;
       if (c < p.in) {
         const float d = a * dwr[k] - b * vv[k];
@@ -823,7 +825,7 @@ __device__ __forceinline__ void finalize_row_wave(const FinArgs& p, const int i)
     } else if (lane == 0) p.dg[i] = p.accumulate ? p.dg[i] + dgi : dgi;
   } else {
 #pragma unroll
-    for (int k = 0; k < FW_MAXK; ++k) {
+    for (int k = 0; k < FW_KU; ++k) {
       const int c = lane + 64 * k;
       if (c < p.in) {
         if (p.adam) {
@@ -851,7 +853,13 @@ __device__ __forceinline__ void finalize_block(const FinAll& p, const int b, flo
   const FinArgs& f = p.f[l];
   if (f.in <= 64 * FW_MAXK) {
     const int i = (b - p.row0[l]) * 4 + (int)(threadIdx.x >> 6);
-    if (i < f.out) finalize_row_wave(f, i);
+    if (i < f.out) {
+      const int ku = (f.in + 63) >> 6;
+      if (ku <= 1) finalize_row_wave<1>(f, i);
+      else if (ku == 2) finalize_row_wave<2>(f, i);
+      else if (ku <= 4) finalize_row_wave<4>(f, i);
+      else finalize_row_wave<8>(f, i);
+    }
   } else finalize_row(f, b - p.row0[l], red);
 }
 __global__ __launch_bounds__(256) void finalize_all_kernel(const FinAll p) {

@@ -57,6 +57,7 @@ class Engine:
         self.loss = torch.zeros(1, **f32)
         self.clip = torch.zeros(2, **f32)   # [norm, coef]
         self._ws = None
+        self._ws_sizes = {}
         self.step = 0
         self.weights_dirty = True
 
@@ -103,12 +104,16 @@ class Engine:
         return self._ws
 
     def train_workspace(self, n_points, n_segments, buckets=0):
-        b = C.c_size_t()
-        if buckets > 2:      # finer split-K slabs than dsdf_workspace_bytes plans for
-            _lib.check(self.lib.dsdf_workspace_bytes_buckets(C.byref(self.cnet), n_points, n_segments, buckets, C.byref(b)))
-        else:
-            _lib.check(self.lib.dsdf_workspace_bytes(C.byref(self.cnet), n_points, n_segments, C.byref(b)))
-        return self._workspace(b.value)
+        key = (int(n_points), int(n_segments), int(buckets) if buckets > 2 else 0)
+        size = self._ws_sizes.get(key)
+        if size is None:     # (the size query plans the whole step -- every bucket's schedule -- on the host: asked once per shape, not
+            b = C.c_size_t()  # once per call; a K-bucket step makes K calls)
+            if buckets > 2:      # finer split-K slabs than dsdf_workspace_bytes plans for
+                _lib.check(self.lib.dsdf_workspace_bytes_buckets(C.byref(self.cnet), n_points, n_segments, buckets, C.byref(b)))
+            else:
+                _lib.check(self.lib.dsdf_workspace_bytes(C.byref(self.cnet), n_points, n_segments, C.byref(b)))
+            size = self._ws_sizes[key] = b.value
+        return self._workspace(size)
 
     # ---- weights -----------------------------------------------------------------------------------------
     def materialize(self):

@@ -12,6 +12,8 @@ case "$1" in
   for n in 6x128 4x64 4x32; do python3 bench.py --network $n --steps 40 --warmup 5 > gpurun_out/r04_net_$n.json.log 2> gpurun_out/r04_net_$n.err || exit 1; tail -1 gpurun_out/r04_net_$n.json.log | cut -c1-300; done
   for b in 1 2 4 8; do DSDF_FORCE_DP_PATH=1 DSDF_AR_BUCKETS=$b one; done > gpurun_out/r04_dp_buckets_one_gpu.log 2>&1; cat gpurun_out/r04_dp_buckets_one_gpu.log
   { python3 tools/extra_configs.py; bash tools/extra_numbers.sh; } > gpurun_out/r04_extra_configs.log 2>&1; tail -12 gpurun_out/r04_extra_configs.log ;;
+ d)  # the data-parallel call sequence on one GPU with K gradient buckets (no collective)
+  for b in 1 2 4 8; do DSDF_FORCE_DP_PATH=1 DSDF_AR_BUCKETS=$b one; done > gpurun_out/r04_dp_buckets_one_gpu.log 2>&1; cat gpurun_out/r04_dp_buckets_one_gpu.log ;;
  c)  # the whole GPU suite, as it is and with the gemm_split default switched on
   timeout -k 10 1100 python3 -m pytest tests -m gpu -q --durations=12 > gpurun_out/r04_gpu_suite.log 2>&1; rc=$?; tail -16 gpurun_out/r04_gpu_suite.log
   [ $rc -eq 0 ] || { echo "FAILED: pytest rc $rc"; exit 1; }
