@@ -223,6 +223,9 @@ int skip_layer(const DsdfNet* n) {
     if ((n->skip_mask >> l) & 1) return l;
   return -1;
 }
+// latent_in names the OUTPUT layer (valid in the reference: deep_sdf_decoder.py:88-89 runs for every layer incl. the last Linear): its
+// input is [a | x0].  No segment mode, no dsdf_decode_latent for such a net; the heads route the x0 columns' gradient (kernels.hpp LastArgs).
+bool last_layer_skip(const DsdfNet* n) { return ((n->skip_mask >> (n->n_layers - 1)) & 1) != 0; }
 // columns of layer l's input that the dW GEMM contracts over the points: all of them, or -- segment mode -- only the
 // previous layer's activations (the x0 columns of layer 0 / the skip layer are hoisted: finalize_row, kernels.hpp)
 int dw_cols(const DsdfNet* n, int l, bool segmode) {
@@ -923,6 +926,10 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     wmac += (double)y.K * y.ncols;
   }
   a.n_layers = cnt;
+  if (last_layer_skip(net)) {   // the head hands the x0 columns' gradient du w[x0 cols] to the skip-layer buffer of d/dx0
+    a.head.dz_out = ncols_dz > 0 ? at<float>(ws, P.dzB_off) : nullptr; a.head.ldz = P.ldz; a.head.dz_cols = ncols_dz;
+    if (ncols_dz > 0) *used_dzB = true;
+  }
   if (phase <= 1) {
     // algorithmic FLOPs of the dX chain (the reference back-propagates through every hidden layer down to x0); the
     // executed count `wmac` is smaller: layer 0's dX and the skip layer's x0 columns come from column sums instead
@@ -1121,6 +1128,7 @@ FusedBwdHead make_head(const DsdfNet* net, const Plan& P, void* ws, const float*
   h.dp_out = at<float>(ws, P.dpl_off[last - 1]); h.ld_dp = P.ld_dp;
   h.part = at<float>(ws, P.part_off); h.ld_part = P.ld_part;
   h.part_db = at<float>(ws, P.partdb_off); h.part_loss = at<float>(ws, P.partloss_off);
+  h.n_act = net->out_dim[last - 1];      // (< in_last only when latent_in names the output layer: run_backward_fused points dz_out)
   return h;
 }
 
@@ -1247,7 +1255,7 @@ int dsdf_decode(const DsdfNet* net, const float* packed, const float* params, co
 
 static bool decode_latent_ok(const DsdfNet* net) {
   return fused_enabled() && fused_eligible(net) && net->geom_dim <= FGEO && net->latent_size <= HOIST_MAXL &&
-         net->latent_size >= 1 && net->n_layers >= 3;
+         net->latent_size >= 1 && net->n_layers >= 3 && !last_layer_skip(net);
 }
 
 int dsdf_decode_latent_supported(const DsdfNet* net) {
@@ -1331,6 +1339,8 @@ int dsdf_module_backward(const DsdfNet* net, const float* packed, const float* p
   a.part_dw = at<float>(ws, P.part_off); a.ld_part = P.ld_part;
   a.part_colsum = at<float>(ws, P.part_off) + P.ld_in[last];
   a.part_db = at<float>(ws, P.partdb_off); a.part_loss = at<float>(ws, P.partloss_off);
+  a.n_act = net->out_dim[last - 1];
+  if (last_layer_skip(net) && d_input) { a.dz = at<float>(ws, P.dzB_off); a.ldz = P.ldz; a.dz_cols = P.W0; }
   bool used_dzB = false;
   if (fusedb) {
     FusedBwdHead h = make_head(net, P, ws, packed, params, HEAD_EXT, training);
@@ -1349,6 +1359,7 @@ int dsdf_module_backward(const DsdfNet* net, const float* packed, const float* p
     }
     TRY(run_backward(net, P, ws, packed, params, n, training, grads, accumulate, d_input ? P.W0 : 0, &used_dzB, st, true, dropout_key, 0,
                      (d_input && net->xyz_in_all) ? &xyz_acc : nullptr));
+    if (last_layer_skip(net) && d_input) used_dzB = true;      // (last_layer_kernel wrote it)
     if (d_input) {
       const long long tot = (long long)n * P.W0;
       hipLaunchKernelGGL(add2_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, at<float>(ws, P.dzA_off), P.ldz,
@@ -1488,6 +1499,7 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
   const int frows = can_merge ? pick_frows(net, n) : FROWS;
   const bool segsum = fusedb && b->seg_len > 0 && b->seg_len % frows == 0 && b->seg_len * R == n && net->n_layers > 2 &&
                       skip_l != net->n_layers - 2 &&   // the deepest hidden layer's dP column sums live in the head's partials
+                      !last_layer_skip(net) &&
                       net->geom_dim <= FGEO && net->latent_size <= HOIST_MAXL;   // (config 5 too: bf16 rounding is element-wise
                                                                                   // on the operands, so the latent products still hoist)
   const int phase = cfg->dw_phase, nbk = cfg->dw_buckets;
@@ -1553,6 +1565,8 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
   a.part_dw = at<float>(ws, P.part_off); a.ld_part = P.ld_part;
   a.part_colsum = at<float>(ws, P.part_off) + P.ld_in[last];
   a.part_db = at<float>(ws, P.partdb_off); a.part_loss = at<float>(ws, P.partloss_off);
+  a.n_act = net->out_dim[last - 1];
+  if (last_layer_skip(net)) { a.dz = at<float>(ws, P.dzB_off); a.ldz = P.ldz; a.dz_cols = Lc; }
   if (!fusedb) TRY(launch_last<LAST_TRAIN>(a, P.last_blocks, st));
 
   bool used_dzB = false;
@@ -1578,6 +1592,7 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
   } else {
     TRY(run_backward(net, P, ws, packed, params, n, cfg->training, grads, accumulate, Lc, &used_dzB, st, want_dw, cfg->dropout_key,
                      (uint32_t)b->row_offset));
+    if (last_layer_skip(net)) used_dzB = true;                 // (last_layer_kernel wrote it)
   }
 
   SegArgs s;

@@ -1396,6 +1396,9 @@ struct FusedBwdHead {
   float* dp_out; int ld_dp;                           // global dP_{last-1}
   float* part; int ld_part;                           // [n_wg][ld_part]: [dW_last (in_last) | colsum of dP_{last-1} at offset ld_a]
   float* part_db; float* part_loss;                   // [n_wg]
+  // latent_in names the OUTPUT layer: columns >= n_act of its input are x0 -- their gradient du w[c] passes no mask and goes to
+  // dz_out (first dz_cols of them) instead of dP_{last-1} (kernels.hpp LastArgs)
+  int n_act; float* dz_out; int ldz; int dz_cols;
 };
 struct FusedBwdArgs {
   int n_layers, N;                 // entries of ly[], processed in order (deepest layer first)
@@ -1547,6 +1550,19 @@ __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float
           d.y = av[cc].y > 0.f ? ds * qv[cc].y : 0.f;
           d.z = av[cc].z > 0.f ? ds * qv[cc].z : 0.f;
           d.w = av[cc].w > 0.f ? ds * qv[cc].w : 0.f;
+          if (c + 3 >= H.n_act) {          // (part of) the chunk lies in the x0 columns of an output-layer skip
+            float dv[4] = {d.x, d.y, d.z, d.w};
+            const float wv[4] = {qv[cc].x, qv[cc].y, qv[cc].z, qv[cc].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int cx = c + e - H.n_act;
+              if (cx >= 0) {
+                if (live && H.dz_out != nullptr && cx < H.dz_cols) H.dz_out[(size_t)grow * H.ldz + cx] = du * wv[e];
+                dv[e] = 0.f;
+              }
+            }
+            d = make_float4(dv[0], dv[1], dv[2], dv[3]);
+          }
           *reinterpret_cast<float4*>(S + row * LDSW + c) = d;
           if (live) *reinterpret_cast<float4*>(H.dp_out + (size_t)grow * H.ld_dp + c) = d;
           dwa[cc].x += du * av[cc].x; dwa[cc].y += du * av[cc].y; dwa[cc].z += du * av[cc].z; dwa[cc].w += du * av[cc].w;

@@ -524,6 +524,10 @@ struct LastArgs {
   float* part_db;          // [nblk]
   float* part_loss;        // [nblk]
   float* part_colsum;      // [nblk][ld_part]
+  // latent_in names the OUTPUT layer (deep_sdf_decoder.py:88-89 with layer = num_layers - 2): its input is [a | x0]; columns >= n_act are
+  // x0, their gradient du w[c] passes no ReLU / dropout mask and goes to dz [n][ldz] (first dz_cols of them), not to dp_prev.
+  int n_act;               // columns of the input that are the previous layer's activations (= in without such a skip)
+  float* dz; int ldz; int dz_cols;
 };
 template <int MODE, int NCH>  // NCH float4 chunks per lane: in <= 256 * NCH
 __global__ __launch_bounds__(256) void last_layer_kernel(const LastArgs p) {
@@ -588,6 +592,20 @@ __global__ __launch_bounds__(256) void last_layer_kernel(const LastArgs p) {
           d.y = a4[c].y > 0.f ? du * w4[c].y * p.mask_scale : 0.f;
           d.z = a4[c].z > 0.f ? du * w4[c].z * p.mask_scale : 0.f;
           d.w = a4[c].w > 0.f ? du * w4[c].w * p.mask_scale : 0.f;
+          const int col0 = 4 * lane + 256 * c;
+          if (col0 + 3 >= p.n_act) {       // (part of) the chunk lies in the x0 columns of an output-layer skip
+            float dv[4] = {d.x, d.y, d.z, d.w};
+            const float wv[4] = {w4[c].x, w4[c].y, w4[c].z, w4[c].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int cx = col0 + e - p.n_act;
+              if (cx >= 0) {
+                if (p.dz != nullptr && cx < p.dz_cols) p.dz[(size_t)row * p.ldz + cx] = du * wv[e];
+                dv[e] = 0.f;
+              }
+            }
+            d = make_float4(dv[0], dv[1], dv[2], dv[3]);
+          }
           if (p.dp_prev) *reinterpret_cast<float4*>(p.dp_prev + (size_t)row * p.lddp + 4 * lane + 256 * c) = d;
           cs[c].x += d.x; cs[c].y += d.y; cs[c].z += d.z; cs[c].w += d.w;
         }

@@ -343,6 +343,9 @@ JVP_CASES = {
     # the shipped small-net shape: last layer weight-normed, use_tanh (tanh o tanh), skip right after layer 0
     "tiny_lastnorm_tanh": dict(L=2, N=333, net=dict(dims=[32] * 4, dropout=[0, 1, 2, 3], dropout_prob=0.2, norm_layers=list(range(8)),
                                                     latent_in=[1], weight_norm=True, use_tanh=True, geom_dimension=3)),
+    # latent_in names the output layer: its x0 columns' gradient / tangent bypass the ReLU mask
+    "skip_into_the_output_layer": dict(L=6, N=300, net=dict(dims=[64, 64, 72], dropout=[0, 1, 2], dropout_prob=0.2, norm_layers=[0, 1, 2, 3],
+                                                             latent_in=[3], weight_norm=True, use_tanh=False, geom_dimension=3)),
     # the headline architecture; N off every tile grid
     "8x512": dict(L=256, N=1000, net=dict(dims=[512] * 8, dropout=list(range(8)), dropout_prob=0.2, norm_layers=list(range(8)),
                                           latent_in=[4], weight_norm=True, use_tanh=False, geom_dimension=3)),
@@ -399,6 +402,58 @@ def test_decoder_jvp_vs_oracle(name):
     assert rel_err(xg.grad.cpu(), dx0) <= GRAD_TOL
     for pname, p in dec.named_parameters():
         assert rel_err(p.grad.cpu(), go[pname].reshape(p.shape)) <= GRAD_TOL, pname
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_specs_through_the_module_seam_vs_oracle(seed):
+    """The seeded random decoders of tests/test_gpu_parity.py::_random_case through the nn.Module seam (dsdf_module_forward /
+    dsdf_module_backward, `decode_sdf`): eval forward, train forward, parameter gradients and d/d(input) against the float64 oracle."""
+    from deepsdf_amd.decoder import Decoder
+    from tests.test_gpu_parity import _random_case
+    c = _random_case(100 + seed)
+    L, G = c["L"], c["net"]["geom_dimension"]
+    N = c["B"] * c["S"] + 7                                             # off every tile grid
+    net = orc.make_net(L, **c["net"])
+    params = orc.init_params(net, 500 + seed)
+    p64 = {k: v.double() for k, v in params.items()}
+    gen = torch.Generator().manual_seed(600 + seed)
+    x = torch.cat([torch.randn(N, L, generator=gen) / math.sqrt(L), torch.rand(N, G, generator=gen) * 2 - 1], 1)
+    _, sv = orc.decoder_forward(net, p64, x.double(), training=False, track_margin=True)
+    x[sv.min_abs_pre < 1e-6] += 0.01                                    # keep every ReLU decision away from fp32 noise
+    dec = Decoder(L, **c["net"]).cuda()
+    dec.load_state_dict(params)
+    dec.eval()
+    with torch.no_grad():
+        ye = dec(x.cuda())
+    yo, _ = orc.decoder_forward(net, p64, x.double(), training=False)
+    assert rel_err(ye.cpu(), yo) <= FWD_TOL, (seed, c)
+    _decode_sdf_agrees_with_the_module(dec, x)
+    for training in (False, True):
+        dec.train(training)
+        dec.zero_grad(set_to_none=True)
+        xg = x.cuda().requires_grad_(True)
+        y = dec(xg)
+        masks = orc.dropout_masks(net, dec.dropout_seed, dec._fwd_calls, N) if training else None
+        yo, svo = orc.decoder_forward(net, p64, x.double(), training=training, masks=masks)
+        assert rel_err(y.detach().cpu(), yo) <= FWD_TOL, (seed, training, c)
+        w = torch.randn(N, 1, generator=gen)
+        (y * w.cuda()).sum().backward()
+        go, dx0 = orc.decoder_backward(net, p64, svo, w.double(), training)
+        assert rel_err(xg.grad.cpu(), dx0) <= GRAD_TOL, (seed, training, c)
+        for pname, p in dec.named_parameters():
+            assert rel_err(p.grad.cpu(), go[pname].reshape(p.shape)) <= GRAD_TOL, (pname, seed, training, c)
+
+
+def _decode_sdf_agrees_with_the_module(dec, x):
+    """deep_sdf.utils.decode_sdf (deep_sdf/utils.py:54-65) with ONE code for all query points -- the consumers' call, which takes
+    dsdf_decode_latent where the library supports the net -- against Decoder.forward on the materialised [z | q] input."""
+    import deep_sdf.utils
+    L = dec.spec.latent_size
+    z, q = x[0, :L].clone(), x[:, L:].clone()
+    with torch.no_grad():
+        out = deep_sdf.utils.decode_sdf(dec, z.cuda(), q.cuda())
+        ref = dec(torch.cat([z.expand(x.shape[0], -1), q], 1).cuda())
+    assert out.shape == ref.shape and rel_err(out.cpu(), ref.cpu()) <= 1e-5
 
 
 def test_second_order_through_the_decoder_warns_once_and_the_jvp_trick_does_not():

@@ -499,6 +499,11 @@ SEG_SHAPES = {
     "s96_three_h32_workgroups": dict(L=6, B=3, S=96, split=1, net=dict(dims=[96, 96, 96], dropout=[0, 1], dropout_prob=0.2,
                                                                          norm_layers=[0, 1, 2], latent_in=[2], weight_norm=True,
                                                                          geom_dimension=3)),
+    # latent_in names the OUTPUT layer (deep_sdf_decoder.py:88-89 runs for the last Linear too): sdf = tanh(<[a | x0], w> + b).  No
+    # segment mode for such a net; the backward heads hand the x0 columns' gradient to d/dx0 unmasked (found by the random specs below)
+    "skip_into_the_output_layer": dict(L=5, B=3, S=64, split=1, net=dict(dims=[64, 72, 72], dropout=[0, 1, 2], dropout_prob=0.2,
+                                                                          norm_layers=[0, 1, 2, 3], latent_in=[3], weight_norm=True,
+                                                                          geom_dimension=3)),
     "geom2_plain": dict(L=16, B=2, S=192, split=1, net=dict(dims=[72, 72, 72, 72], dropout=[], dropout_prob=0.0, norm_layers=[],
                                                             latent_in=[2], weight_norm=False, geom_dimension=2)),
 }
@@ -548,6 +553,97 @@ def test_segment_mode_odd_shapes_vs_oracle(name, monkeypatch):
             assert rel_err(tr.lat.cpu(), st64.latents) <= ptol, (step, kw, rows)
     monkeypatch.delenv("DSDF_FROWS", raising=False)
     monkeypatch.delenv("DSDF_NO_NARROW", raising=False)
+
+
+def _random_case(seed):
+    """A seeded random NetworkSpecs + batch shape inside what the reference's Decoder constructor accepts and the fused kernels take:
+    2-6 hidden layers of widths 32 ... 264 (not all on the 32-column tile grid), any / no skip layer (also in front of the output
+    layer), weight norm on a random subset (or none), dropout on a random subset with p in {0, 0.2, 0.5}, use_tanh, 2-D / 3-D
+    geometry, latent sizes 1 ... 64, 1-5 scenes of 32 ... 264 samples (multiples of 32 and not), --batch_split 1 or 2."""
+    import random
+    rng = random.Random(1000 + seed)
+    nh = rng.randint(2, 6)
+    G = rng.choice([2, 3, 3, 3])
+    L = rng.choice([1, 2, 3, 5, 8, 16, 29, 64])
+    W0 = L + G
+    widths = [w for w in (32, 40, 64, 72, 96, 128, 136, 160, 200, 264) if w - W0 >= 8]
+    dims = [rng.choice(widths) for _ in range(nh)]
+    latent_in = [] if rng.random() < 0.3 else [rng.randint(1, nh)]
+    wn = rng.random() < 0.8
+    norm_layers = sorted(rng.sample(range(nh + 1), rng.randint(1, nh + 1))) if wn else []
+    dropout = sorted(rng.sample(range(nh), rng.randint(0, nh)))
+    p = rng.choice([0.0, 0.2, 0.5]) if dropout else 0.0
+    B = rng.randint(1, 5)
+    S = rng.choice([32, 64, 96, 128, 160, 256, 40, 100, 264])
+    split = 2 if (B * S) % 2 == 0 and rng.random() < 0.3 else 1
+    net = dict(dims=dims, dropout=dropout, dropout_prob=p, norm_layers=norm_layers, latent_in=latent_in, weight_norm=wn,
+               use_tanh=rng.random() < 0.3, geom_dimension=G)
+    return dict(L=L, B=B, S=S, split=split, net=net)
+
+
+@pytest.mark.parametrize("seed", range(36))
+def test_random_specs_and_shapes_vs_oracle(seed, monkeypatch):
+    """Seeded random decoders and batch shapes (see _random_case), one optimiser step each against the float64 oracle, segment and
+    ragged, rotated over the three kernel families (32-point workgroups / narrow-net or full 64-point kernels / full-size kernels
+    only).  The hand-picked shapes above cover the cases somebody thought of; the 65536-point overrun of rounds 1-3 was one nobody
+    had."""
+    c = _random_case(seed)
+    L, B, S, G = c["L"], c["B"], c["S"], c["net"]["geom_dimension"]
+    family = seed % 3
+    monkeypatch.delenv("DSDF_FROWS", raising=False)
+    monkeypatch.delenv("DSDF_NO_NARROW", raising=False)
+    if family >= 1:
+        monkeypatch.setenv("DSDF_FROWS", "64")
+    if family == 2:
+        monkeypatch.setenv("DSDF_NO_NARROW", "1")
+    net = orc.make_net(L, **c["net"])
+    spec = spec_from_meta(dict(L=L, net_specs=c["net"]))
+    params = orc.init_params(net, 200 + seed)
+    lat0 = torch.randn(B, L, generator=torch.Generator().manual_seed(300 + seed)) / math.sqrt(L)
+    lat0[-1] *= 1.7 / lat0[-1].norm()                    # one row above the max-norm bound
+    st64 = orc.TrainState.create({k: v.double() for k, v in params.items()}, lat0.double())
+    idx, xyz, gt = _safe_batch(net, st64, B, S, 400 + seed, 0.1, 1.0, 77, G=G)
+    r64 = orc.train_step(net, st64, idx, xyz.double(), gt.double(), delta=0.1, code_bound=1.0, epoch=130, seed=77, batch_split=c["split"])
+    for kw in ({}, dict(force_ragged=True)):
+        tr = HipTrainer(spec, params, lat0)
+        rh = tr.step(idx, xyz, gt, delta=0.1, code_bound=1.0, code_reg=True, lam=1e-4, epoch=130, lr=(5e-4, 1e-3), seed=77,
+                     batch_split=c["split"], **kw)
+        what = (seed, c, kw, family)
+        assert abs(rh["loss"] - r64["loss"]) <= 1e-5 * abs(r64["loss"]), what
+        for k in r64["grads"]:
+            assert rel_err(rh["grads"][k], r64["grads"][k]) <= GRAD_TOL, (k, what)
+            assert worst_elem(rh["grads"][k], r64["grads"][k]) <= GRAD_ELEM_TOL, (k, what)
+        assert rel_err(rh["dlat"], r64["dlat"]) <= GRAD_TOL, what
+        P = tr.params()
+        for k in st64.params:
+            assert rel_err(P[k], st64.params[k]) <= 5e-5, (k, what)      # (tiny batches: gradient entries near Adam's eps, see one_long_scene)
+        assert rel_err(tr.lat.cpu(), st64.latents) <= 5e-5, what
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_specs_gemm_split_vs_oracle(seed):
+    """The same random decoders with NetworkSpecs gemm_split (the fused kernels' hidden GEMMs as 6 bf16 MFMAs on 3-way cut fp32
+    operands): its k-loops are kernels of their own (woven asm for four n-tiles per wave, compiler-scheduled for fewer), so they
+    get their own walk over widths, skips and batch shapes -- with the fp32 tolerances, as everywhere for this mode."""
+    c = _random_case(200 + seed)
+    L, B, S, G = c["L"], c["B"], c["S"], c["net"]["geom_dimension"]
+    net = orc.make_net(L, **c["net"])
+    spec = spec_from_meta(dict(L=L, net_specs=dict(c["net"], gemm_split=True)))
+    assert spec.gemm_split
+    params = orc.init_params(net, 210 + seed)
+    lat0 = torch.randn(B, L, generator=torch.Generator().manual_seed(310 + seed)) / math.sqrt(L)
+    st64 = orc.TrainState.create({k: v.double() for k, v in params.items()}, lat0.double())
+    idx, xyz, gt = _safe_batch(net, st64, B, S, 410 + seed, 0.1, 1.0, 78, G=G)
+    r64 = orc.train_step(net, st64, idx, xyz.double(), gt.double(), delta=0.1, code_bound=1.0, epoch=130, seed=78, batch_split=c["split"])
+    for kw in ({}, dict(force_ragged=True)):
+        tr = HipTrainer(spec, params, lat0)
+        rh = tr.step(idx, xyz, gt, delta=0.1, code_bound=1.0, code_reg=True, lam=1e-4, epoch=130, lr=(5e-4, 1e-3), seed=78,
+                     batch_split=c["split"], **kw)
+        what = (seed, c, kw)
+        assert abs(rh["loss"] - r64["loss"]) <= 1e-5 * abs(r64["loss"]), what
+        for k in r64["grads"]:
+            assert rel_err(rh["grads"][k], r64["grads"][k]) <= GRAD_TOL, (k, what)
+        assert rel_err(rh["dlat"], r64["dlat"]) <= GRAD_TOL, what
 
 
 _CONFIG5 = {}
