@@ -113,6 +113,8 @@ int validate(const DsdfNet* n) {
   }
   if ((n->latent_dropout || n->xyz_in_all || n->ln_param_mask) && n->fwd_bf16)
     return fail(DSDF_E_INVALID, "fwd_bf16 is not available with latent_dropout / xyz_in_all / LayerNorm");
+  if (n->fwd_bf16 && ((n->skip_mask >> (n->n_layers - 1)) & 1))   // the bf16 kernels' output layer is a dot product over the activations only
+    return fail(DSDF_E_INVALID, "fwd_bf16 is not available when latent_in names the output layer");
   if (n->gemm_split) {
     if (n->latent_dropout || n->xyz_in_all || n->ln_param_mask)
       return fail(DSDF_E_INVALID, "gemm_split is not available with latent_dropout / xyz_in_all / LayerNorm");

@@ -62,6 +62,10 @@ class NetSpec:
             raise NotImplementedError("xyz_in_all needs geom_dimension <= 4")
         if (self.xyz_in_all or self.latent_dropout or layer_norm) and self.forward_bf16:
             raise NotImplementedError("forward_bf16 is not available with xyz_in_all / latent_dropout / LayerNorm")
+        if self.forward_bf16 and len(self.dims) + 0 in [int(k) for k in (latent_in or ())]:
+            # (layer index len(dims) is the output Linear: the bf16 kernels fold it into the last hidden layer's epilogue as a dot
+            # product over the activations only)
+            raise NotImplementedError("forward_bf16 is not available when latent_in names the output layer")
         if self.gemm_split and (self.xyz_in_all or self.latent_dropout or layer_norm or max(self.dims) > 512
                                 or self.latent_size + self.geom_dimension > 512):
             if gemm_split:      # asked for explicitly

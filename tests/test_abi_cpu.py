@@ -88,6 +88,13 @@ def test_invalid_nets_rejected(lib):
     from deepsdf_amd.net import NetSpec
     with pytest.raises(NotImplementedError):
         NetSpec(4, [32] * 2, 3, xyz_in_all=True, forward_bf16=True)
+    with pytest.raises(NotImplementedError, match="output layer"):      # config 5's kernels: the output layer sees activations only
+        NetSpec(4, [32] * 2, 3, latent_in=[2], forward_bf16=True)
+    last_skip = NetSpec(4, [32] * 2, 3, latent_in=[2]).c_struct()          # fine in fp32 ...
+    bq = C.c_size_t()
+    assert lib.dsdf_workspace_bytes(C.byref(last_skip), 8, 1, C.byref(bq)) == 0
+    last_skip.fwd_bf16 = 1                                                  # ... refused by the library too
+    assert lib.dsdf_workspace_bytes(C.byref(last_skip), 8, 1, C.byref(bq)) == -1 and b"output layer" in lib.dsdf_last_error()
     ln = NetSpec(4, [32] * 2, 3, norm_layers=[0, 2], weight_norm=False)    # LayerNorm variant: bn modules, also the unused last one
     assert [p.name for p in ln.params] == ["lin0.weight", "lin0.bias", "bn0.weight", "bn0.bias", "lin1.weight", "lin1.bias",
                                            "lin2.weight", "lin2.bias", "bn2.weight", "bn2.bias"]
