@@ -86,6 +86,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 constexpr int NSPLIT_MAX = 32;     // split-K factor of the dW GEMMs
 constexpr int LAST_BLOCKS_MAX = 1024;
+constexpr int LAT_SLICES_MAX = 8;   // partial copies of the per-segment latent gradient (SegLatArgs.nslice)
 constexpr int LAST_GROUPS = 16;    // second-stage partial groups of the last-layer reduction
 constexpr int LN_BLOCKS = 256;     // LayerNorm backward: fixed grid = fixed summation order of its column partials
 
@@ -377,7 +378,7 @@ Plan make_plan(const DsdfNet* n, int64_t N, int64_t R, bool inference, bool segm
   P.part2_off = take((size_t)LAST_GROUPS * P.ld_part * 4);
   P.partdb_off = take(part_rows * 4);
   P.partloss_off = take(part_rows * 4);
-  P.segpart_off = take((size_t)(R > 0 ? R : 1) * (n->latent_size > 0 ? n->latent_size : 1) * 4);
+  P.segpart_off = take((size_t)LAT_SLICES_MAX * (R > 0 ? R : 1) * (n->latent_size > 0 ? n->latent_size : 1) * 4);   // (up to 8 partial copies)
   P.segnorm_off = take((size_t)(R > 0 ? R : 1) * 4);
   P.gnorm_off = take(1024 * 4);
   P.nwg = (int)((N + frows - 1) / frows);
@@ -879,7 +880,7 @@ struct FuseAdam { const DsdfAdamCfg* cfg; float* params; float* exp_avg; float* 
 // dX chain (writes every dP_l, column sums, latent-gradient inputs), then dW (split-K) + finalize per layer.
 // Segment mode (sb != nullptr): what the weight gradients of the hoisted layers need from the batch
 struct SegBwd { const FusedSeg* seg; const int64_t* seg_scene; const float* table; int R;
-                const ScatterArgs* scatter; bool* scatter_done;
+                ScatterArgs* scatter; bool* scatter_done;       // (scatter->nslice is set here: the latent role decides it)
                 const float* zr; };   // the segments' renormed latent rows (run_hoist), or nullptr: read table[seg_scene[r]]   // the dense latent-gradient scatter may ride on the finalize launch
 
 int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float* packed, const float* params, int64_t n,
@@ -967,7 +968,7 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
   // the workgroups the dW launch leaves idle, or by a launch of its own when there is no dW launch / no idle workgroup
   PostBwdArgs q;
   memset(&q, 0, sizeof(q));
-  int lat_n = 0;
+  int lat_n = 0, lat_slices = 1;
   if (segmode) {
     if (want_dw) {
       q.rr = rr; q.rr_bx = rr_bx; q.rr_n = rr_bx * LAST_GROUPS;
@@ -992,8 +993,16 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     g.seg_scene = sb->seg_scene; g.table = sb->table; g.zr = sb->zr;
     g.segpart = at<float>(ws, P.segpart_off); g.segnorm = at<float>(ws, P.segnorm_off);
     q.lat_bx = sb->R;
-    lat_n = sb->R * ((net->latent_size + 15) / 16);
+    g.nchunk = (net->latent_size + 15) / 16;
+    lat_n = sb->R * g.nchunk;
+    // few long segments in a launch of their own (config 4: one shape): cut each segment's workgroups into slices so that the launch
+    // has blocks for the chip; the scatter adds the slices
+    g.nslice = 1; g.slice_stride = (long long)sb->R * net->latent_size;
+    while (g.nslice < LAT_SLICES_MAX && lat_n * g.nslice * 2 <= chip_waves() / 4 && g.wg_per_seg / (g.nslice * 2) >= 16) g.nslice *= 2;
+    lat_n *= g.nslice;
+    lat_slices = g.nslice;
   }
+  auto tell_scatter = [&]() { if (segmode && sb->scatter != nullptr) { sb->scatter->nslice = lat_slices; sb->scatter->slice_stride = (long long)sb->R * net->latent_size; } };
   const int cus = chip_waves() / 4;
   const int dw_items = DS.n_full + DS.n_narrow;
   const int dw_busy = want_dw ? ((dw_items + 3) / 4 < cus ? (dw_items + 3) / 4 : cus) : 0;
@@ -1010,10 +1019,13 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
   const bool post_rides = segmode && want_dw && cus - dw_busy >= 8 && P.nwg <= cus && !no_ride && !net->gemm_split && phase <= 1 &&
                           dw_items > 0;
   if (post_rides) {   // the few-workgroups forms: 32 weight-gradient rows per block, one latent-gradient block per 16 columns
+    q.lat.nslice = 1; lat_slices = 1;
     q.lat_bx = 0;
     lat_n = (net->latent_size + 15) / 16;
+    q.rr_n = q.rr_bx;               // one block per 64-column strip of the head's partials takes all groups (reduce_rows_strip_body)
     q.dw_n = (q.dw.out[0] + SDW_ROWS_RIDE - 1) / SDW_ROWS_RIDE + (ks > 0 ? (q.dw.out[1] + SDW_ROWS_RIDE - 1) / SDW_ROWS_RIDE : 0);
   }
+  tell_scatter();
   if (segmode && !post_rides && phase <= 1) {
     hipLaunchKernelGGL(post_bwd_kernel, dim3((unsigned)(q.rr_n + q.dw_n + lat_n)), dim3(256), 0, st, q, lat_n);
     LAUNCH_OK("post_bwd_kernel");

@@ -933,12 +933,19 @@ struct SegLatArgs {
   const int64_t* seg_scene; const float* table;
   const float* zr;                                                         // non-null: segment r's latent row is zr + r L
   float* segpart; float* segnorm;
+  // launch-of-its-own form, few long segments (config 4: ONE shape of 250 workgroups): the segment's workgroups are cut into nslice
+  // ranges, block (bx, by = chunk + nchunk * slice) writes the partial products of its range to segpart + slice * slice_stride, and
+  // seg_scatter_body adds the slices in order -- 8 x the blocks for a launch that had 16 of them on 256 CUs
+  int nslice, nchunk; long long slice_stride;
 };
 constexpr int SLAT_LDS_FLOATS = 2 * FSEG_MAXW + 16 * 17;
 __device__ __forceinline__ void seg_latgrad_body(const SegLatArgs& p, int bx, int by, float* lds) {
   // (bx, by) in (R, ceil(L/16)); block = 16 columns x 16 k-slices: 1024+ blocks of short dot products instead of 256 long ones
   float (*ss)[FSEG_MAXW] = reinterpret_cast<float (*)[FSEG_MAXW]>(lds);
   float (*red)[17] = reinterpret_cast<float (*)[17]>(lds + 2 * FSEG_MAXW);
+  const int nsl = p.nslice > 1 ? p.nslice : 1, slice = nsl > 1 ? by / p.nchunk : 0;
+  if (nsl > 1) by -= slice * p.nchunk;
+  const int gper = (p.wg_per_seg + nsl - 1) / nsl, gbeg = min(slice * gper, p.wg_per_seg), gend = min(gbeg + gper, p.wg_per_seg);
   const int r = bx, c0 = by * 16, tid = threadIdx.x, cx = tid & 15, ks = tid >> 4;
   // a segment's column sums = the sum of its workgroups' column sums, in workgroup order.  The loads go out 32 at a time (the adds
   // keep their order, so the result bits do not change): one load per add left a 256-workgroup segment -- one scene x 16384
@@ -946,15 +953,15 @@ __device__ __forceinline__ void seg_latgrad_body(const SegLatArgs& p, int bx, in
   auto seg_colsum = [&](const float* cs, int j) {
     const float* q = cs + (size_t)r * p.wg_per_seg * p.ldcs + j;
     float s = 0.f;
-    int g = 0;
-    for (; g + 32 <= p.wg_per_seg; g += 32) {
+    int g = gbeg;
+    for (; g + 32 <= gend; g += 32) {
       float t[32];
 #pragma unroll
       for (int u = 0; u < 32; ++u) t[u] = q[(size_t)(g + u) * p.ldcs];
 #pragma unroll
       for (int u = 0; u < 32; ++u) s += t[u];
     }
-    for (; g < p.wg_per_seg; ++g) s += q[(size_t)g * p.ldcs];
+    for (; g < gend; ++g) s += q[(size_t)g * p.ldcs];
     return s;
   };
   for (int j = tid; j < p.out0; j += 256) ss[0][j] = seg_colsum(p.cs0, j);
@@ -986,9 +993,9 @@ __device__ __forceinline__ void seg_latgrad_body(const SegLatArgs& p, int bx, in
     float s = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) s += red[q][cx];
-    p.segpart[(size_t)r * p.L + col] = s;
+    p.segpart[(size_t)slice * p.slice_stride + (size_t)r * p.L + col] = s;
   }
-  if (by == 0 && tid < 64) {
+  if (by == 0 && slice == 0 && tid < 64) {
     const float* row = p.zr != nullptr ? p.zr + (size_t)r * p.L : p.table + (size_t)p.seg_scene[r] * p.L;
     float q = 0.f;
     for (int c = tid; c < p.L; c += 64) { const float v = row[c]; q += v * v; }
@@ -1035,25 +1042,21 @@ __device__ __forceinline__ void seg_latgrad_all_body(const SegLatArgs& p, int by
         const bool iok = i0 + li < n;
         const float* qs = cs + (size_t)s0 * wps * p.ldcs + min(i0 + li, n - 1);   // workgroup row wg of this group: qs + wg ldcs
         const int lastwg = ng * wps - 1;
-        if (!sliced) {      // thread (lq, li): segments sl = lq, lq + 4, ...; each one's workgroups in order; flat batches of 32 loads
-          const int mine = lq < ng ? (ng - lq + 3) >> 2 : 0, total = mine * wps;
-          int sl = lq, g = 0;
+        if (!sliced) {      // thread (lq, li): a CONTIGUOUS quarter of the segments, i.e. consecutive workgroup rows: flat batches of 32
+          const int mq = (ng + 3) >> 2, sfirst = min(lq * mq, ng), mine = min(mq, ng - sfirst), total = mine * wps;
+          const int off0 = sfirst * wps * p.ldcs, offlast = lastwg * p.ldcs;      // (32-bit offsets: at most 256 workgroup rows)
+          int sl = sfirst, g = 0;
           float a = 0.f;
           for (int e0 = 0; e0 < total; e0 += 32) {
             float tv[32];
-            {
-              int sl2 = sl, g2 = g;
 #pragma unroll
-              for (int u = 0; u < 32; ++u) {     // (unconditional loads: past the end a lane re-reads its last valid workgroup row)
-                tv[u] = qs[(size_t)min(sl2 * wps + g2, lastwg) * p.ldcs];
-                if (++g2 == wps) { g2 = 0; sl2 += 4; }
-              }
-            }
+            for (int u = 0; u < 32; ++u)         // (unconditional loads: past the end a lane re-reads the group's last workgroup row)
+              tv[u] = qs[min(off0 + (e0 + u) * p.ldcs, offlast)];
 #pragma unroll
             for (int u = 0; u < 32; ++u) {
               if (e0 + u < total) {
                 a += iok ? tv[u] : 0.f;
-                if (++g == wps) { css[sl][li] = a; a = 0.f; g = 0; sl += 4; }
+                if (++g == wps) { css[sl][li] = a; a = 0.f; g = 0; ++sl; }
               }
             }
           }
@@ -1128,6 +1131,39 @@ __device__ __forceinline__ void reduce_rows_body(const ReduceRowsArgs& a, int bx
     a.out[(size_t)g * a.ld + c] = (red[0][x] + red[1][x]) + (red[2][x] + red[3][x]);
   }
 }
+// The same for ALL groups of a 64-column strip in one block (the riding form: a sixteenth of the blocks, every load of a thread --
+// its column of 4 rows per group x G groups -- in flight at once; groups of at most 16 rows, i.e. P <= 16 G, else the loop form above)
+__device__ __forceinline__ void reduce_rows_strip_body(const ReduceRowsArgs& a, int bx, float* lds) {
+  float (*red)[64] = reinterpret_cast<float (*)[64]>(lds);
+  const int x = threadIdx.x & 63, c = bx * 64 + x, ry = threadIdx.x >> 6;
+  const int cc = min(c, a.n - 1);
+  for (int g0 = 0; g0 < a.G; g0 += 16) {
+    float t[16][4];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int g = min(g0 + u, a.G - 1);
+      const int beg = (int)((long long)g * a.P / a.G), end = (int)((long long)(g + 1) * a.P / a.G);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t[u][k] = a.part[(size_t)min(beg + ry + 4 * k, a.P - 1) * a.ld + cc];
+      (void)end;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (g0 + u < a.G) {                         // (block-uniform)
+        const int g = g0 + u;
+        const int beg = (int)((long long)g * a.P / a.G), end = (int)((long long)(g + 1) * a.P / a.G);
+        float sm = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sm += beg + ry + 4 * k < end ? t[u][k] : 0.f;      // rows beg + ry, + 4, ...: reduce_rows_body's order
+        for (int r = beg + ry + 16; r < end; r += 4) sm += a.part[(size_t)r * a.ld + cc];   // (groups longer than 16 rows)
+        __syncthreads();
+        red[ry][x] = sm;
+        __syncthreads();
+        if (ry == 0 && c < a.n) a.out[(size_t)g * a.ld + c] = (red[0][x] + red[1][x]) + (red[2][x] + red[3][x]);
+      }
+    }
+  }
+}
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const ReduceRowsArgs a) {
   __shared__ float red[4 * 64];
   reduce_rows_body(a, blockIdx.x, blockIdx.y, red);
@@ -1148,7 +1184,11 @@ static_assert(ROLE_LDS_FLOATS >= SLAT_LDS_FLOATS && ROLE_LDS_FLOATS >= 4 * 64, "
 // The riding form is a NOINLINE call: inlined into the dW kernels its register needs leaked into their k-loops' allocation.
 template <bool RIDE>
 __device__ __forceinline__ void post_bwd_role(const PostBwdArgs& p, int i, int lat_n, float* lds) {
-  if (i < p.rr_n) { reduce_rows_body(p.rr, i % p.rr_bx, i / p.rr_bx, lds); return; }
+  if (i < p.rr_n) {
+    if constexpr (RIDE) reduce_rows_strip_body(p.rr, i, lds);      // (riding: rr_n = rr_bx strips, every group in one block)
+    else reduce_rows_body(p.rr, i % p.rr_bx, i / p.rr_bx, lds);
+    return;
+  }
   i -= p.rr_n;
   if (i < p.dw_n) { seg_dw_body<RIDE ? SDW_ROWS_RIDE : SDW_ROWS_WIDE>(p.dw, i, lds); return; }
   i -= p.dw_n;
@@ -1170,6 +1210,7 @@ __global__ __launch_bounds__(256) void post_bwd_kernel(const PostBwdArgs p, cons
 struct ScatterArgs {
   const float* segpart; const float* segnorm; const int64_t* seg_scene; const int64_t* seg_offset; int R; int L;
   float* table; float* dlat; float creg;
+  int nslice; long long slice_stride;   // segpart comes in nslice partial copies (SegLatArgs), added here in order; <= 1: one
   const float* zr;             // non-null (segment-mode training steps): segment r's renormed latent row (seg_hoist_kernel); the owner
                                // block of a scene writes it back into the table here -- the in-place embedding_renorm_ of the step
   // block 0: loss_out (+)= sum(part_loss[0..n_part)) * loss_scale + regulariser loss
@@ -1206,6 +1247,7 @@ __device__ __forceinline__ void seg_scatter_body(const ScatterArgs& p, int r) {
     for (int q = r; q < p.R; ++q) {
       if (q != r && p.seg_scene[q] != j) continue;
       float v = p.segpart[(size_t)q * p.L + c];
+      for (int sl = 1; sl < p.nslice; ++sl) v += p.segpart[(size_t)sl * p.slice_stride + (size_t)q * p.L + c];
       if (p.creg != 0.f) {
         const float nrm = p.segnorm[q];
         if (nrm > 0.f) v += p.creg * (float)(p.seg_offset[q + 1] - p.seg_offset[q]) * z / nrm;
