@@ -1615,7 +1615,13 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
   s.seg_scene = b->seg_scene; s.seg_offset = b->seg_offset; s.R = (int)R; s.L = Lc; s.table = latent_table;
   s.segpart = at<float>(ws, P.segpart_off); s.segnorm = at<float>(ws, P.segnorm_off);
   if (!segsum) {   // (segment mode: per-segment latent gradients came out of post_bwd_kernel)
-    hipLaunchKernelGGL(seg_reduce_kernel, dim3((unsigned)R, (Lc + 63) / 64), dim3(256), 0, st, s);
+    // few long segments: cut their rows into slices until the launch has blocks for the chip (the scatter adds the slices)
+    int nsl = 1;
+    const long long blocks = (long long)R * ((Lc + 63) / 64);
+    while (nsl < LAT_SLICES_MAX && blocks * nsl * 2 <= chip_waves() / 4 && n / (R * (int64_t)nsl * 2) >= 128) nsl *= 2;
+    s.nslice = nsl; s.slice_stride = (long long)R * Lc;
+    sc.nslice = nsl; sc.slice_stride = s.slice_stride;
+    hipLaunchKernelGGL(seg_reduce_kernel, dim3((unsigned)R, (Lc + 63) / 64, (unsigned)nsl), dim3(256), 0, st, s);
     LAUNCH_OK("seg_reduce_kernel");
   }
   if (!scatter_done) {

@@ -892,27 +892,37 @@ struct SegArgs {
   const float* dzA; const float* dzB; int ldz;   // dzB may be null
   const int64_t* seg_scene; const int64_t* seg_offset; int R; int L;
   const float* table;
-  float* segpart;   // [R][L]
+  float* segpart;   // [R][L]  (nslice > 1: nslice partial copies slice_stride apart, one per blockIdx.z; seg_scatter_body adds them)
   float* segnorm;   // [R]
+  int nslice; long long slice_stride;
 };
 __global__ __launch_bounds__(256) void seg_reduce_kernel(const SegArgs p) {
   __shared__ float red[4][64];
   const int r = blockIdx.x, c0 = blockIdx.y * 64;
   const int tid = threadIdx.x, cx = tid & 63, ry = tid >> 6;
-  const int64_t beg = p.seg_offset[r], end = p.seg_offset[r + 1];
-  const int col = c0 + cx;
+  // a long segment (config 4 off the workgroup grid: ONE shape of 8001 points was 4 blocks walking 2000 dependent loads each, 0.6 ms)
+  // is cut into gridDim.z row ranges; 8 rows per thread in flight, clamped addresses
+  const int64_t sbeg = p.seg_offset[r], send = p.seg_offset[r + 1];
+  const int64_t per = (send - sbeg + gridDim.z - 1) / gridDim.z;
+  const int64_t beg = min(sbeg + (int64_t)blockIdx.z * per, send), end = min(beg + per, send);
+  const int col = c0 + cx, cc = min(col, p.L - 1);
   float s = 0.f;
-  if (col < p.L) {
-    for (int64_t n = beg + ry; n < end; n += 4) {
-      float v = p.dzA[(size_t)n * p.ldz + col];
-      if (p.dzB) v += p.dzB[(size_t)n * p.ldz + col];
-      s += v;
+  for (int64_t n = beg + ry; n < end; n += 32) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t m = min(n + 4 * u, end - 1);
+      t[u] = p.dzA[(size_t)m * p.ldz + cc];
+      if (p.dzB) t[u] += p.dzB[(size_t)m * p.ldz + cc];
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += n + 4 * u < end ? t[u] : 0.f;
   }
   red[ry][cx] = s;
   __syncthreads();
-  if (ry == 0 && col < p.L) p.segpart[(size_t)r * p.L + col] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
-  if (blockIdx.y == 0 && tid < 64) {
+  if (ry == 0 && col < p.L)
+    p.segpart[(size_t)blockIdx.z * p.slice_stride + (size_t)r * p.L + col] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+  if (blockIdx.y == 0 && blockIdx.z == 0 && tid < 64) {
     const float* row = p.table + (size_t)p.seg_scene[r] * p.L;
     float ss = 0.f;
     for (int c = tid; c < p.L; c += 64) { const float v = row[c]; ss += v * v; }
