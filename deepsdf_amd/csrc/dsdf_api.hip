@@ -238,7 +238,9 @@ int dw_cols(const DsdfNet* n, int l, bool segmode) {
 }
 // Layers [l0, l1) only (the others get no items): the two-phase backward of a data-parallel step (DsdfLossCfg.dw_phase) schedules
 // each half of the layers so that it fills the chip by itself.
-DwSched dw_schedule(const DsdfNet* n, int64_t N, const int* ld_in, bool segmode, int l0 = 0, int l1 = DSDF_MAX_LAYERS) {
+// reserve: waves the K-split leaves free on purpose -- phase 1 of a phased backward in segment mode keeps 16 workgroups for the riding
+// post-backward roles (without them the roles are a launch of their own: +21 us per step)
+DwSched dw_schedule(const DsdfNet* n, int64_t N, const int* ld_in, bool segmode, int l0 = 0, int l1 = DSDF_MAX_LAYERS, int reserve = 0) {
   DwSched S;
   memset(&S, 0, sizeof(S));
   const int nh = n->n_layers - 1;
@@ -258,7 +260,8 @@ DwSched dw_schedule(const DsdfNet* n, int64_t N, const int* ld_in, bool segmode,
   // full-width tiles (every layer narrower than 128: the reference's shipped 4 x 64 / 4 x 32 specs) is split by its narrow items
   // instead -- round 3 left such nets at ONE split, i.e. one wave contracting all the points of a layer.
   const int Tsplit = Tfull > 0 ? Tfull : Tnarrow;
-  int ns = Tsplit > 0 && chip_waves() / Tsplit > 0 ? chip_waves() / Tsplit : 1;
+  const int waves = chip_waves() - reserve > 0 ? chip_waves() - reserve : chip_waves();
+  int ns = Tsplit > 0 && waves / Tsplit > 0 ? waves / Tsplit : 1;
   const int maxsplit = N / 64 > 0 ? (int)(N / 64) : 1;
   if (ns > maxsplit) ns = maxsplit;
   int kchunk = (int)rup((N + ns - 1) / ns, 2);
@@ -390,7 +393,11 @@ Plan make_plan(const DsdfNet* n, int64_t N, int64_t R, bool inference, bool segm
   P.dw = dw_schedule(n, N, P.ld_in, segmode);
   P.dw_nb = nb < 2 ? 2 : (nb > DSDF_MAX_BUCKETS ? DSDF_MAX_BUCKETS : nb);
   dw_bucket_cuts(n, P.dw_nb, P.dw_cut);
-  for (int t = 0; t < P.dw_nb; ++t) P.dwph[t] = dw_schedule(n, N, P.ld_in, segmode, P.dw_cut[t + 1], P.dw_cut[t]);
+  for (int t = 0; t < P.dw_nb; ++t)
+    // (two buckets only: the riding roles take ~180 us, a bucket's launch must be at least that long or they become its tail --
+    // measured: K = 2 1.3100 -> 1.3032 ms/step with the reserve, K = 4 1.3776 -> 1.4116)
+    P.dwph[t] = dw_schedule(n, N, P.ld_in, segmode, P.dw_cut[t + 1], P.dw_cut[t],
+                            t == 0 && P.dw_nb == 2 && segmode && P.nwg <= chip_waves() / 4 ? 64 : 0);
   for (int l = 0; l < P.nl - 1; ++l) {   // slabs sized for whichever schedule splits K finest: the layout does not depend on the phase
     int ns = P.dw.nsplit[l];
     for (int t = 0; t < P.dw_nb; ++t)
