@@ -947,6 +947,13 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
     for (int l = 0; l < last; ++l) amac += (double)net->in_dim[l] * net->out_dim[l];
     (void)wmac;
     if (fwd != nullptr) {
+#ifdef DSDF_LAB
+      // lab: stamps of the MERGED launch (forward slots 0.., backward slots 32..), dumped after every launch
+      static unsigned long long* mdbg = nullptr;
+      FusedFwdArgs fwd_l = *fwd;
+      if (!mdbg && getenv("DSDF_LAB_MDBG")) { (void)hipMalloc(&mdbg, 8192 * 64 * 8); }
+      if (mdbg) { (void)hipMemsetAsync(mdbg, 0, 8192 * 64 * 8, st); fwd_l.dbg = mdbg; a.dbg = mdbg; fwd = &fwd_l; }
+#endif
       ProfScope ps(DSDF_PROF_FUSED_FWD_BWD, 4.0 * (double)n * amac, st);   // forward + dX chain
       if (net->fwd_bf16 && net->gemm_split) hipLaunchKernelGGL(fused_fwd_bf16_bwd_split_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
       else if (net->fwd_bf16) hipLaunchKernelGGL(fused_fwd_bf16_bwd_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
@@ -955,6 +962,15 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
       else if (net_narrow(net)) hipLaunchKernelGGL(fused_fwd_bwd_n128_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
       else hipLaunchKernelGGL(fused_fwd_bwd_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
       LAUNCH_OK("fused_fwd_bwd_kernel");
+#ifdef DSDF_LAB
+      if (mdbg && getenv("DSDF_LAB_MDBG")) {
+        (void)hipDeviceSynchronize();
+        static unsigned long long h[8192 * 64];
+        (void)hipMemcpy(h, mdbg, sizeof(h), hipMemcpyDeviceToHost);
+        FILE* f = fopen(getenv("DSDF_LAB_MDBG"), "wb");
+        if (f) { fwrite(h, 1, sizeof(h), f); fclose(f); }
+      }
+#endif
     } else {
       ProfScope ps(DSDF_PROF_FUSED_BWD, 2.0 * (double)n * amac, st);
       if (P.frows != FROWS) return fail(DSDF_E_LAUNCH, "internal: the separate backward kernel has 64-row workgroups only");

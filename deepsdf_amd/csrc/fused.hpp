@@ -122,6 +122,22 @@ __device__ __forceinline__ void fused_load_x0(float* S, const float* x0, int ldx
 // C-layout rows of a 32x32 MFMA tile held by one lane: reg -> (reg & 3) + 8 (reg >> 2) (+ 4 * (lane >> 5))
 __device__ __forceinline__ constexpr int crow(int reg) { return (reg & 3) + 8 * (reg >> 2); }
 
+// Narrow-net kernels (NT = 1, MT = 2: every layer has at most 4 n-tiles).  With one n-tile per wave a 32-wide layer would be the work of
+// wave 0 alone and a 64-wide one of waves 0-1 -- and a lone wave issues one vector instruction every 4 cycles, so the layer takes as
+// long as that wave's instruction stream (stamps: a 32-wide layer = 2.6-4.5 k cycles of k-loop + 4.1-4.7 k of epilogue, 2 k of them
+// MFMA).  Layers of one or two n-tiles are therefore split by ROWS as well: wave w owns tile (n-tile nt, m-tile mo) -- two waves busy on
+// a 32-wide layer, all four on a 64-wide one.  Wider layers keep (n-tile w, both m-tiles).
+struct NarrowTile { int nt, mo; bool split, active; };
+__device__ __forceinline__ NarrowTile narrow_tile(int ncols, int w) {
+  const int ntl = (ncols + 31) >> 5;
+  NarrowTile t;
+  t.split = ntl <= 2;
+  if (ntl <= 1) { t.nt = 0; t.mo = w & 1; t.active = w < 2; }
+  else if (ntl == 2) { t.nt = w & 1; t.mo = w >> 1; t.active = true; }
+  else { t.nt = w; t.mo = 0; t.active = w < ntl; }
+  return t;
+}
+
 // Forward epilogue of one wave: bias + ReLU (+ dropout) on its 2x4 accumulators, written to the LDS slab (next
 // layer's input) and to the global activation copy.  Lean by construction: global stores are buffer stores (hardware
 // bounds check drops rows >= N and masked columns; row offsets are SCALAR), LDS stores use immediate offsets.
@@ -134,7 +150,7 @@ constexpr int FLDH = 520;        // slab row stride in bf16 elements (bf16 forwa
 template <bool DROP, bool EVEN, bool HS = false, int MT = 2, int NT = 4, int LDSW = FLD>
 __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[MT][NT], const float (&biasv)[NT], float* S,
                                                    const FusedLayer& L, int w, int fr, int fh, int row0, int N,
-                                                   uint32_t row_offset) {
+                                                   uint32_t row_offset, int mo = 0) {   // mo: MT = NT = 1 (a NarrowTile): its m-tile
   const int rows_here = min(32 * MT, N - row0);
   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       L.out != nullptr ? (void*)(L.out + (size_t)row0 * L.ld_out) : (void*)S, 0,
@@ -194,8 +210,12 @@ __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[MT][NT], 
     mq[0 + (ni >> 1)] |= mb[0] << (16 * (ni & 1));
     mq[2 + (ni >> 1)] |= mb[1] << (16 * (ni & 1));
   }
-  if (L.maskbits != nullptr)
-    *reinterpret_cast<uint4*>(L.maskbits + ((size_t)blockIdx.x * 256 + threadIdx.x) * 4) = make_uint4(mq[0], mq[1], mq[2], mq[3]);
+  if (L.maskbits != nullptr) {
+    if constexpr (MT == 1 && NT == 1)    // a NarrowTile: the word thread (wave nt, lane) of the whole-rows form keeps for m-tile mo
+      L.maskbits[((size_t)blockIdx.x * 256 + w * 64 + fr + 32 * fh) * 4 + 2 * mo] = mq[0];
+    else
+      *reinterpret_cast<uint4*>(L.maskbits + ((size_t)blockIdx.x * 256 + threadIdx.x) * 4) = make_uint4(mq[0], mq[1], mq[2], mq[3]);
+  }
 }
 
 // Optional (lab: -DFUSED_ROTATE=1): every workgroup walks the k-units of a layer in its own rotated order, so that the CUs
@@ -869,7 +889,14 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
 
   typename KlSets<SPLIT, NT>::type PB;
   const int lfirst = (segm && p.n_hidden > 1) ? 1 : 0;   // first layer with an MFMA pass (segment mode: layer 0 has none)
-  kl_prefetch<SPLIT, NT>(PB, p.ly[lfirst].wf, p.ly[lfirst].wplane, p.ly[lfirst].wf32, p.ly[lfirst].U, w, lane, fused_nact(p.ly[lfirst].out_dim, w), (p.ly[lfirst].in + 15) >> 4);
+  // (narrow kernels: the tile owner of a layer depends on its width -- narrow_tile)
+  auto tile_w = [&](int ncols) { if constexpr (NT == 1 && MT == 2) return narrow_tile(ncols, w).nt; else return w; };
+  auto tile_n = [&](int ncols) { if constexpr (NT == 1 && MT == 2) return narrow_tile(ncols, w).active ? 1 : 0; else return fused_nact(ncols, w); };
+  // the next layer's first weights are requested while this layer's epilogue has not stored yet
+  auto prefetch_layer = [&](const FusedLayer& Ln) {
+    kl_prefetch<SPLIT, NT>(PB, Ln.wf, Ln.wplane, Ln.wf32, Ln.U, tile_w(Ln.out_dim), lane, tile_n(Ln.out_dim), (Ln.in + 15) >> 4);
+  };
+  prefetch_layer(p.ly[lfirst]);
   if (segm) {
     if (tid < ROWS) {
       float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -921,6 +948,47 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
     }
     int hidx = -1;
     if (segm) hidx = l == p.seg.h[0].layer ? 0 : (l == p.seg.h[1].layer ? 1 : -1);
+    if constexpr (NT == 1 && MT == 2) {
+      const NarrowTile T = narrow_tile(L.out_dim, w);
+      if (T.split) {      // one or two n-tiles: this wave's tile is (T.nt, T.mo) -- one m-tile
+        f32x16 a1[1][1];
+        float b1[1];
+        b1[0] = 32 * T.nt + fr < L.out_dim ? L.bias[32 * T.nt + fr] : 0.f;
+        float* Sm = S + 32 * T.mo * LDSW;
+        if (hidx >= 0 && T.active) {
+          fused_hoist_init<1, 1>(a1, hu[hidx], hwx[hidx], xs + 32 * T.mo, L.out_dim, T.nt, fr, fh);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) a1[0][0][r] = 0.f;
+        }
+        if (nu > 0) {
+          fused_kloop_dispatch<SPLIT, 1, 1, LDSW>(a1, Sm + fr * LDSW + 8 * fh, L.wf, L.wplane, L.wf32, L.U, T.nt, lane, nu, T.active ? 1 : 0, PB);
+          if (l + 1 < p.n_hidden) prefetch_layer(p.ly[l + 1]);
+        }
+#ifdef DSDF_LAB
+        if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 1 + 3 * l] = __builtin_amdgcn_s_memtime();
+#endif
+        __syncthreads();
+#ifdef DSDF_LAB
+        if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 2 + 3 * l] = __builtin_amdgcn_s_memtime();
+#endif
+        if (L.x0_col >= 0) fused_load_x0<ROWS, LDSW>(S, p.x0, p.ldx0, p.W0, row0, p.N, L.x0_col);
+        if (T.active) {
+          const int r0 = row0 + 32 * T.mo, n1 = max(p.N, r0);      // (rows_here >= 0)
+          const bool drop = L.drop_thr != 0u;
+          const bool even = ((p.row_offset + (uint32_t)row0) & 1u) == 0u;
+          if (!drop) fused_fwd_epilogue<false, true, false, 1, 1, LDSW>(a1, b1, Sm, L, T.nt, fr, fh, r0, n1, p.row_offset, T.mo);
+          else if (even) fused_fwd_epilogue<true, true, false, 1, 1, LDSW>(a1, b1, Sm, L, T.nt, fr, fh, r0, n1, p.row_offset, T.mo);
+          else fused_fwd_epilogue<true, false, false, 1, 1, LDSW>(a1, b1, Sm, L, T.nt, fr, fh, r0, n1, p.row_offset, T.mo);
+        }
+        fused_zero_pad<ROWS, LDSW>(S, L.x0_col >= 0 ? L.x0_col + p.W0 : L.out_dim);
+        __syncthreads();
+#ifdef DSDF_LAB
+        if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 3 + 3 * l] = __builtin_amdgcn_s_memtime();
+#endif
+        continue;
+      }
+    }
     if (hidx >= 0) {
       fused_hoist_init<MT, NT>(acc, hu[hidx], hwx[hidx], xs, L.out_dim, w, fr, fh);
     } else {
@@ -934,10 +1002,7 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
     const float* ap = S + fr * LDSW + 8 * fh;
     if (nu > 0) {
       fused_kloop_dispatch<SPLIT, MT, NT, LDSW>(acc, ap, L.wf, L.wplane, L.wf32, L.U, w, lane, nu, fused_nact(L.out_dim, w), PB);
-      if (l + 1 < p.n_hidden) {   // next layer's first weights travel while this layer's epilogue runs
-        const FusedLayer& Ln = p.ly[l + 1];
-        kl_prefetch<SPLIT, NT>(PB, Ln.wf, Ln.wplane, Ln.wf32, Ln.U, w, lane, fused_nact(Ln.out_dim, w), (Ln.in + 15) >> 4);
-      }
+      if (l + 1 < p.n_hidden) prefetch_layer(p.ly[l + 1]);   // next layer's first weights travel while this layer's epilogue runs
     }
 #ifdef DSDF_LAB
     if (p.dbg && tid == 0) p.dbg[blockIdx.x * 64 + 1 + 3 * l] = __builtin_amdgcn_s_memtime();
@@ -1406,12 +1471,19 @@ struct FusedBwdArgs {
   const float* xyz; int G;                   // segment mode ([N][G], G <= FGEO), else nullptr
   FusedBwdHead head;
   FusedBwdLayer ly[DSDF_MAX_LAYERS];
+  unsigned long long* dbg;   // lab builds (-DDSDF_LAB): per-workgroup s_memtime stamps (slots 32..: head, then 3 per layer), else unused
 };
+#ifdef DSDF_LAB
+#define FUSED_STAMP(P, SLOT) do { if ((P).dbg && threadIdx.x == 0) (P).dbg[blockIdx.x * 64 + (SLOT)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FUSED_STAMP(P, SLOT) do { } while (0)
+#endif
 
 template <bool XS, int MT = 2, int NT = 4, int LDSW = FLD>
 __device__ __forceinline__ void fused_bwd_epilogue(const f32x16 (&acc)[MT][NT], float* S, const FusedBwdLayer& L, int w, int fr,
-                                                   int fh, int row0, int N, const uint4 mq, const float4* xs) {
-  const int rows_here = min(32 * MT, N - row0);
+                                                   int fh, int row0, int N, const uint4 mq, const float4* xs,
+                                                   float* cs_out = nullptr, float4* cx_out = nullptr) {   // MT = NT = 1 (a NarrowTile): the
+  const int rows_here = min(32 * MT, N - row0);                                                   // column sums go back to the caller
   __amdgpu_buffer_rsrc_t rdp = __builtin_amdgcn_make_buffer_rsrc(
       L.dp_out != nullptr ? (void*)(L.dp_out + (size_t)row0 * L.ld_dp) : (void*)S, 0,
       L.dp_out != nullptr ? rows_here * L.ld_dp * 4 : 0, 0x00020000);
@@ -1452,6 +1524,14 @@ __device__ __forceinline__ void fused_bwd_epilogue(const f32x16 (&acc)[MT][NT], 
         for (int r = 0; r < 16; ++r)
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][ni][r]), rdz, voff, (32 * m + crow(r)) * ldzb, 0);
     }
+    if constexpr (MT == 1 && NT == 1) {     // half of the workgroup's rows: the caller adds the other half's sums
+      cs += __shfl_xor(cs, 32, 64);
+      if constexpr (XS) {
+        cx.x += __shfl_xor(cx.x, 32, 64); cx.y += __shfl_xor(cx.y, 32, 64);
+        cx.z += __shfl_xor(cx.z, 32, 64); cx.w += __shfl_xor(cx.w, 32, 64);
+      }
+      *cs_out = cs; *cx_out = cx;
+    } else {
     if (L.colsum != nullptr) {   // rows >= N contribute exact zeros (their dP rows were loaded as zeros)
       cs += __shfl_xor(cs, 32, 64);
       if (fh == 0 && col < L.mask_cols) L.colsum[(size_t)blockIdx.x * L.ldcs + col] = cs;
@@ -1464,23 +1544,47 @@ __device__ __forceinline__ void fused_bwd_epilogue(const f32x16 (&acc)[MT][NT], 
         q[0] = cx.x; q[L.ldcs] = cx.y; q[2 * L.ldcs] = cx.z; q[3 * L.ldcs] = cx.w;
       }
     }
+    }
   }
+}
+
+// What the head needs from global memory: the output layer's weights (a row's in_last <= 512 floats over the 64 lanes as two float4
+// chunks), its bias, and for the row this lane does the scalar math of (wave_sum16_index: four lanes per row of the wave's ROWS / 4)
+// the target / incoming gradient.  A kernel may request it long before the head runs (pre != nullptr below; round 4: doing so in the
+// narrow-net kernel -- 11 registers through the forward -- measured nothing, so no kernel does).
+struct HeadPre { float4 qv[2]; float tq, uext, blast; };
+template <int ROWS>
+__device__ __forceinline__ void head_prefetch(HeadPre& h, const FusedBwdArgs& p, int w, int lane, int row0) {
+  const FusedBwdHead& H = p.head;
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc) {
+    const int c = 4 * lane + 256 * cc;
+    h.qv[cc] = c < H.in_last ? *reinterpret_cast<const float4*>(H.w_last + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  h.blast = H.b_last[0];
+  const int gq = min(row0 + (ROWS / 4) * w + wave_sum16_index(lane), p.N - 1);      // (N > 0) unconditional, clamped loads
+  h.tq = 0.f; h.uext = 0.f;
+  if (H.mode == HEAD_TRAIN) h.tq = H.gt[gq];
+  else { h.tq = H.d_sdf[gq]; h.uext = H.u_in[gq]; }
 }
 
 // slab_ready: the slab already holds the last hidden activation (the merged forward+backward kernel) -- no reload, no code
 // warm-up; hred / hsc: scratch of the head's cross-wave reductions.
 template <bool SPLIT = false, int MT = 2, int NT = 4, int LDSW = FLD>
 __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float* S, float4* xs, float (*hred)[2 * FMAXW],
-                                                    float (*hsc)[2], bool slab_ready) {
+                                                    float (*hsc)[2], bool slab_ready, const HeadPre* pre = nullptr) {
   constexpr int ROWS = 32 * MT;      // points per workgroup
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int row0 = blockIdx.x * ROWS;
+  FUSED_STAMP(p, 32);
   if (!slab_ready) {
     const uint32_t warm = warm_own_code(64 * 1024);
     if (warm == 0x9E3779B1u && p.N < 0) S[0] = 1.f;   // never true: keeps the loads
   }
-  if (p.xyz != nullptr && tid < ROWS) {
+  // (merged launch: the forward staged the same rows' xyz -- and a load here would first wait for the acknowledgement of the forward's
+  // last stores, ~5 k cycles by the round-4 stamps)
+  if (p.xyz != nullptr && tid < ROWS && !slab_ready) {
     float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row0 + tid < p.N) {
       const float* q = p.xyz + (size_t)(row0 + tid) * p.G;
@@ -1498,58 +1602,83 @@ __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float
   } else {
     const FusedBwdHead& H = p.head;
     if (!slab_ready) fused_load_x0<ROWS, LDSW>(S, H.a_last, H.ld_a, H.in_last, row0, p.N, 0);
+    HeadPre hp;
+    if (pre != nullptr) hp = *pre; else head_prefetch<ROWS>(hp, p, w, lane, row0);
     float4 qv[2], dwa[2], csa[2];
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
-      const int c = 4 * lane + 256 * cc;
-      qv[cc] = c < H.in_last ? *reinterpret_cast<const float4*>(H.w_last + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      qv[cc] = hp.qv[cc];
       dwa[cc] = make_float4(0.f, 0.f, 0.f, 0.f); csa[cc] = dwa[cc];
     }
-    const float blast = H.b_last[0];
+    const float blast = hp.blast;
     float lossacc = 0.f, dbacc = 0.f;
+    // A wave owns RW consecutive rows.  Three passes instead of one row at a time (round 4 stamps: the row-by-row form was 16 serial
+    // chains of {gt load from HBM -> dot -> 6 dependent shuffles -> tanh}, 30 k cycles of a 77 k-cycle narrow-net workgroup):
+    //   1. the RW dot products, reduced TOGETHER (wave_sum16: the same butterfly as wave_sum, lane L ends up with row q(L)'s total);
+    //   2. the scalar head math of row q(L) by lane L (its gt / d_sdf / u_in were requested before the slab barrier);
+    //   3. per row: du broadcast by readlane, dP row, the dW_last / column-sum accumulation (row order as before).
+    constexpr int RW = ROWS / 4;
+    static_assert(RW <= 16, "wave_sum16 reduces at most 16 rows");
+    const int q = wave_sum16_index(lane);                       // this lane's row (four lanes per row)
+    const int growq = row0 + RW * w + q;
+    const bool liveq = q < RW && growq < p.N;
+    const float tq = hp.tq, uq_ext = hp.uext;
     __syncthreads();
-    for (int rr = 0; rr < ROWS / 4; ++rr) {
-      const int row = (ROWS / 4) * w + rr, grow = row0 + row;
-      float4 av[2];
-      float dot = 0.f;
+    float dots[16];
 #pragma unroll
-      for (int cc = 0; cc < 2; ++cc) {
-        const int c = 4 * lane + 256 * cc;
-        av[cc] = c < H.in_last ? *reinterpret_cast<const float4*>(S + row * LDSW + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        dot += av[cc].x * qv[cc].x + av[cc].y * qv[cc].y + av[cc].z * qv[cc].z + av[cc].w * qv[cc].w;
-      }
-      const bool live = grow < p.N;
-      float u = wave_sum(dot) + blast;
-      if (H.mode == HEAD_EXT && live) u = H.u_in[grow];
-      const float t1 = H.use_tanh ? tanhf(u) : u;
-      const float y = tanhf(t1);
-      float dy = 0.f;
-      if (live) {
-        if (H.mode == HEAD_TRAIN) {
-          const float yh = fminf(fmaxf(y, -H.delta), H.delta);
-          const float th = fminf(fmaxf(H.gt[grow], -H.delta), H.delta);
-          const float diff = yh - th;
-          lossacc += fabsf(diff);
-          const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
-          dy = (y >= -H.delta && y <= H.delta) ? sg * H.inv_n : 0.f;
-        } else {
-          dy = H.d_sdf[grow];
+    for (int rr = 0; rr < 16; ++rr) {
+      float dot = 0.f;
+      if (rr < RW) {
+        const int row = RW * w + rr;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          const int c = 4 * lane + 256 * cc;
+          if (c < H.in_last) {
+            const float4 a = *reinterpret_cast<const float4*>(S + row * LDSW + c);
+            dot += a.x * qv[cc].x + a.y * qv[cc].y + a.z * qv[cc].z + a.w * qv[cc].w;
+          }
         }
-        if (lane == 0 && H.y_out != nullptr) H.y_out[grow] = y;
       }
-      float du = dy * (1.f - y * y);
-      if (H.use_tanh) du *= (1.f - t1 * t1);
+      dots[rr] = dot;
+    }
+    float uq = wave_sum16(dots, lane) + blast;
+    if (H.mode == HEAD_EXT && liveq) uq = uq_ext;
+    const float t1q = H.use_tanh ? tanhf(uq) : uq;
+    const float yq = tanhf(t1q);
+    float dyq = 0.f, lsq = 0.f;
+    if (liveq) {
+      if (H.mode == HEAD_TRAIN) {
+        const float yh = fminf(fmaxf(yq, -H.delta), H.delta);
+        const float th = fminf(fmaxf(tq, -H.delta), H.delta);
+        const float diff = yh - th;
+        lsq = fabsf(diff);
+        const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+        dyq = (yq >= -H.delta && yq <= H.delta) ? sg * H.inv_n : 0.f;
+      } else {
+        dyq = tq;
+      }
+      if ((lane & 3) == 0 && H.y_out != nullptr) H.y_out[growq] = yq;
+    }
+    float duq = dyq * (1.f - yq * yq);
+    if (H.use_tanh) duq *= (1.f - t1q * t1q);
+#pragma unroll 4
+    for (int rr = 0; rr < RW; ++rr) {      // (four rows per trip: their LDS reads overlap; the source lane of the broadcasts is scalar)
+      const int row = RW * w + rr, grow = row0 + row;
+      const bool live = grow < p.N;
+      const float du = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(duq), wave_sum16_lane(rr)));
+      lossacc += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(lsq), wave_sum16_lane(rr)));
       dbacc += du;
       const float ds = du * H.mask_scale;
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc) {
         const int c = 4 * lane + 256 * cc;
         if (c < H.in_last) {
+          const float4 a = *reinterpret_cast<const float4*>(S + row * LDSW + c);
           float4 d;
-          d.x = av[cc].x > 0.f ? ds * qv[cc].x : 0.f;
-          d.y = av[cc].y > 0.f ? ds * qv[cc].y : 0.f;
-          d.z = av[cc].z > 0.f ? ds * qv[cc].z : 0.f;
-          d.w = av[cc].w > 0.f ? ds * qv[cc].w : 0.f;
+          d.x = a.x > 0.f ? ds * qv[cc].x : 0.f;
+          d.y = a.y > 0.f ? ds * qv[cc].y : 0.f;
+          d.z = a.z > 0.f ? ds * qv[cc].z : 0.f;
+          d.w = a.w > 0.f ? ds * qv[cc].w : 0.f;
           if (c + 3 >= H.n_act) {          // (part of) the chunk lies in the x0 columns of an output-layer skip
             float dv[4] = {d.x, d.y, d.z, d.w};
             const float wv[4] = {qv[cc].x, qv[cc].y, qv[cc].z, qv[cc].w};
@@ -1565,7 +1694,7 @@ __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float
           }
           *reinterpret_cast<float4*>(S + row * LDSW + c) = d;
           if (live) *reinterpret_cast<float4*>(H.dp_out + (size_t)grow * H.ld_dp + c) = d;
-          dwa[cc].x += du * av[cc].x; dwa[cc].y += du * av[cc].y; dwa[cc].z += du * av[cc].z; dwa[cc].w += du * av[cc].w;
+          dwa[cc].x += du * a.x; dwa[cc].y += du * a.y; dwa[cc].z += du * a.z; dwa[cc].w += du * a.w;
           csa[cc].x += d.x; csa[cc].y += d.y; csa[cc].z += d.z; csa[cc].w += d.w;
         }
       }
@@ -1588,13 +1717,61 @@ __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float
     }
     fused_zero_pad<ROWS, LDSW>(S, H.in_last);
   }
+  FUSED_STAMP(p, 33);
   typename KlSets<SPLIT, NT>::type PB;
-  if (p.n_layers > 0) kl_prefetch<SPLIT, NT>(PB, p.ly[0].wtf, p.ly[0].wplane, p.ly[0].wtf32, p.ly[0].U, w, lane, fused_nact(p.ly[0].ncols, w), (p.ly[0].K + 15) >> 4);
+  auto tile_w = [&](int ncols) { if constexpr (NT == 1 && MT == 2) return narrow_tile(ncols, w).nt; else return w; };
+  auto tile_n = [&](int ncols) { if constexpr (NT == 1 && MT == 2) return narrow_tile(ncols, w).active ? 1 : 0; else return fused_nact(ncols, w); };
+  auto prefetch_layer = [&](const FusedBwdLayer& Ln) {
+    kl_prefetch<SPLIT, NT>(PB, Ln.wtf, Ln.wplane, Ln.wtf32, Ln.U, tile_w(Ln.ncols), lane, tile_n(Ln.ncols), (Ln.K + 15) >> 4);
+  };
+  if (p.n_layers > 0) prefetch_layer(p.ly[0]);
   __syncthreads();
 
   for (int i = 0; i < p.n_layers; ++i) {
     const FusedBwdLayer& L = p.ly[i];
     const int nu = (L.K + 15) >> 4;
+    if constexpr (NT == 1 && MT == 2) {
+      const NarrowTile T = narrow_tile(L.ncols, w);
+      if (T.split) {      // one or two n-tiles: this wave's tile is (T.nt, T.mo) -- one m-tile (see narrow_tile)
+        f32x16 a1[1][1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a1[0][0][r] = 0.f;
+        float* Sm = S + 32 * T.mo * LDSW;
+        uint4 mq1 = make_uint4(0u, 0u, 0u, 0u);
+        if (L.maskbits != nullptr) mq1.x = L.maskbits[((size_t)blockIdx.x * 256 + T.nt * 64 + lane) * 4 + 2 * T.mo];
+        fused_kloop_dispatch<SPLIT, 1, 1, LDSW>(a1, Sm + fr * LDSW + 8 * fh, L.wtf, L.wplane, L.wtf32, L.U, T.nt, lane, nu, T.active ? 1 : 0, PB);
+        if (i + 1 < p.n_layers) prefetch_layer(p.ly[i + 1]);
+        FUSED_STAMP(p, 34 + 3 * i);
+        __syncthreads();
+        FUSED_STAMP(p, 35 + 3 * i);
+        float cs = 0.f;
+        float4 cx = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int col = 32 * T.nt + fr;
+        if (T.active) {
+          const int r0 = row0 + 32 * T.mo, n1 = max(p.N, r0);
+          if (L.xsum != nullptr) fused_bwd_epilogue<true, 1, 1, LDSW>(a1, Sm, L, T.nt, fr, fh, r0, n1, mq1, xs + 32 * T.mo, &cs, &cx);
+          else fused_bwd_epilogue<false, 1, 1, LDSW>(a1, Sm, L, T.nt, fr, fh, r0, n1, mq1, xs + 32 * T.mo, &cs, &cx);
+        }
+        // the workgroup's column sums = rows 0-31 (wave of m-tile 0) + rows 32-63 (through LDS; the head's scratch is free by now)
+        float* comb = &hred[0][0];       // [2 n-tiles][32 columns][5]
+        if (T.active && T.mo == 1 && fh == 0) {
+          float* q = comb + (T.nt * 32 + fr) * 5;
+          q[0] = cs; q[1] = cx.x; q[2] = cx.y; q[3] = cx.z; q[4] = cx.w;
+        }
+        fused_zero_pad<ROWS, LDSW>(S, L.mask_cols);
+        __syncthreads();
+        if (T.active && T.mo == 0 && fh == 0 && col < L.mask_cols) {
+          const float* q = comb + (T.nt * 32 + fr) * 5;
+          if (L.colsum != nullptr) L.colsum[(size_t)blockIdx.x * L.ldcs + col] = cs + q[0];
+          if (L.xsum != nullptr) {
+            float* o = L.xsum + (size_t)blockIdx.x * FGEO * L.ldcs + col;
+            o[0] = cx.x + q[1]; o[L.ldcs] = cx.y + q[2]; o[2 * L.ldcs] = cx.z + q[3]; o[3 * L.ldcs] = cx.w + q[4];
+          }
+        }
+        FUSED_STAMP(p, 36 + 3 * i);
+        continue;
+      }
+    }
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -1606,15 +1783,15 @@ __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float
     uint4 mq = make_uint4(0u, 0u, 0u, 0u);
     if (L.maskbits != nullptr) mq = *reinterpret_cast<const uint4*>(L.maskbits + ((size_t)blockIdx.x * 256 + tid) * 4);
     fused_kloop_dispatch<SPLIT, MT, NT, LDSW>(acc, ap, L.wtf, L.wplane, L.wtf32, L.U, w, lane, nu, fused_nact(L.ncols, w), PB);
-    if (i + 1 < p.n_layers) {
-      const FusedBwdLayer& Ln = p.ly[i + 1];
-      kl_prefetch<SPLIT, NT>(PB, Ln.wtf, Ln.wplane, Ln.wtf32, Ln.U, w, lane, fused_nact(Ln.ncols, w), (Ln.K + 15) >> 4);
-    }
+    if (i + 1 < p.n_layers) prefetch_layer(p.ly[i + 1]);
+    FUSED_STAMP(p, 34 + 3 * i);
     __syncthreads();
+    FUSED_STAMP(p, 35 + 3 * i);
     if (L.xsum != nullptr) fused_bwd_epilogue<true, MT, NT, LDSW>(acc, S, L, w, fr, fh, row0, p.N, mq, xs);
     else fused_bwd_epilogue<false, MT, NT, LDSW>(acc, S, L, w, fr, fh, row0, p.N, mq, xs);
     fused_zero_pad<ROWS, LDSW>(S, L.mask_cols);
     __syncthreads();
+    FUSED_STAMP(p, 36 + 3 * i);
   }
 }
 

@@ -1,6 +1,6 @@
 import numpy as np, sys
 d = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(8192, 64)
-nwg = int(sys.argv[2]); nl = 8
+nwg = int(sys.argv[2]); nl = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 d = d[:nwg].astype(np.int64)
 t0 = d[:, 0]
 print("start spread (cycles@100MHz?):", t0.max() - t0.min())
