@@ -572,10 +572,19 @@ bool net_narrow(const DsdfNet* net) {
 // Rows per workgroup of the fused kernels: 64, or 32 (fused_*_h32_kernel: fp32 MFMA, merged forward + backward or forward alone) when
 // 32-row workgroups still fit one per CU -- i.e. when 64-row workgroups would leave at least half of the chip idle (BASELINE config 4:
 // one shape x 8000 points).  DSDF_FROWS=64 switches it off (A/B).
-int pick_frows(const DsdfNet* net, int64_t n) {
+// merged: the training step's one-launch forward + backward.  Nets of at most 32-wide layers take it WAVE-PRIVATE at every batch size
+// (32 points per one-wave workgroup, fused_fwd_bwd_w32_kernel; DSDF_NO_W32=1: the 64-row narrow kernels instead).
+bool w32_wanted(const DsdfNet* net) {
+  if (!net_narrow(net) || getenv("DSDF_NO_W32")) return false;
+  for (int l = 0; l < net->n_layers; ++l)
+    if (net->in_dim[l] > FWW || (l < net->n_layers - 1 && net->out_dim[l] > FWW)) return false;
+  return true;
+}
+int pick_frows(const DsdfNet* net, int64_t n, bool merged = false) {
   const char* e = getenv("DSDF_FROWS");      // read per call: the tests switch it inside one process
   const bool off = e && !strcmp(e, "64");
   if (off || !fused_enabled() || !fused_eligible(net) || net->gemm_split || net->fwd_bf16) return FROWS;
+  if (merged && n > 0 && w32_wanted(net)) return 32;
   return n > 0 && n <= 32ll * (chip_waves() / 4) ? 32 : FROWS;
 }
 
@@ -958,6 +967,7 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
       if (net->fwd_bf16 && net->gemm_split) hipLaunchKernelGGL(fused_fwd_bf16_bwd_split_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
       else if (net->fwd_bf16) hipLaunchKernelGGL(fused_fwd_bf16_bwd_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
       else if (net->gemm_split) hipLaunchKernelGGL(fused_fwd_bwd_split_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
+      else if (P.frows == 32 && w32_wanted(net)) hipLaunchKernelGGL(fused_fwd_bwd_w32_kernel, dim3((unsigned)P.nwg), dim3(64), 0, st, *fwd, a);
       else if (P.frows == 32) hipLaunchKernelGGL(fused_fwd_bwd_h32_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
       else if (net_narrow(net)) hipLaunchKernelGGL(fused_fwd_bwd_n128_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
       else hipLaunchKernelGGL(fused_fwd_bwd_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
@@ -1533,7 +1543,7 @@ int train_fb_impl(const DsdfNet* net, const float* packed, const float* params, 
                          && !getenv("DSDF_LAB_DBG")
 #endif
       ;
-  const int frows = can_merge ? pick_frows(net, n) : FROWS;
+  const int frows = can_merge ? pick_frows(net, n, true) : FROWS;
   const bool segsum = fusedb && b->seg_len > 0 && b->seg_len % frows == 0 && b->seg_len * R == n && net->n_layers > 2 &&
                       skip_l != net->n_layers - 2 &&   // the deepest hidden layer's dP column sums live in the head's partials
                       !last_layer_skip(net) &&

@@ -37,7 +37,16 @@ namespace dsdf {
 constexpr int FROWS = 64;        // points per workgroup
 constexpr int FLD = 516;         // slab row stride in floats
 constexpr int FMAXW = 512;       // widest layer the fused kernels handle
+constexpr int FLDN = 132, FNW = 128;   // narrow-net kernels (every layer <= FNW wide): slab row stride in floats
+constexpr int FLDW = 36, FWW = 32;     // wave-private kernel (every layer <= FWW wide)
+// Waves per workgroup: 4 -- or ONE in the wave-private narrow-net kernel (fused_fwd_bwd_w32_kernel), whose bodies are the
+// (32 rows, FLDW) instantiations: that wave owns every n-tile of its 32 rows (n-tile index = ni instead of w + 4 ni).
+__host__ __device__ constexpr int fused_nw(int rows, int ldsw) { return rows == 32 && ldsw == FLDW ? 1 : 4; }
                   //                     8 = no global activation stores in the forward epilogue
+#ifndef W32_WAVES
+#define W32_WAVES 3                // waves per SIMD the wave-private kernel is compiled for (168 registers; measured on the 4 x 32 spec:
+                                   // 2 -> 92.9 us, 3 -> 84.5 us, 4 -> 157 us with 216 B of scratch)
+#endif
 #ifndef FUSED_STORE_AUX
 #define FUSED_STORE_AUX 2          // cache policy of the activation / dP copies (lab: 2 = nt, 16 = sc1 write-through)
 #endif
@@ -90,13 +99,14 @@ struct FusedFwdArgs {
 template <int ROWS = FROWS, int LDSW = FLD>
 __device__ __forceinline__ void fused_load_x0(float* S, const float* x0, int ldx0, int W0, int row0, int N, int col0) {
   constexpr int XCH = 20;                   // float4 chunks per thread per pass
+  constexpr int NTH = 64 * fused_nw(ROWS, LDSW);
   const int cpr = (W0 + 3) >> 2;            // chunks per row (ldx0 is a multiple of 4: the tail chunk is in bounds)
   const int total = ROWS * cpr;
-  for (int base = 0; base < total; base += 256 * XCH) {
+  for (int base = 0; base < total; base += NTH * XCH) {
     float4 v[XCH];
 #pragma unroll
     for (int k = 0; k < XCH; ++k) {
-      const int ci = base + threadIdx.x + 256 * k;
+      const int ci = base + threadIdx.x + NTH * k;
       v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ci < total) {
         const int r = ci / cpr, c = ci - r * cpr;
@@ -105,7 +115,7 @@ __device__ __forceinline__ void fused_load_x0(float* S, const float* x0, int ldx
     }
 #pragma unroll
     for (int k = 0; k < XCH; ++k) {
-      const int ci = base + threadIdx.x + 256 * k;
+      const int ci = base + threadIdx.x + NTH * k;
       if (ci < total) {
         const int r = ci / cpr, c = ci - r * cpr;
         float* d = S + r * LDSW + col0 + 4 * c;
@@ -158,9 +168,10 @@ __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[MT][NT], 
   const int ldb = L.ld_out * 4;   // bytes per global row (wave-uniform)
   const bool has_out = L.out != nullptr;
   uint32_t mq[4] = {0u, 0u, 0u, 0u};
+  constexpr int NW = fused_nw(32 * MT, LDSW);
 #pragma unroll
   for (int ni = 0; ni < NT; ++ni) {
-    const int col = 32 * (w + 4 * ni) + fr;
+    const int col = 32 * (w + NW * ni) + fr;
     const bool cok = col < L.out_dim;
     const uint32_t voff = cok ? (uint32_t)((4 * fh) * ldb + col * 4) : 0x7FFFFFFFu;
     float* sp = S + (4 * fh) * LDSW + col;
@@ -211,7 +222,7 @@ __device__ __forceinline__ void fused_fwd_epilogue(const f32x16 (&acc)[MT][NT], 
     mq[2 + (ni >> 1)] |= mb[1] << (16 * (ni & 1));
   }
   if (L.maskbits != nullptr) {
-    if constexpr (MT == 1 && NT == 1)    // a NarrowTile: the word thread (wave nt, lane) of the whole-rows form keeps for m-tile mo
+    if constexpr (MT == 1 && NT == 1 && NW == 4)   // a NarrowTile (four-wave workgroup): the word thread (wave nt, lane) of the whole-rows form keeps for m-tile mo
       L.maskbits[((size_t)blockIdx.x * 256 + w * 64 + fr + 32 * fh) * 4 + 2 * mo] = mq[0];
     else
       *reinterpret_cast<uint4*>(L.maskbits + ((size_t)blockIdx.x * 256 + threadIdx.x) * 4) = make_uint4(mq[0], mq[1], mq[2], mq[3]);
@@ -243,13 +254,13 @@ template <int NT> struct FusedBSetsT { float4 b0[NT][2], b1[NT][2]; };   // weig
 typedef FusedBSetsT<4> FusedBSets;
 
 template <int NT>
-__device__ __forceinline__ void fused_prefetch_b(FusedBSetsT<NT>& B, const float* wf, int U, int w, int lane, int nact, int nu) {
+__device__ __forceinline__ void fused_prefetch_b(FusedBSetsT<NT>& B, const float* wf, int U, int w, int lane, int nact, int nu, int nws = 4) {
   const int rot = fused_rot(nu);
   const int u0 = fused_unit(0, rot, nu), u1 = fused_unit(nu > 1 ? 1 : 0, rot, nu);
 #pragma unroll
   for (int ni = 0; ni < NT; ++ni) {
     if (ni < nact) {
-      const float* q = wf + (size_t)(w + 4 * ni) * U * 512 + lane * 4;
+      const float* q = wf + (size_t)(w + nws * ni) * U * 512 + lane * 4;
       B.b0[ni][0] = *reinterpret_cast<const float4*>(q + 512 * u0);
       B.b0[ni][1] = *reinterpret_cast<const float4*>(q + 512 * u0 + 256);
       if (nu > 1) {
@@ -268,12 +279,12 @@ __device__ __forceinline__ void fused_prefetch_b(FusedBSetsT<NT>& B, const float
 #endif
 #if FUSED_RSRC4
 struct FusedBView { __amdgpu_buffer_rsrc_t rsrc[4]; int voff; };   // rsrc[ni] based at n-tile (w + 4 ni); voff = lane * 16
-__device__ __forceinline__ FusedBView fused_bview(const float* wf, int U, int w, int lane) {
+__device__ __forceinline__ FusedBView fused_bview(const float* wf, int U, int w, int lane, int nws = 4) {
   FusedBView v;
   const int ws = __builtin_amdgcn_readfirstlane(w);
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni)
-    v.rsrc[ni] = __builtin_amdgcn_make_buffer_rsrc((void*)(wf + (size_t)(ws + 4 * ni) * U * 512), 0, 0x7FFFFFFF, 0x00020000);
+    v.rsrc[ni] = __builtin_amdgcn_make_buffer_rsrc((void*)(wf + (size_t)(ws + nws * ni) * U * 512), 0, 0x7FFFFFFF, 0x00020000);
   v.voff = lane * 16;
   return v;
 }
@@ -284,12 +295,12 @@ __device__ __forceinline__ float4 fused_bload(const FusedBView& B, int ni, int u
 }
 #else
 struct FusedBView { __amdgpu_buffer_rsrc_t rsrc; int tbase[4]; int voff; };   // tbase[ni] = (w + 4 ni) * U; voff = lane * 16
-__device__ __forceinline__ FusedBView fused_bview(const float* wf, int U, int w, int lane) {
+__device__ __forceinline__ FusedBView fused_bview(const float* wf, int U, int w, int lane, int nws = 4) {
   FusedBView v;
   v.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, 0x7FFFFFFF, 0x00020000);
   const int ws = __builtin_amdgcn_readfirstlane(w);
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) v.tbase[ni] = (ws + 4 * ni) * U;
+  for (int ni = 0; ni < 4; ++ni) v.tbase[ni] = (ws + nws * ni) * U;
   v.voff = lane * 16;
   return v;
 }
@@ -805,9 +816,9 @@ template <bool SPLIT, int NT = 4> struct KlSets { typedef FusedBSetsT<NT> type; 
 template <int NT> struct KlSets<true, NT> { typedef SplitBSet type; };
 template <bool SPLIT, int NT = 4>
 __device__ __forceinline__ void kl_prefetch(typename KlSets<SPLIT, NT>::type& PB, const float* wf, int wplane, const float* wf32, int U, int w, int lane,
-                                            int nact, int nu) {
+                                            int nact, int nu, int nws = 4) {
   if constexpr (SPLIT) split_prefetch_b(PB, wf, wplane, wf32, U, w, lane, nact, nu);
-  else fused_prefetch_b<NT>(PB, wf, U, w, lane, nact, nu);
+  else fused_prefetch_b<NT>(PB, wf, U, w, lane, nact, nu, nws);
 }
 template <bool SPLIT, int MT = 2, int NT = 4, int LDSW = FLD>
 __device__ __forceinline__ void fused_kloop_dispatch(f32x16 (&acc)[MT][NT], const float* ap, const float* wf, int wplane, const float* wf32, int U,
@@ -827,7 +838,7 @@ __device__ __forceinline__ void fused_kloop_dispatch(f32x16 (&acc)[MT][NT], cons
       default: break;
     }
   } else {
-    const FusedBView bv = fused_bview(wf, U, w, lane);
+    const FusedBView bv = fused_bview(wf, U, w, lane, fused_nw(32 * MT, LDSW));
     if constexpr (NT == 4) {
       switch (nact) {
         case 4: fused_kloop<4, MT, NT, LDSW>(acc, ap, bv, nu, PB); break;
@@ -843,24 +854,24 @@ __device__ __forceinline__ void fused_kloop_dispatch(f32x16 (&acc)[MT][NT], cons
   }
 }
 
-__device__ __forceinline__ int fused_nact(int ncols, int w) {   // how many of this wave's n-tiles {w, w+4, w+8, w+12} exist
-  const int ntl = (ncols + 31) >> 5;
-  return ntl > w ? min(4, (ntl - w + 3) >> 2) : 0;
+__device__ __forceinline__ int fused_nact(int ncols, int w, int nws = 4) {   // how many of this wave's n-tiles {w, w+4, w+8, w+12} exist
+  const int ntl = (ncols + 31) >> 5;                                          // (nws = 1, the wave-private kernel: {0, 1, 2, 3})
+  return ntl > w ? min(4, (ntl - w + nws - 1) / nws) : 0;
 }
 
 template <int ROWS = FROWS, int LDSW = FLD>
 __device__ __forceinline__ void fused_zero_pad(float* S, int nin) {   // columns [nin, roundup16(nin)) of every slab row
   const int zc = ((nin + 15) & ~15) - nin;
-  for (int i = threadIdx.x; i < ROWS * zc; i += 256) S[(i / zc) * LDSW + nin + (i % zc)] = 0.f;
+  for (int i = threadIdx.x; i < ROWS * zc; i += 64 * fused_nw(ROWS, LDSW)) S[(i / zc) * LDSW + nin + (i % zc)] = 0.f;
 }
 
 // accumulators of a hoisted layer start at  U_s[col] + <xyz[row], W[col, xyz]>  (all operands staged in LDS)
 template <int MT = 2, int NT = 4>
 __device__ __forceinline__ void fused_hoist_init(f32x16 (&acc)[MT][NT], const float* hu, const float4* hwx, const float4* xs,
-                                                 int out_dim, int w, int fr, int fh) {
+                                                 int out_dim, int w, int fr, int fh, int nws = 4) {
 #pragma unroll
   for (int ni = 0; ni < NT; ++ni) {   // one n-tile at a time (few live registers); the xyz rows are re-read from LDS (broadcast)
-    const int col = 32 * (w + 4 * ni) + fr;
+    const int col = 32 * (w + nws * ni) + fr;
     const bool ok = col < out_dim;
     const float ub = ok ? hu[col] : 0.f;
     const float4 wq = ok ? hwx[col] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -876,10 +887,12 @@ __device__ __forceinline__ void fused_hoist_init(f32x16 (&acc)[MT][NT], const fl
 
 // S: the slab; xs: segment mode, xyz of the 64 points (zero padded); hu / hwx: segment mode, U_s of the hoisted layers and
 // their xyz weight columns.  On return in the training form (no y_out / u_out) the slab holds the last hidden activation.
-template <bool SPLIT = false, int MT = 2, int NT = 4, int LDSW = FLD>
-__device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float* S, float4* xs, float (*hu)[FMAXW],
-                                                   float4 (*hwx)[FMAXW], int warm_bytes) {
+// HW: columns a hoist scratch row holds (the widest layer the kernel accepts)
+template <bool SPLIT = false, int MT = 2, int NT = 4, int LDSW = FLD, int HW = FMAXW>
+__device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float* S, float4* xs, float (*hu)[HW],
+                                                   float4 (*hwx)[HW], int warm_bytes) {
   constexpr int ROWS = 32 * MT;      // points per workgroup
+  constexpr int NW = fused_nw(ROWS, LDSW), NTH = 64 * NW;      // waves / threads per workgroup
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int row0 = blockIdx.x * ROWS;
@@ -891,10 +904,10 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
   const int lfirst = (segm && p.n_hidden > 1) ? 1 : 0;   // first layer with an MFMA pass (segment mode: layer 0 has none)
   // (narrow kernels: the tile owner of a layer depends on its width -- narrow_tile)
   auto tile_w = [&](int ncols) { if constexpr (NT == 1 && MT == 2) return narrow_tile(ncols, w).nt; else return w; };
-  auto tile_n = [&](int ncols) { if constexpr (NT == 1 && MT == 2) return narrow_tile(ncols, w).active ? 1 : 0; else return fused_nact(ncols, w); };
+  auto tile_n = [&](int ncols) { if constexpr (NT == 1 && MT == 2) return narrow_tile(ncols, w).active ? 1 : 0; else return fused_nact(ncols, w, NW); };
   // the next layer's first weights are requested while this layer's epilogue has not stored yet
   auto prefetch_layer = [&](const FusedLayer& Ln) {
-    kl_prefetch<SPLIT, NT>(PB, Ln.wf, Ln.wplane, Ln.wf32, Ln.U, tile_w(Ln.out_dim), lane, tile_n(Ln.out_dim), (Ln.in + 15) >> 4);
+    kl_prefetch<SPLIT, NT>(PB, Ln.wf, Ln.wplane, Ln.wf32, Ln.U, tile_w(Ln.out_dim), lane, tile_n(Ln.out_dim), (Ln.in + 15) >> 4, NW);
   };
   prefetch_layer(p.ly[lfirst]);
   if (segm) {
@@ -915,7 +928,7 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
       const FusedHoist& H = p.seg.h[t];
       if (H.layer < 0) continue;
       const int od = p.ly[H.layer].out_dim;
-      for (int c = tid; c < od; c += 256) {
+      for (int c = tid; c < od; c += NTH) {
         hu[t][c] = p.seg.U[((size_t)sidx * FHOIST + t) * p.seg.ldu + c];
         const float* q = H.wx + (size_t)c * H.ldw;
         float4 x = make_float4(q[0], 0.f, 0.f, 0.f);
@@ -943,7 +956,7 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
     float biasv[NT];
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
-      const int col = 32 * (w + 4 * ni) + fr;
+      const int col = 32 * (w + NW * ni) + fr;
       biasv[ni] = col < L.out_dim ? L.bias[col] : 0.f;
     }
     int hidx = -1;
@@ -990,7 +1003,7 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
       }
     }
     if (hidx >= 0) {
-      fused_hoist_init<MT, NT>(acc, hu[hidx], hwx[hidx], xs, L.out_dim, w, fr, fh);
+      fused_hoist_init<MT, NT>(acc, hu[hidx], hwx[hidx], xs, L.out_dim, w, fr, fh, NW);
     } else {
 #pragma unroll
       for (int m = 0; m < MT; ++m)
@@ -1001,7 +1014,7 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
     }
     const float* ap = S + fr * LDSW + 8 * fh;
     if (nu > 0) {
-      fused_kloop_dispatch<SPLIT, MT, NT, LDSW>(acc, ap, L.wf, L.wplane, L.wf32, L.U, w, lane, nu, fused_nact(L.out_dim, w), PB);
+      fused_kloop_dispatch<SPLIT, MT, NT, LDSW>(acc, ap, L.wf, L.wplane, L.wf32, L.U, w, lane, nu, fused_nact(L.out_dim, w, NW), PB);
       if (l + 1 < p.n_hidden) prefetch_layer(p.ly[l + 1]);   // next layer's first weights travel while this layer's epilogue runs
     }
 #ifdef DSDF_LAB
@@ -1035,8 +1048,8 @@ __device__ __forceinline__ void fused_forward_body(const FusedFwdArgs& p, float*
     qv[cc] = c < p.in_last ? *reinterpret_cast<const float4*>(p.w_last + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const float blast = p.b_last[0];
-  for (int rr = 0; rr < ROWS / 4; ++rr) {
-    const int row = (ROWS / 4) * w + rr;
+  for (int rr = 0; rr < ROWS / NW; ++rr) {
+    const int row = (ROWS / NW) * w + rr;
     float dot = 0.f;
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
@@ -1077,7 +1090,6 @@ __global__ __launch_bounds__(256, 1) void fused_forward_h32_kernel(const FusedFw
 // CU.  These nets are not MFMA bound: a 32-wide layer is 2 k cycles of MFMAs inside ~12 k cycles of dependent latencies (weights
 // from L2, the epilogue's store acknowledgements in front of the next layer's loads, two barriers); a second resident workgroup
 // overlaps them.
-constexpr int FLDN = 132;
 __global__ __launch_bounds__(256, 2) void fused_forward_n128_kernel(const FusedFwdArgs p) {
   __shared__ __attribute__((aligned(16))) float S[FROWS * FLDN];
   __shared__ float4 xs[FROWS];
@@ -1492,9 +1504,10 @@ __device__ __forceinline__ void fused_bwd_epilogue(const f32x16 (&acc)[MT][NT], 
       L.dz_out != nullptr ? rows_here * L.ldz * 4 : 0, 0x00020000);
   const int ldb = L.ld_dp * 4, ldzb = L.ldz * 4;
   const uint32_t mw[4] = {mq.x, mq.y, mq.z, mq.w};
+  constexpr int NW = fused_nw(32 * MT, LDSW);
 #pragma unroll
   for (int ni = 0; ni < NT; ++ni) {
-    const int col = 32 * (w + 4 * ni) + fr;
+    const int col = 32 * (w + NW * ni) + fr;
     float cs = 0.f;
     float4 cx = make_float4(0.f, 0.f, 0.f, 0.f);
     if (col < L.mask_cols) {
@@ -1524,7 +1537,7 @@ __device__ __forceinline__ void fused_bwd_epilogue(const f32x16 (&acc)[MT][NT], 
         for (int r = 0; r < 16; ++r)
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][ni][r]), rdz, voff, (32 * m + crow(r)) * ldzb, 0);
     }
-    if constexpr (MT == 1 && NT == 1) {     // half of the workgroup's rows: the caller adds the other half's sums
+    if constexpr (MT == 1 && NT == 1 && NW == 4) {     // a NarrowTile = half of a four-wave workgroup's rows: the caller adds the other half's sums
       cs += __shfl_xor(cs, 32, 64);
       if constexpr (XS) {
         cx.x += __shfl_xor(cx.x, 32, 64); cx.y += __shfl_xor(cx.y, 32, 64);
@@ -1553,7 +1566,7 @@ __device__ __forceinline__ void fused_bwd_epilogue(const f32x16 (&acc)[MT][NT], 
 // the target / incoming gradient.  A kernel may request it long before the head runs (pre != nullptr below; round 4: doing so in the
 // narrow-net kernel -- 11 registers through the forward -- measured nothing, so no kernel does).
 struct HeadPre { float4 qv[2]; float tq, uext, blast; };
-template <int ROWS>
+template <int RW>      // RW: rows per wave
 __device__ __forceinline__ void head_prefetch(HeadPre& h, const FusedBwdArgs& p, int w, int lane, int row0) {
   const FusedBwdHead& H = p.head;
 #pragma unroll
@@ -1562,7 +1575,7 @@ __device__ __forceinline__ void head_prefetch(HeadPre& h, const FusedBwdArgs& p,
     h.qv[cc] = c < H.in_last ? *reinterpret_cast<const float4*>(H.w_last + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   h.blast = H.b_last[0];
-  const int gq = min(row0 + (ROWS / 4) * w + wave_sum16_index(lane), p.N - 1);      // (N > 0) unconditional, clamped loads
+  const int gq = min(row0 + RW * w + wave_sum16_index(lane), p.N - 1);      // (N > 0) unconditional, clamped loads
   h.tq = 0.f; h.uext = 0.f;
   if (H.mode == HEAD_TRAIN) h.tq = H.gt[gq];
   else { h.tq = H.d_sdf[gq]; h.uext = H.u_in[gq]; }
@@ -1570,10 +1583,11 @@ __device__ __forceinline__ void head_prefetch(HeadPre& h, const FusedBwdArgs& p,
 
 // slab_ready: the slab already holds the last hidden activation (the merged forward+backward kernel) -- no reload, no code
 // warm-up; hred / hsc: scratch of the head's cross-wave reductions.
-template <bool SPLIT = false, int MT = 2, int NT = 4, int LDSW = FLD>
-__device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float* S, float4* xs, float (*hred)[2 * FMAXW],
+template <bool SPLIT = false, int MT = 2, int NT = 4, int LDSW = FLD, int HW = FMAXW>
+__device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float* S, float4* xs, float (*hred)[2 * HW],
                                                     float (*hsc)[2], bool slab_ready, const HeadPre* pre = nullptr) {
   constexpr int ROWS = 32 * MT;      // points per workgroup
+  constexpr int NW = fused_nw(ROWS, LDSW), NTH = 64 * NW;      // waves / threads per workgroup
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int row0 = blockIdx.x * ROWS;
@@ -1602,8 +1616,9 @@ __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float
   } else {
     const FusedBwdHead& H = p.head;
     if (!slab_ready) fused_load_x0<ROWS, LDSW>(S, H.a_last, H.ld_a, H.in_last, row0, p.N, 0);
+    constexpr int RW = ROWS / NW;      // rows per wave: 16 (8 in the 32-row workgroups; 32 in the wave-private kernel: two batches)
     HeadPre hp;
-    if (pre != nullptr) hp = *pre; else head_prefetch<ROWS>(hp, p, w, lane, row0);
+    if (pre != nullptr) hp = *pre; else head_prefetch<RW>(hp, p, w, lane, row0);
     float4 qv[2], dwa[2], csa[2];
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
@@ -1612,24 +1627,32 @@ __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float
     }
     const float blast = hp.blast;
     float lossacc = 0.f, dbacc = 0.f;
-    // A wave owns RW consecutive rows.  Three passes instead of one row at a time (round 4 stamps: the row-by-row form was 16 serial
-    // chains of {gt load from HBM -> dot -> 6 dependent shuffles -> tanh}, 30 k cycles of a 77 k-cycle narrow-net workgroup):
-    //   1. the RW dot products, reduced TOGETHER (wave_sum16: the same butterfly as wave_sum, lane L ends up with row q(L)'s total);
+    // A wave owns RW consecutive rows.  Three passes per batch of (at most) 16 rows instead of one row at a time (round 4 stamps: the
+    // row-by-row form was 16 serial chains of {gt load from HBM -> dot -> 6 dependent shuffles -> tanh}, 30 k cycles of a 77 k-cycle
+    // narrow-net workgroup):
+    //   1. the dot products, reduced TOGETHER (wave_sum16: the same butterfly as wave_sum, lane L ends up with row q(L)'s total);
     //   2. the scalar head math of row q(L) by lane L (its gt / d_sdf / u_in were requested before the slab barrier);
     //   3. per row: du broadcast by readlane, dP row, the dW_last / column-sum accumulation (row order as before).
-    constexpr int RW = ROWS / 4;
-    static_assert(RW <= 16, "wave_sum16 reduces at most 16 rows");
-    const int q = wave_sum16_index(lane);                       // this lane's row (four lanes per row)
-    const int growq = row0 + RW * w + q;
-    const bool liveq = q < RW && growq < p.N;
-    const float tq = hp.tq, uq_ext = hp.uext;
+    constexpr int RB = RW < 16 ? RW : 16;                       // rows of a batch
+    static_assert(RW % RB == 0, "whole batches");
     __syncthreads();
+#pragma unroll
+    for (int hb = 0; hb < RW; hb += 16) {
+    const int q = wave_sum16_index(lane);                       // this lane's row of the batch (four lanes per row)
+    const int growq = row0 + RW * w + hb + q;
+    const bool liveq = q < RB && growq < p.N;
+    float tq = hp.tq, uq_ext = hp.uext;
+    if (hb > 0) {                                               // (later batches: requested here)
+      const int gq = min(growq, p.N - 1);
+      if (H.mode == HEAD_TRAIN) tq = H.gt[gq];
+      else { tq = H.d_sdf[gq]; uq_ext = H.u_in[gq]; }
+    }
     float dots[16];
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) {
       float dot = 0.f;
-      if (rr < RW) {
-        const int row = RW * w + rr;
+      if (rr < RB) {
+        const int row = RW * w + hb + rr;
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
           const int c = 4 * lane + 256 * cc;
@@ -1662,8 +1685,8 @@ __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float
     float duq = dyq * (1.f - yq * yq);
     if (H.use_tanh) duq *= (1.f - t1q * t1q);
 #pragma unroll 4
-    for (int rr = 0; rr < RW; ++rr) {      // (four rows per trip: their LDS reads overlap; the source lane of the broadcasts is scalar)
-      const int row = RW * w + rr, grow = row0 + row;
+    for (int rr = 0; rr < RB; ++rr) {      // (four rows per trip: their LDS reads overlap; the source lane of the broadcasts is scalar)
+      const int row = RW * w + hb + rr, grow = row0 + row;
       const bool live = grow < p.N;
       const float du = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(duq), wave_sum16_lane(rr)));
       lossacc += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(lsq), wave_sum16_lane(rr)));
@@ -1699,30 +1722,48 @@ __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float
         }
       }
     }
+    }
+    if constexpr (NW == 1) {       // one wave: its registers ARE the workgroup's partial rows
 #pragma unroll
-    for (int cc = 0; cc < 2; ++cc) {
-      *reinterpret_cast<float4*>(&hred[w][4 * lane + 256 * cc]) = dwa[cc];
-      *reinterpret_cast<float4*>(&hred[w][FMAXW + 4 * lane + 256 * cc]) = csa[cc];
-    }
-    if (lane == 0) { hsc[w][0] = lossacc; hsc[w][1] = dbacc; }
-    __syncthreads();
-    for (int c = tid; c < H.in_last; c += 256) {
-      H.part[(size_t)blockIdx.x * H.ld_part + c] = (hred[0][c] + hred[1][c]) + (hred[2][c] + hred[3][c]);
-      H.part[(size_t)blockIdx.x * H.ld_part + H.ld_a + c] =
-          (hred[0][FMAXW + c] + hred[1][FMAXW + c]) + (hred[2][FMAXW + c] + hred[3][FMAXW + c]);
-    }
-    if (tid == 0) {
-      H.part_loss[blockIdx.x] = (hsc[0][0] + hsc[1][0]) + (hsc[2][0] + hsc[3][0]);
-      H.part_db[blockIdx.x] = (hsc[0][1] + hsc[1][1]) + (hsc[2][1] + hsc[3][1]);
+      for (int cc = 0; cc < 2; ++cc) {
+        const int c = 4 * lane + 256 * cc;
+        if (c < H.in_last) {
+          float* o = H.part + (size_t)blockIdx.x * H.ld_part + c;
+          const float dv[4] = {dwa[cc].x, dwa[cc].y, dwa[cc].z, dwa[cc].w}, cv[4] = {csa[cc].x, csa[cc].y, csa[cc].z, csa[cc].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c + e < H.in_last) { o[e] = dv[e]; o[H.ld_a + e] = cv[e]; }
+        }
+      }
+      if (lane == 0) { H.part_loss[blockIdx.x] = lossacc; H.part_db[blockIdx.x] = dbacc; }
+    } else {
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        if (4 * lane + 256 * cc < HW) {      // (in_last <= HW)
+          *reinterpret_cast<float4*>(&hred[w][4 * lane + 256 * cc]) = dwa[cc];
+          *reinterpret_cast<float4*>(&hred[w][HW + 4 * lane + 256 * cc]) = csa[cc];
+        }
+      }
+      if (lane == 0) { hsc[w][0] = lossacc; hsc[w][1] = dbacc; }
+      __syncthreads();
+      for (int c = tid; c < H.in_last; c += NTH) {
+        H.part[(size_t)blockIdx.x * H.ld_part + c] = (hred[0][c] + hred[1][c]) + (hred[2][c] + hred[3][c]);
+        H.part[(size_t)blockIdx.x * H.ld_part + H.ld_a + c] =
+            (hred[0][HW + c] + hred[1][HW + c]) + (hred[2][HW + c] + hred[3][HW + c]);
+      }
+      if (tid == 0) {
+        H.part_loss[blockIdx.x] = (hsc[0][0] + hsc[1][0]) + (hsc[2][0] + hsc[3][0]);
+        H.part_db[blockIdx.x] = (hsc[0][1] + hsc[1][1]) + (hsc[2][1] + hsc[3][1]);
+      }
     }
     fused_zero_pad<ROWS, LDSW>(S, H.in_last);
   }
   FUSED_STAMP(p, 33);
   typename KlSets<SPLIT, NT>::type PB;
   auto tile_w = [&](int ncols) { if constexpr (NT == 1 && MT == 2) return narrow_tile(ncols, w).nt; else return w; };
-  auto tile_n = [&](int ncols) { if constexpr (NT == 1 && MT == 2) return narrow_tile(ncols, w).active ? 1 : 0; else return fused_nact(ncols, w); };
+  auto tile_n = [&](int ncols) { if constexpr (NT == 1 && MT == 2) return narrow_tile(ncols, w).active ? 1 : 0; else return fused_nact(ncols, w, NW); };
   auto prefetch_layer = [&](const FusedBwdLayer& Ln) {
-    kl_prefetch<SPLIT, NT>(PB, Ln.wtf, Ln.wplane, Ln.wtf32, Ln.U, tile_w(Ln.ncols), lane, tile_n(Ln.ncols), (Ln.K + 15) >> 4);
+    kl_prefetch<SPLIT, NT>(PB, Ln.wtf, Ln.wplane, Ln.wtf32, Ln.U, tile_w(Ln.ncols), lane, tile_n(Ln.ncols), (Ln.K + 15) >> 4, NW);
   };
   if (p.n_layers > 0) prefetch_layer(p.ly[0]);
   __syncthreads();
@@ -1782,7 +1823,7 @@ __device__ __forceinline__ void fused_backward_body(const FusedBwdArgs& p, float
     const float* ap = S + fr * LDSW + 8 * fh;
     uint4 mq = make_uint4(0u, 0u, 0u, 0u);
     if (L.maskbits != nullptr) mq = *reinterpret_cast<const uint4*>(L.maskbits + ((size_t)blockIdx.x * 256 + tid) * 4);
-    fused_kloop_dispatch<SPLIT, MT, NT, LDSW>(acc, ap, L.wtf, L.wplane, L.wtf32, L.U, w, lane, nu, fused_nact(L.ncols, w), PB);
+    fused_kloop_dispatch<SPLIT, MT, NT, LDSW>(acc, ap, L.wtf, L.wplane, L.wtf32, L.U, w, lane, nu, fused_nact(L.ncols, w, NW), PB);
     if (i + 1 < p.n_layers) prefetch_layer(p.ly[i + 1]);
     FUSED_STAMP(p, 34 + 3 * i);
     __syncthreads();
@@ -1837,6 +1878,24 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_bwd_h32_kernel(const FusedFw
   fused_forward_body<false, 1>(f, S, xs, hu, hwx, 150 * 1024);
   __syncthreads();
   fused_backward_body<false, 1>(b, S, xs, hred, hsc, true);
+}
+// ... for the narrowest nets (every layer at most 32 wide: the reference's 4 x 32 spec), WAVE-PRIVATE: a workgroup is ONE wave with 32
+// points and the single n-tile of a layer -- 16 accumulator registers, a 4.6 KB slab.  Nothing in a layer waits for another wave (the
+// workgroup barriers are single-wave barriers; a layer is {A from the own slab rows, 16 MFMAs, epilogue into the same rows}), and many
+// such waves share a SIMD.  The 64-row narrow kernels spend a layer's ~8 k cycles on one or two waves' instruction streams and on the
+// barriers between four.  Measured with all four n-tiles in one wave (widths <= 128: 256 registers, 196 B of scratch):
+// 4 x 32 169 -> 131 us, 4 x 64 202 -> 206, 6 x 128 554 -> 716 -- so only the 32-wide form exists.
+__global__ __launch_bounds__(64, W32_WAVES) void fused_fwd_bwd_w32_kernel(const FusedFwdArgs f, const FusedBwdArgs b) {
+  __shared__ __attribute__((aligned(16))) float S[32 * FLDW];
+  __shared__ float4 xs[32];
+  __shared__ float4 scratch[FHOIST * FWW + FHOIST * FWW / 4];      // hu [2][32] floats + hwx [2][32] float4
+  float (*hu)[FWW] = reinterpret_cast<float (*)[FWW]>(scratch);
+  float4 (*hwx)[FWW] = reinterpret_cast<float4 (*)[FWW]>(scratch + FHOIST * FWW / 4);
+  float (*hred)[2 * FWW] = reinterpret_cast<float (*)[2 * FWW]>(scratch);      // (unused: one wave)
+  float (*hsc)[2] = reinterpret_cast<float (*)[2]>(scratch + 2 * FWW / 4);
+  fused_forward_body<false, 1, 1, FLDW, FWW>(f, S, xs, hu, hwx, 48 * 1024);
+  __syncthreads();
+  fused_backward_body<false, 1, 1, FLDW, FWW>(b, S, xs, hred, hsc, true);
 }
 // ... for narrow nets (see fused_forward_n128_kernel): two workgroups per CU
 __global__ __launch_bounds__(256, 2) void fused_fwd_bwd_n128_kernel(const FusedFwdArgs f, const FusedBwdArgs b) {
