@@ -620,6 +620,75 @@ def test_random_specs_and_shapes_vs_oracle(seed, monkeypatch):
         assert rel_err(tr.lat.cpu(), st64.latents) <= 5e-5, what
 
 
+def _random_w32_case(seed):
+    """A seeded random decoder whose every layer is at most 32 wide (the reference's double_lattice_3D_small_network family): what the
+    wave-private merged kernel (fused_fwd_bwd_w32_kernel: a workgroup = ONE wave with 32 points) takes.  2-5 hidden layers of 16 ... 32
+    columns, any / no skip layer (also in front of the output layer), dropout, weight norm, use_tanh, 2-D / 3-D, scenes of 32 ... 1000
+    samples (multiples of 32 and not, so both segment mode and the ragged path)."""
+    import random
+    rng = random.Random(7000 + seed)
+    nh = rng.randint(2, 5)
+    G = rng.choice([2, 3, 3])
+    L = rng.choice([1, 2, 3, 5, 8])
+    W0 = L + G
+    widths = [w for w in (16, 20, 24, 28, 32) if w - W0 >= 8]
+    dims = [rng.choice(widths) for _ in range(nh)]
+    latent_in = [] if rng.random() < 0.3 else [rng.randint(1, nh)]
+    wn = rng.random() < 0.8
+    norm_layers = sorted(rng.sample(range(nh + 1), rng.randint(1, nh + 1))) if wn else []
+    dropout = sorted(rng.sample(range(nh), rng.randint(0, nh)))
+    p = rng.choice([0.0, 0.2, 0.5]) if dropout else 0.0
+    B = rng.randint(1, 6)
+    S = rng.choice([32, 64, 96, 320, 992, 40, 100, 1000])
+    split = 2 if (B * S) % 2 == 0 and rng.random() < 0.3 else 1
+    net = dict(dims=dims, dropout=dropout, dropout_prob=p, norm_layers=norm_layers, latent_in=latent_in, weight_norm=wn,
+               use_tanh=rng.random() < 0.3, geom_dimension=G)
+    return dict(L=L, B=B, S=S, split=split, net=net)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_wave_private_kernel_vs_oracle_and_the_four_wave_kernels(seed, monkeypatch):
+    """Nets of at most 32-wide layers train on the wave-private merged kernel at every batch size.  One optimiser step of seeded random
+    such nets against the float64 oracle, segment and ragged -- and the same step with DSDF_NO_W32=1 (the 64-row narrow kernels /
+    32-row four-wave workgroups) must agree with it to fp32 summation order: same loss, gradients, parameters."""
+    c = _random_w32_case(seed)
+    L, B, S, G = c["L"], c["B"], c["S"], c["net"]["geom_dimension"]
+    monkeypatch.delenv("DSDF_FROWS", raising=False)
+    monkeypatch.delenv("DSDF_NO_NARROW", raising=False)
+    net = orc.make_net(L, **c["net"])
+    spec = spec_from_meta(dict(L=L, net_specs=c["net"]))
+    params = orc.init_params(net, 7200 + seed)
+    lat0 = torch.randn(B, L, generator=torch.Generator().manual_seed(7300 + seed)) / math.sqrt(L)
+    lat0[-1] *= 1.7 / lat0[-1].norm()                    # one row above the max-norm bound
+    st64 = orc.TrainState.create({k: v.double() for k, v in params.items()}, lat0.double())
+    idx, xyz, gt = _safe_batch(net, st64, B, S, 7400 + seed, 0.1, 1.0, 79, G=G)
+    r64 = orc.train_step(net, st64, idx, xyz.double(), gt.double(), delta=0.1, code_bound=1.0, epoch=130, seed=79, batch_split=c["split"])
+    for kw in ({}, dict(force_ragged=True)):
+        res = {}
+        for no_w32 in (False, True):
+            monkeypatch.delenv("DSDF_NO_W32", raising=False)
+            if no_w32:
+                monkeypatch.setenv("DSDF_NO_W32", "1")
+            tr = HipTrainer(spec, params, lat0)
+            rh = tr.step(idx, xyz, gt, delta=0.1, code_bound=1.0, code_reg=True, lam=1e-4, epoch=130, lr=(5e-4, 1e-3), seed=79,
+                         batch_split=c["split"], **kw)
+            what = (seed, c, kw, no_w32)
+            assert abs(rh["loss"] - r64["loss"]) <= 1e-5 * abs(r64["loss"]), what
+            for k in r64["grads"]:
+                assert rel_err(rh["grads"][k], r64["grads"][k]) <= GRAD_TOL, (k, what)
+                assert worst_elem(rh["grads"][k], r64["grads"][k]) <= GRAD_ELEM_TOL, (k, what)
+            assert rel_err(rh["dlat"], r64["dlat"]) <= GRAD_TOL, what
+            P = tr.params()
+            for k in st64.params:
+                assert rel_err(P[k], st64.params[k]) <= 5e-5, (k, what)
+            assert rel_err(tr.lat.cpu(), st64.latents) <= 5e-5, what
+            res[no_w32] = rh
+        for k in res[False]["grads"]:
+            assert rel_err(res[False]["grads"][k], res[True]["grads"][k]) <= 1e-5, (k, seed, kw)
+        assert abs(res[False]["loss"] - res[True]["loss"]) <= 2e-6 * abs(res[True]["loss"]), (seed, kw)
+    monkeypatch.delenv("DSDF_NO_W32", raising=False)
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_random_specs_gemm_split_vs_oracle(seed):
     """The same random decoders with NetworkSpecs gemm_split (the fused kernels' hidden GEMMs as 6 bf16 MFMAs on 3-way cut fp32
