@@ -1014,6 +1014,7 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
       d.HS = at<float>(ws, P.hs_off); d.ldh = P.ldh; d.hstride = P.hstride;
       // (block counts of the launch-of-its-own form; the riding form below has its own)
       q.dw_n = (d.out[0] + SDW_ROWS_WIDE - 1) / SDW_ROWS_WIDE + (ks > 0 ? (d.out[1] + SDW_ROWS_WIDE - 1) / SDW_ROWS_WIDE : 0);
+      if (seg_dw_long_form(d.wg_per_seg, d.out[0], d.out[1])) q.dw_n = d.out[0] + d.out[1];      // long segments, narrow layers: one row per block (seg_dw_row_body)
     }
     SegLatArgs& g = q.lat;   // per-segment latent gradient from the column sums of dP_0 / dP_skip
     g.cs0 = at<float>(ws, P.cs_off[0]); g.ldcs = P.ldcs; g.out0 = net->out_dim[0];

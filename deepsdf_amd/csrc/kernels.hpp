@@ -1181,6 +1181,86 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const ReduceRowsArgs a
 
 // Segment mode: everything that consumes only the fused backward's per-workgroup partials, in ONE launch -- the head's
 // second reduction stage, the hoisted layers' x0 weight-gradient columns and the per-segment latent gradient.
+// The same for LONG segments in a launch of its own (hundreds of workgroups per scene: the reference's 10 x 16000 batches; round 4:
+// the 8-rows-per-block form above walked a 4 x 32 net's 5000 workgroups in 8 blocks -- 56 us, the step's second-largest launch): ONE
+// output row per block, out[0] + out[1] blocks.  The 256 threads walk a segment's workgroups together, eight segments per pass (all
+// their loads in flight, one pair of barriers), fixed-order sums; the latent products in segment order as above.
+// (host and device decide alike.  Narrow layers only: at 512 rows the 1024 one-row blocks fetch every partial line eight times over --
+// the shipped 8 x 512 shapes measured +70 us per 13.4 ms step with it)
+__host__ __device__ inline bool seg_dw_long_form(int wg_per_seg, int out0, int out1) { return wg_per_seg > 16 && out0 + out1 <= 256; }
+constexpr int SDWR_SB = 8;
+__device__ __forceinline__ void seg_dw_row_body(const SegDwArgs& p, int bidx, float* lds) {
+  float (*red)[SDWR_SB] = reinterpret_cast<float (*)[SDWR_SB]>(lds);     // [4 waves][segments of a pass]
+  float (*xred)[4] = reinterpret_cast<float (*)[4]>(lds + 4 * SDWR_SB);  // [4 waves][4]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int i = bidx, t = 0;
+  if (i >= p.out[0]) { i -= p.out[0]; t = 1; }
+  const float* cs = p.cs[t] + i;
+  const float* xs = p.xsum[t] + i;
+  float* hs = p.HS + (size_t)t * p.hstride + (size_t)i * p.ldh;
+  // xyz columns: every workgroup's sums, four workgroups per thread and pass in flight (unconditional loads on clamped rows)
+  float xa[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int wg0 = tid; wg0 < p.nwg; wg0 += 4 * 256) {
+    float tx[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tx[u][j] = xs[((size_t)min(wg0 + 256 * u, p.nwg - 1) * 4 + j) * p.ldcs];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xa[j] += (wg0 + 256 * u < p.nwg && j < p.G) ? tx[u][j] : 0.f;
+  }
+  constexpr int NC = HOIST_MAXL / 256;
+  float acc[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) acc[k] = 0.f;
+  const float* lat = p.zr != nullptr ? p.zr : p.table;
+  const int wps = p.wg_per_seg;
+  for (int s0 = 0; s0 < p.R; s0 += SDWR_SB) {
+    float a[SDWR_SB];
+#pragma unroll
+    for (int u = 0; u < SDWR_SB; ++u) {
+      const size_t base = (size_t)min(s0 + u, p.R - 1) * wps;
+      float v = 0.f;
+      for (int g = tid; g < wps; g += 256) v += cs[(base + g) * p.ldcs];
+      a[u] = s0 + u < p.R ? v : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < SDWR_SB; ++u) a[u] = wave_sum(a[u]);
+    __syncthreads();                       // (red is free: the previous pass has read it)
+    if (lane == 0)
+#pragma unroll
+      for (int u = 0; u < SDWR_SB; ++u) red[w][u] = a[u];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < SDWR_SB; ++u) {
+      const int sg = s0 + u;
+      if (sg < p.R) {
+        const float tot = (red[0][u] + red[1][u]) + (red[2][u] + red[3][u]);
+        const long long srow = p.zr != nullptr ? (long long)sg * p.L : (long long)p.seg_scene[sg] * p.L;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          const int c = tid + 256 * k;
+          if (c < p.L) acc[k] = fmaf(tot, lat[srow + c], acc[k]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const int c = tid + 256 * k;
+    if (c < p.L) hs[c] = acc[k];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) xa[j] = wave_sum(xa[j]);
+  if (lane == 0)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xred[w][j] = xa[j];
+  __syncthreads();
+  if (tid < p.G) hs[p.L + tid] = (xred[0][tid] + xred[1][tid]) + (xred[2][tid] + xred[3][tid]);
+}
+
 struct PostBwdArgs {
   ReduceRowsArgs rr; int rr_bx, rr_n;        // blocks [0, rr_n): (bx, g) = (i % rr_bx, i / rr_bx)
   SegDwArgs dw; int dw_n;                    // next dw_n blocks (0: weights frozen)
@@ -1200,7 +1280,13 @@ __device__ __forceinline__ void post_bwd_role(const PostBwdArgs& p, int i, int l
     return;
   }
   i -= p.rr_n;
-  if (i < p.dw_n) { seg_dw_body<RIDE ? SDW_ROWS_RIDE : SDW_ROWS_WIDE>(p.dw, i, lds); return; }
+  if (i < p.dw_n) {
+    if constexpr (!RIDE) {
+      if (seg_dw_long_form(p.dw.wg_per_seg, p.dw.out[0], p.dw.out[1])) { seg_dw_row_body(p.dw, i, lds); return; }
+    }
+    seg_dw_body<RIDE ? SDW_ROWS_RIDE : SDW_ROWS_WIDE>(p.dw, i, lds);
+    return;
+  }
   i -= p.dw_n;
   if constexpr (RIDE) seg_latgrad_all_body(p.lat, i, lat_n, lds);
   else seg_latgrad_body(p.lat, i % p.lat_bx, i / p.lat_bx, lds);
