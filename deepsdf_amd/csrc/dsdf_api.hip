@@ -574,12 +574,18 @@ bool net_narrow(const DsdfNet* net) {
 // one shape x 8000 points).  DSDF_FROWS=64 switches it off (A/B).
 // merged: the training step's one-launch forward + backward.  Nets of at most 32-wide layers take it WAVE-PRIVATE at every batch size
 // (32 points per one-wave workgroup, fused_fwd_bwd_w32_kernel; DSDF_NO_W32=1: the 64-row narrow kernels instead).
-bool w32_wanted(const DsdfNet* net) {
-  if (!net_narrow(net) || getenv("DSDF_NO_W32")) return false;
-  for (int l = 0; l < net->n_layers; ++l)
-    if (net->in_dim[l] > FWW || (l < net->n_layers - 1 && net->out_dim[l] > FWW)) return false;
-  return true;
+int w32_width(const DsdfNet* net) {      // 0: no; 32 / 64: the wave-private kernel for nets of at most that width
+  if (!net_narrow(net) || getenv("DSDF_NO_W32")) return 0;
+  int wmax = 0;
+  for (int l = 0; l < net->n_layers; ++l) {
+    wmax = std::max(wmax, net->in_dim[l]);
+    if (l < net->n_layers - 1) wmax = std::max(wmax, net->out_dim[l]);
+  }
+  if (wmax <= FWW) return FWW;
+  if (wmax <= FWW2 && !getenv("DSDF_NO_W32X2")) return FWW2;
+  return 0;
 }
+bool w32_wanted(const DsdfNet* net) { return w32_width(net) != 0; }
 int pick_frows(const DsdfNet* net, int64_t n, bool merged = false) {
   const char* e = getenv("DSDF_FROWS");      // read per call: the tests switch it inside one process
   const bool off = e && !strcmp(e, "64");
@@ -967,7 +973,8 @@ int run_backward_fused(const DsdfNet* net, const Plan& P, void* ws, const float*
       if (net->fwd_bf16 && net->gemm_split) hipLaunchKernelGGL(fused_fwd_bf16_bwd_split_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
       else if (net->fwd_bf16) hipLaunchKernelGGL(fused_fwd_bf16_bwd_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
       else if (net->gemm_split) hipLaunchKernelGGL(fused_fwd_bwd_split_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
-      else if (P.frows == 32 && w32_wanted(net)) hipLaunchKernelGGL(fused_fwd_bwd_w32_kernel, dim3((unsigned)P.nwg), dim3(64), 0, st, *fwd, a);
+      else if (P.frows == 32 && w32_width(net) == FWW) hipLaunchKernelGGL(fused_fwd_bwd_w32_kernel, dim3((unsigned)P.nwg), dim3(64), 0, st, *fwd, a);
+      else if (P.frows == 32 && w32_width(net) == FWW2) hipLaunchKernelGGL(fused_fwd_bwd_w32x2_kernel, dim3((unsigned)P.nwg), dim3(64), 0, st, *fwd, a);
       else if (P.frows == 32) hipLaunchKernelGGL(fused_fwd_bwd_h32_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
       else if (net_narrow(net)) hipLaunchKernelGGL(fused_fwd_bwd_n128_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);
       else hipLaunchKernelGGL(fused_fwd_bwd_kernel, dim3((unsigned)P.nwg), dim3(256), 0, st, *fwd, a);

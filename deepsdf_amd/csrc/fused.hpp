@@ -38,14 +38,18 @@ constexpr int FROWS = 64;        // points per workgroup
 constexpr int FLD = 516;         // slab row stride in floats
 constexpr int FMAXW = 512;       // widest layer the fused kernels handle
 constexpr int FLDN = 132, FNW = 128;   // narrow-net kernels (every layer <= FNW wide): slab row stride in floats
-constexpr int FLDW = 36, FWW = 32;     // wave-private kernel (every layer <= FWW wide)
-// Waves per workgroup: 4 -- or ONE in the wave-private narrow-net kernel (fused_fwd_bwd_w32_kernel), whose bodies are the
-// (32 rows, FLDW) instantiations: that wave owns every n-tile of its 32 rows (n-tile index = ni instead of w + 4 ni).
-__host__ __device__ constexpr int fused_nw(int rows, int ldsw) { return rows == 32 && ldsw == FLDW ? 1 : 4; }
+constexpr int FLDW = 36, FWW = 32;     // wave-private kernels: every layer <= 32 wide (one n-tile per wave) ...
+constexpr int FLDW2 = 68, FWW2 = 64;   // ... or <= 64 wide (two)
+// Waves per workgroup: 4 -- or ONE in the wave-private narrow-net kernels (fused_fwd_bwd_w32_kernel / _w32x2_kernel), whose bodies are
+// the (32 rows, FLDW / FLDW2) instantiations: that wave owns every n-tile of its 32 rows (n-tile index = ni instead of w + 4 ni).
+__host__ __device__ constexpr int fused_nw(int rows, int ldsw) { return rows == 32 && (ldsw == FLDW || ldsw == FLDW2) ? 1 : 4; }
                   //                     8 = no global activation stores in the forward epilogue
 #ifndef W32_WAVES
 #define W32_WAVES 3                // waves per SIMD the wave-private kernel is compiled for (168 registers; measured on the 4 x 32 spec:
                                    // 2 -> 92.9 us, 3 -> 84.5 us, 4 -> 157 us with 216 B of scratch)
+#endif
+#ifndef W32X2_WAVES
+#define W32X2_WAVES 2              // ... the two-n-tile form
 #endif
 #ifndef FUSED_STORE_AUX
 #define FUSED_STORE_AUX 2          // cache policy of the activation / dP copies (lab: 2 = nt, 16 = sc1 write-through)
@@ -847,8 +851,11 @@ __device__ __forceinline__ void fused_kloop_dispatch(f32x16 (&acc)[MT][NT], cons
         case 1: fused_kloop<1, MT, NT, LDSW>(acc, ap, bv, nu, PB); break;
         default: break;
       }
+    } else if constexpr (NT == 2) {
+      if (nact >= 2) fused_kloop<2, MT, NT, LDSW>(acc, ap, bv, nu, PB);
+      else if (nact == 1) fused_kloop<1, MT, NT, LDSW>(acc, ap, bv, nu, PB);
     } else {
-      static_assert(NT == 1, "n-tiles per wave: 4 or 1");
+      static_assert(NT == 1, "n-tiles per wave: 4, 2 or 1");
       if (nact == 1) fused_kloop<1, MT, NT, LDSW>(acc, ap, bv, nu, PB);
     }
   }
@@ -1896,6 +1903,19 @@ __global__ __launch_bounds__(64, W32_WAVES) void fused_fwd_bwd_w32_kernel(const 
   fused_forward_body<false, 1, 1, FLDW, FWW>(f, S, xs, hu, hwx, 48 * 1024);
   __syncthreads();
   fused_backward_body<false, 1, 1, FLDW, FWW>(b, S, xs, hred, hsc, true);
+}
+// ... the same for nets of at most 64-wide layers (the reference's 4 x 64 spec): two n-tiles per wave, slab row stride 68
+__global__ __launch_bounds__(64, W32X2_WAVES) void fused_fwd_bwd_w32x2_kernel(const FusedFwdArgs f, const FusedBwdArgs b) {
+  __shared__ __attribute__((aligned(16))) float S[32 * FLDW2];
+  __shared__ float4 xs[32];
+  __shared__ float4 scratch[FHOIST * FWW2 + FHOIST * FWW2 / 4];      // hu [2][64] floats + hwx [2][64] float4
+  float (*hu)[FWW2] = reinterpret_cast<float (*)[FWW2]>(scratch);
+  float4 (*hwx)[FWW2] = reinterpret_cast<float4 (*)[FWW2]>(scratch + FHOIST * FWW2 / 4);
+  float (*hred)[2 * FWW2] = reinterpret_cast<float (*)[2 * FWW2]>(scratch);      // (unused: one wave)
+  float (*hsc)[2] = reinterpret_cast<float (*)[2]>(scratch + 2 * FWW2 / 4);
+  fused_forward_body<false, 1, 2, FLDW2, FWW2>(f, S, xs, hu, hwx, 48 * 1024);
+  __syncthreads();
+  fused_backward_body<false, 1, 2, FLDW2, FWW2>(b, S, xs, hred, hsc, true);
 }
 // ... for narrow nets (see fused_forward_n128_kernel): two workgroups per CU
 __global__ __launch_bounds__(256, 2) void fused_fwd_bwd_n128_kernel(const FusedFwdArgs f, const FusedBwdArgs b) {

@@ -631,7 +631,8 @@ def _random_w32_case(seed):
     G = rng.choice([2, 3, 3])
     L = rng.choice([1, 2, 3, 5, 8])
     W0 = L + G
-    widths = [w for w in (16, 20, 24, 28, 32) if w - W0 >= 8]
+    # seeds >= 16: layers of up to 64 columns (the corner_spheres_only_small_network family): the two-n-tile form, fused_fwd_bwd_w32x2_kernel
+    widths = [w for w in ((16, 20, 24, 28, 32) if seed < 16 else (24, 32, 40, 48, 56, 64, 64)) if w - W0 >= 8]
     dims = [rng.choice(widths) for _ in range(nh)]
     latent_in = [] if rng.random() < 0.3 else [rng.randint(1, nh)]
     wn = rng.random() < 0.8
@@ -646,9 +647,9 @@ def _random_w32_case(seed):
     return dict(L=L, B=B, S=S, split=split, net=net)
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(28))
 def test_wave_private_kernel_vs_oracle_and_the_four_wave_kernels(seed, monkeypatch):
-    """Nets of at most 32-wide layers train on the wave-private merged kernel at every batch size.  One optimiser step of seeded random
+    """Nets of at most 32-wide (seeds 16 ...: 64-wide) layers train on the wave-private merged kernels at every batch size.  One optimiser step of seeded random
     such nets against the float64 oracle, segment and ragged -- and the same step with DSDF_NO_W32=1 (the 64-row narrow kernels /
     32-row four-wave workgroups) must agree with it to fp32 summation order: same loss, gradients, parameters."""
     c = _random_w32_case(seed)
