@@ -843,14 +843,19 @@ def test_random_specs_phased_backward_equals_the_single_call(seed):
     assert rel_err(ph.dlat.cpu(), one.dlat.cpu()) <= 1e-6, (seed, K, c)
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", list(range(8)) + ["w32_3", "w32_6", "w32_9", "w32_17", "w32_21", "w32_26"])
 def test_random_specs_reconstruction_vs_oracle(seed):
     """Latent-only reconstruction (frozen decoder, eval mode, Adam on the codes: BASELINE config 4's path) on the random decoders and
     shape counts: three iterations of reconstruct() against oracle.latent_step in float64, every shape following its own single-code
-    trajectory -- sample counts on and off the 32-point grid (segment mode / the ragged frozen path)."""
+    trajectory -- sample counts on and off the 32-point grid (segment mode / the ragged frozen path).  The w32_* cases are nets of at
+    most 32- / 64-wide layers (_random_w32_case): the frozen-decoder form of the wave-private kernels."""
     from deepsdf_amd.engine import Engine
     from deepsdf_amd.reconstruct import reconstruct
-    c = _random_case(500 + seed)
+    if isinstance(seed, str):
+        c = _random_w32_case(int(seed.split("_")[1]))
+        seed = 40 + int(seed.split("_")[1])
+    else:
+        c = _random_case(500 + seed)
     L, B, S, G = c["L"], c["B"], c["S"], c["net"]["geom_dimension"]
     net = orc.make_net(L, **c["net"])
     params = orc.init_params(net, 250 + seed)
